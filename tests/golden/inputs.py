@@ -1,0 +1,26 @@
+"""Reference-free, deterministic input builders shared by make_golden.py and the tests."""
+import numpy as np
+
+
+def planted_inputs(Ns, Nd, C, seed, B=1):
+    """Each src row = c_i * dst_pi(i) + s_i * e_i_perp with strictly spaced c_i:
+    argmax and rank order are separated by far more than fp32 rounding.  Deterministic numpy code shared by
+    make_golden.py and the tests."""
+    rng = np.random.default_rng(seed)
+    out_a, out_b = [], []
+    for b in range(B):
+        dst = rng.standard_normal((Nd, C))
+        dst /= np.linalg.norm(dst, axis=1, keepdims=True)
+        pi = rng.integers(0, Nd, size=Ns)
+        c = np.linspace(0.99, 0.55, Ns)
+        rng.shuffle(c)
+        e = rng.standard_normal((Ns, C))
+        d = dst[pi]
+        e -= (e * d).sum(1, keepdims=True) * d
+        e /= np.linalg.norm(e, axis=1, keepdims=True)
+        src = c[:, None] * d + np.sqrt(1 - c * c)[:, None] * e
+        src *= rng.uniform(0.5, 2.0, size=(Ns, 1))
+        dscale = rng.uniform(0.5, 2.0, size=(Nd, 1))
+        out_a.append(src.astype(np.float32))
+        out_b.append((dst * dscale).astype(np.float32))
+    return np.stack(out_a), np.stack(out_b)
