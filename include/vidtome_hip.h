@@ -1,0 +1,187 @@
+/*
+ * vidtome_hip.h -- C ABI of libvidtome_hip.so: the MI355X (gfx950) implementation of VidToMe's
+ * cross-frame token-merging hot path.
+ *
+ * Every entry point replaces a piece of the reference's Python hot path (the reference has no
+ * native code; "binding" = the ctypes stub in vidtome_amd/_lib.py).
+ * Citations are file:line under the reference checkout (/root/reference).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
+ *   - the caller allocates every input, output and workspace (e.g. through PyTorch's caching
+ *     allocator); the library is stateless, never allocates or frees device memory and never
+ *     synchronises the device;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - every call returns 0 on success or a negative VTM_E* code; vtm_last_error() returns a
+ *     thread-local description of the last failure;
+ *   - index arrays are int32 (the reference uses int64 tensors; values are identical);
+ *   - token tensors are row-major (B, rows, C) in the model dtype (VTM_F16 / VTM_BF16 / VTM_F32).
+ *
+ * Canonical arithmetic of the matching path (bitwise equal to oracle/vtm_oracle.c):
+ *   tokens upcast to fp32; norm = sqrtf(k-ascending fmaf chain of x*x); xhat = x / norm (IEEE
+ *   divide); score = k-ascending fmaf chain from +0 (v_mfma_f32_32x32x2_f32 is exactly that chain);
+ *   row max = first index among equals, first NaN wins; sort = descending, NaN first, ties by
+ *   ascending index.
+ */
+#ifndef VIDTOME_HIP_H
+#define VIDTOME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTM_ABI_VERSION 1
+
+enum vtm_dtype { VTM_F32 = 0, VTM_F16 = 1, VTM_BF16 = 2 };
+
+enum vtm_status {
+    VTM_OK = 0,
+    VTM_EINVAL = -1,   /* bad argument (null pointer, negative size, unsupported dtype/shape) */
+    VTM_ELAUNCH = -2,  /* HIP launch / runtime error (message in vtm_last_error) */
+    VTM_EWORKSPACE = -3 /* workspace too small */
+};
+
+typedef void *vtm_stream_t; /* hipStream_t */
+
+int vtm_version(void);
+const char *vtm_last_error(void);
+
+/* Tile geometry the operand matrices of vtm_match must be padded to (rows to VTM_MATCH_ROW_PAD,
+ * channels to VTM_MATCH_K_PAD). */
+#define VTM_MATCH_ROW_PAD 128
+#define VTM_MATCH_K_PAD 32
+int64_t vtm_pad_rows(int64_t n);
+int64_t vtm_pad_k(int64_t C);
+
+/* ------------------------------------------------------------------------------------------------
+ * vtm_normalize_gather -- replaces `metric / metric.norm(dim=-1, keepdim=True)` fused with `split`
+ * (vidtome/merge.py:76-85 and 383-390).
+ * The token pool is two row segments: x0 = the joined chunk (B, P0, C) and x1 = the block's global
+ * anchor tokens (B, P1, C) (x1 may be NULL when P1 == 0); pool row id p < P0 addresses x0, else x1.
+ * rows (B, n) int32 are pool row ids.  out (B, n_pad, C_pad) fp32 receives the normalised rows in the
+ * operand layout of vtm_match: within every group of 8 channels the order is [0,2,4,6,1,3,5,7]
+ * (so one 16-byte LDS read feeds four consecutive v_mfma_f32_32x32x2_f32 k-steps in ascending k
+ * order); rows >= n and channels >= C are zero.  norms (B, n) fp32 receives the row norms (it doubles
+ * as the scratch between the two kernels of the call).
+ * ---------------------------------------------------------------------------------------------- */
+int vtm_normalize_gather(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                         int64_t C, const int32_t *rows, int64_t n, float *norms, float *out,
+                         int64_t n_pad, int64_t C_pad, vtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * vtm_match -- replaces `scores = a @ b.transpose(-1,-2)` + `scores.max(dim=-1)`
+ * (vidtome/merge.py:87,109-113 and 392,413-417) and, with align != 0, the aligned variant
+ * `torch.cat([*scores], dim=-1).max(dim=-1)` (merge.py:93-97 / 397-401).  The (B, Ns, Nd) score
+ * matrix is never materialised.
+ * a (B, Ns_pad, C_pad), b (B, Nd_pad, C_pad): outputs of vtm_normalize_gather.
+ * best: (B, Ns) uint64 when align == 0, (Ns) when align != 0.  Each entry is a packed key
+ *     (orderable(node_max) << 32) | ~node_idx
+ * whose unsigned maximum implements "largest value, first index, first NaN wins"; node_idx is in
+ * [0, Nd) (align == 0) or [0, B*Nd) (align != 0, concatenated dst axis).  The call zero-fills
+ * `best` itself.  Decode with vtm_decode_best.
+ * ---------------------------------------------------------------------------------------------- */
+int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd, int64_t Ns_pad,
+              int64_t Nd_pad, int64_t C_pad, int align, uint64_t *best, vtm_stream_t stream);
+
+/* node_max (fp32, -0 canonicalised to +0) and node_idx (int32) out of packed keys; either output may
+ * be NULL. */
+int vtm_decode_best(const uint64_t *best, int64_t n, float *node_max, int32_t *node_idx,
+                    vtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * vtm_sort_desc -- replaces `node_max.argsort(dim=-1, descending=True)` (merge.py:98,113 / 402,417)
+ * with the canonical stable order (descending value, NaN first, ties by ascending index).
+ * best (rows, n) packed keys from vtm_match -> perm (rows, n) int32.
+ * ws: workspace of at least vtm_sort_ws_bytes(rows, n) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+size_t vtm_sort_ws_bytes(int64_t rows, int64_t n);
+int vtm_sort_desc(const uint64_t *best, int64_t rows, int64_t n, int32_t *perm, void *ws,
+                  size_t ws_bytes, vtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index planning (all tiny, int32, device-resident; no host round trips).
+ *
+ * vtm_partition_local -- the src/dst partition of bipartite_soft_matching_randframe
+ * (merge.py:41-74): tnum = (N_in - unm_pre) / F is passed in; ts = min(target_stride, F);
+ * randf is the value of the reference's `torch.randint(0, ts, [1], generator=...)` draw (the host
+ * draws it from the same CPU generator).  cur (B, N_in) holds the pool row id of every token of the
+ * current sequence (NULL = identity, i.e. the first level).  Outputs: a_pos (Ns) / b_pos (Nd) =
+ * a_idx / b_idx of the reference, a_rows (B, Ns) / b_rows (B, Nd) = cur gathered at those positions.
+ * Ns / Nd must be the counts vtm_partition_counts returns.
+ * ---------------------------------------------------------------------------------------------- */
+int vtm_partition_counts(int64_t N_in, int64_t unm_pre, int64_t tnum, int64_t ts, int64_t randf,
+                         int64_t *Ns, int64_t *Nd); /* host-only helper */
+int vtm_partition_local(const int32_t *cur, int64_t B, int64_t N_in, int64_t unm_pre, int64_t tnum,
+                        int64_t ts, int64_t randf, int32_t *a_pos, int32_t *b_pos, int32_t *a_rows,
+                        int32_t *b_rows, int64_t Ns, int64_t Nd, vtm_stream_t stream);
+
+/* vtm_partition_global -- bipartite_soft_matching_2s's split (merge.py:374-375) for the sequence
+ * `cat([local, global])` (local_is_src != 0, patch.py:63-66) or `cat([global, local])`
+ * (patch.py:68-71).  cur_local (B, Ml) pool ids of the local merged tokens; the anchors are pool
+ * rows [anchor_base, anchor_base + Mg).  Outputs a_pos/b_pos/a_rows/b_rows as above with
+ * Ns = src_len, Nd = Ml + Mg - src_len. */
+int vtm_partition_global(const int32_t *cur_local, int64_t B, int64_t Ml, int64_t anchor_base,
+                         int64_t Mg, int local_is_src, int32_t *a_pos, int32_t *b_pos,
+                         int32_t *a_rows, int32_t *b_rows, vtm_stream_t stream);
+
+/* vtm_plan_apply -- the index split after the sort (merge.py:100-117 / 404-421) and the bookkeeping
+ * of the merge / unmerge closures (merge.py:119-155 / 423-460) as composed maps:
+ *   unm_idx = perm[r:], src_idx = perm[:r], dst_idx = node_idx[src_idx] (% Nd when align);
+ *   new_cur (B, U + Nd), U = Ns - r: pool ids of `cat([unm, dst])`  (the merge closure);
+ *   inv (B, N_in): position in the merged sequence each input position is restored from
+ *                  (the unmerge closure: dst -> itself, unm -> itself, src -> its dst).
+ * best/perm have one row when align != 0.  unm_idx/src_idx/dst_idx (B, U)/(B, r)/(B, r) are optional
+ * (NULL to skip) copies of the reference's index tensors. */
+int vtm_plan_apply(const uint64_t *best, const int32_t *perm, const int32_t *a_pos,
+                   const int32_t *b_pos, const int32_t *a_rows, const int32_t *b_rows, int64_t B,
+                   int64_t N_in, int64_t Ns, int64_t Nd, int64_t r, int align, int32_t *new_cur,
+                   int32_t *inv, int32_t *unm_idx, int32_t *src_idx, int32_t *dst_idx,
+                   vtm_stream_t stream);
+
+/* vtm_compose -- func_warper composition of unmerge closures (vidtome/utils.py:42-48, patch.py:85):
+ * out[b, i] = inv_level[b, offset + inv_acc[b, i]] for i < n (inv_acc NULL = identity).  `offset`
+ * selects the part bipartite_soft_matching_2s's unmerge returns (merge.py:459). */
+int vtm_compose(const int32_t *inv_acc, const int32_t *inv_level, int64_t B, int64_t n,
+                int64_t level_len, int64_t offset, int32_t *out, vtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * vtm_gather_rows -- the composed `merge` closure in replace mode (merge.py:119-133 / 423-437,
+ * patch.py:52,76) and the global-token update `u(merged_tokens)` (patch.py:80):
+ * out[b, p, :] = pool[b, map[b, p], :], pool = (x0 | x1) as in vtm_normalize_gather.  out is
+ * (B, out_rows, C) with out_rows >= M (rows >= M are not written: callers pad merged sequences to a
+ * multiple of 8 rows so the projection GEMMs keep 16-byte aligned leading dimensions).
+ * ---------------------------------------------------------------------------------------------- */
+int vtm_gather_rows(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                    int64_t C, const int32_t *map, int64_t M, void *out, int64_t out_rows,
+                    vtm_stream_t stream);
+
+/* vtm_unmerge_add -- the composed `unmerge` closure + split_frame + residual
+ * (merge.py:135-155 / 439-460, vidtome/utils.py:37-40, patch.py:168-169):
+ * out[b, i, :] = y[b, inv[b, i], :] (+ resid[b, i, :] when resid != NULL).  y is (B, M, C). */
+int vtm_unmerge_add(const void *y, int64_t M, const int32_t *inv, const void *resid, int dtype,
+                    int64_t B, int64_t L, int64_t C, void *out, vtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * vtm_attention -- the self-attention core inside `self.attn1(...)` (patch.py:157-162) as stated by
+ * the reference's own `sa_forward` (utils/pnp_utils.py:47-95): per head
+ *     out = softmax(q k^T * scale) v,      no mask, no dropout.
+ * q, k, out: (B, Mp, h*d) buffers of which the first M rows per sample are the sequence (Mp >= M is
+ * the per-sample row count of the buffers), with row strides ldq/ldk/ldo elements (heads interleaved on the channel
+ * axis = head_to_batch_dim / batch_to_head_dim without the copies); vt: (B, h*d, ldvt) = v
+ * TRANSPOSED (channel-major, key-contiguous, ldvt >= M and a multiple of 8) so that the PV operand
+ * is read without a transpose.  dtype VTM_F16 or VTM_BF16; fp32 accumulation; d in {40,64,80,160}
+ * (any multiple of 8 up to 160).
+ * share_groups > 1 = the PnP injection branch (pnp_utils.py:57-67,86-90): probabilities of sample
+ * b come from q/k of sample b % (B / share_groups), v stays per sample.
+ * ---------------------------------------------------------------------------------------------- */
+int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt,
+                  int64_t ldvt, void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t M,
+                  int64_t Mp, int64_t d, float scale, int share_groups, vtm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDTOME_HIP_H */

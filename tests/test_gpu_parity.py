@@ -1,0 +1,397 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+(1) the CPU oracle on seeded inputs -- BITWISE for the matching / index path, 1e-3 for attention;
+(2) the golden vectors generated from the reference itself (tests/golden);
+(3) size-independent properties at BASELINE.json's full sizes."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import forked_generator_from_state, load_cases, load_chain
+from inputs import planted_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+IDX = ("a_idx", "b_idx", "unm_idx", "src_idx", "dst_idx")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from vidtome_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def _deinterleave(op, n, C):
+    """(B, n_pad, C_pad) k-interleaved operand -> (B, n, C) plain."""
+    B, n_pad, C_pad = op.shape
+    g = op.reshape(B, n_pad, C_pad // 8, 2, 4).permute(0, 1, 2, 4, 3).reshape(B, n_pad, C_pad)
+    return g[:, :n, :C]
+
+
+def _bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# primitives vs oracle
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_normalize_gather_bitwise(L, oracle, dtype):
+    g = torch.Generator().manual_seed(0)
+    B, P0, P1, C, n = 2, 300, 77, 40, 211
+    x0 = torch.randn(B, P0, C, generator=g).to(dtype)
+    x1 = torch.randn(B, P1, C, generator=g).to(dtype)
+    x0[1, 5] = 0          # zero row -> NaN
+    rows = torch.randint(0, P0 + P1, (B, n), generator=g, dtype=torch.int32)
+    rows[1, 3] = 5
+    op, norms = L.normalize_gather(x0.to(DEV), x1.to(DEV), rows.to(DEV))
+    pool = torch.cat([x0, x1], 1).float().numpy()
+    ref = oracle.normalize_gather(pool, rows.numpy())
+    got = _deinterleave(op, n, C).cpu().numpy()
+    assert np.array_equal(_bits(got), _bits(ref))
+    assert torch.count_nonzero(op[:, n:]) == 0 and torch.count_nonzero(op.reshape(B, -1, op.shape[2] // 8, 8)[:, :, C // 8:]) == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 29, 24), (3, 300, 513, 40), (1, 129, 128, 320), (2, 1000, 700, 64)])
+@pytest.mark.parametrize("align", [False, True])
+def test_match_bitwise(L, oracle, shape, align):
+    B, Ns, Nd, C = shape
+    rng = np.random.default_rng(Ns * 7 + Nd)
+    x = rng.standard_normal((B, Ns + Nd, C)).astype(np.float32)
+    x[:, Ns + Nd // 2] = x[:, Ns + 1]                 # duplicate dst rows -> exact ties, first index wins
+    ra = np.broadcast_to(np.arange(Ns, dtype=np.int32), (B, Ns)).copy()
+    rb = np.broadcast_to(np.arange(Ns, Ns + Nd, dtype=np.int32), (B, Nd)).copy()
+    a_op, _ = L.normalize_gather(_t(x), None, _t(ra))
+    b_op, _ = L.normalize_gather(_t(x), None, _t(rb))
+    best = L.match(a_op, b_op, Ns, Nd, align)
+    nm, ni = L.decode_best(best)
+    a = oracle.normalize_gather(x, ra)
+    b = oracle.normalize_gather(x, rb)
+    rm, ri = oracle.match(a, b, align)
+    rm = rm + np.float32(0.0)
+    assert np.array_equal(ni.cpu().numpy().reshape(ri.shape), ri)
+    assert np.array_equal(_bits(nm.cpu().numpy().reshape(rm.shape)), _bits(rm))
+
+
+def test_match_nan_semantics(L, oracle):
+    rng = np.random.default_rng(3)
+    B, Ns, Nd, C = 2, 70, 150, 16
+    x = rng.standard_normal((B, Ns + Nd, C)).astype(np.float32)
+    x[0, 5] = 0            # NaN src row -> (NaN, 0)
+    x[1, Ns + 40] = 0      # NaN dst row -> every src row of sample 1 -> (NaN, 40)
+    x[1, Ns + 90] = 0
+    ra = np.broadcast_to(np.arange(Ns, dtype=np.int32), (B, Ns)).copy()
+    rb = np.broadcast_to(np.arange(Ns, Ns + Nd, dtype=np.int32), (B, Nd)).copy()
+    a_op, _ = L.normalize_gather(_t(x), None, _t(ra))
+    b_op, _ = L.normalize_gather(_t(x), None, _t(rb))
+    for align in (False, True):
+        nm, ni = L.decode_best(L.match(a_op, b_op, Ns, Nd, align))
+        rm, ri = oracle.match(oracle.normalize_gather(x, ra), oracle.normalize_gather(x, rb), align)
+        assert np.array_equal(ni.cpu().numpy().reshape(ri.shape), ri)
+        assert np.array_equal(np.isnan(nm.cpu().numpy().reshape(rm.shape)), np.isnan(rm))
+        perm = L.sort_desc(L.match(a_op, b_op, Ns, Nd, align)).cpu().numpy()
+        assert np.array_equal(perm.reshape(rm.shape), oracle.sort_desc(rm))
+
+
+@pytest.mark.parametrize("n", [1, 17, 1000, 1024, 5000, 49152, 110592])
+def test_sort_desc(L, oracle, n):
+    rng = np.random.default_rng(n)
+    k = rng.standard_normal((2, n)).astype(np.float32)
+    if n > 20:
+        k[:, ::7] = k[:, 1::7][:, :k[:, ::7].shape[1]]     # exact ties
+        k[0, 3] = np.nan
+        k[1, 11] = -0.0
+        k[1, 12] = 0.0
+    # build packed keys the way vtm_match does
+    f = k + np.float32(0.0)
+    u = f.view(np.uint32).astype(np.uint64)
+    o = np.where(u & 0x80000000, (~u) & 0xFFFFFFFF, u | 0x80000000)
+    o = np.where(np.isnan(k), np.uint64(0xFFFFFFFF), o)
+    packed = (o << np.uint64(32)) | np.uint64(0x12345)
+    perm = L.sort_desc(_t(packed.view(np.int64))).cpu().numpy()
+    assert np.array_equal(perm, oracle.sort_desc(k))
+
+
+def test_gather_and_unmerge_add(L, oracle):
+    g = torch.Generator().manual_seed(5)
+    for dtype in (torch.float32, torch.float16, torch.bfloat16):
+        B, P0, P1, C, M, Ln = 2, 100, 30, 48, 77, 150
+        x0 = torch.randn(B, P0, C, generator=g).to(dtype)
+        x1 = torch.randn(B, P1, C, generator=g).to(dtype)
+        idx = torch.randint(0, P0 + P1, (B, M), generator=g, dtype=torch.int32)
+        out = L.gather_rows(x0.to(DEV), x1.to(DEV), idx.to(DEV), pad_to=8)
+        ref = torch.gather(torch.cat([x0, x1], 1), 1, idx.long()[..., None].expand(-1, -1, C))
+        assert out.shape[1] == 80 and torch.equal(out[:, :M].cpu(), ref) and torch.count_nonzero(out[:, M:]) == 0
+        inv = torch.randint(0, M, (B, Ln), generator=g, dtype=torch.int32)
+        resid = torch.randn(B, Ln, C, generator=g).to(dtype)
+        got = L.unmerge_add(out, inv.to(DEV), resid.to(DEV)).cpu()
+        exp = torch.gather(ref, 1, inv.long()[..., None].expand(-1, -1, C)) + resid
+        assert torch.equal(got, exp)
+
+
+# ---------------------------------------------------------------------------------------------------
+# matchers through the mirrored Python API vs golden vectors from the reference
+# ---------------------------------------------------------------------------------------------------
+def _cmp_info(info, c):
+    for n in IDX:
+        assert np.array_equal(info[n].cpu().numpy().astype(np.int64), c[n]), n
+
+
+def test_randframe_golden_gpu(L):
+    from vidtome_amd import merge
+    for c in load_cases("randframe.npz"):
+        torch.manual_seed(int(c["seed"]))
+        gen = torch.Generator(device="cpu").set_state(torch.get_rng_state())
+        x = _t(c["x"])
+        m, u, info = merge.bipartite_soft_matching_randframe(x, int(c["F"]), float(c["ratio"]), int(c["unm_pre"]),
+                                                             gen, int(c["stride"]), bool(c["align"]))
+        assert info["unm_num"] == c["unm_num"]
+        if c["noop"]:
+            assert m is merge.do_nothing and u is merge.do_nothing
+            continue
+        _cmp_info(info, c)
+        assert np.array_equal(m(x).cpu().numpy(), c["merged"])
+        assert np.array_equal(u(_t(c["y"])).cpu().numpy(), c["unmerged"])
+
+
+def test_2s_golden_gpu(L):
+    from vidtome_amd import merge
+    for c in load_cases("twos.npz"):
+        x = _t(c["x"])
+        m, u, info = merge.bipartite_soft_matching_2s(x, int(c["src_len"]), float(c["ratio"]), bool(c["align"]),
+                                                      unmerge_chunk=int(c["unmerge_chunk"]))
+        _cmp_info(info, c)
+        assert np.array_equal(m(x).cpu().numpy(), c["merged"])
+        assert np.array_equal(u(_t(c["y"])).cpu().numpy(), c["unmerged"])
+    assert len(merge.bipartite_soft_matching_2s(_t(load_cases("twos.npz")[0]["x"]), 40, 0.0, False)) == 2  # merge.py:364-365
+
+
+def test_nan_and_kat_golden_gpu(L):
+    from vidtome_amd import merge
+    nan_c, kat = load_cases("misc.npz")
+    torch.manual_seed(int(nan_c["seed"]))
+    gen = torch.Generator(device="cpu").set_state(torch.get_rng_state())
+    _, _, info = merge.bipartite_soft_matching_randframe(_t(nan_c["x"]), int(nan_c["F"]), float(nan_c["ratio"]), 0, gen)
+    _cmp_info(info, nan_c)
+    for align, sfx in ((False, ""), (True, "_al")):
+        gen = torch.Generator().manual_seed(123)
+        _, _, info = merge.bipartite_soft_matching_randframe(_t(kat["x"]), 4, 0.5, 0, gen, 4, align)
+        for n in ("unm_idx", "src_idx", "dst_idx"):
+            assert np.array_equal(info[n].cpu().numpy(), kat[n + sfx]), n
+
+
+def _planted_gpu(c):
+    from vidtome_amd import merge
+    a, b = planted_inputs(int(c["Ns"]), int(c["Nd"]), int(c["C"]), seed=int(c["seed"]))
+    F, randf = int(c["F"]), int(c["randf"])
+    Ltot = a.shape[1] + b.shape[1]
+    tnum = Ltot // F
+    x = np.empty((1, Ltot, a.shape[2]), np.float32)
+    is_dst = (np.arange(Ltot) // tnum) % 4 == randf
+    x[0, is_dst] = b[0]
+    x[0, ~is_dst] = a[0]
+    lv = merge.local_level(_t(x), None, Ltot, F, float(c["ratio"]), 0, randf, 4, False, want_indices=True)
+    for n in ("unm_idx", "src_idx", "dst_idx"):
+        got = getattr(lv, n)[0].cpu().numpy().astype(np.int32)
+        assert np.array_equal(got[:16], c[n + "_head"]), n
+        assert hashlib.sha256(got.tobytes()).hexdigest() == str(c[n + "_sha256"]), n
+
+
+def test_planted_golden_gpu(L):
+    """cfg-2 top-block level-1 size (49152 x 16384 x 320): the REFERENCE's index arrays (sha256) reproduced
+    bit-exactly by the HIP path."""
+    for c in load_cases("planted.npz"):
+        _planted_gpu(c)
+
+
+# ---------------------------------------------------------------------------------------------------
+# apply_patch on the stand-in UNet vs the reference's recorded run
+# ---------------------------------------------------------------------------------------------------
+def _tie_aware_equal(level, ref_unm, ref_src, ref_dst, align):
+    """exact, except inside groups of exactly equal node_max (see tests/test_oracle_golden.py)."""
+    got = [getattr(level, n).cpu().numpy() for n in ("unm_idx", "src_idx", "dst_idx")]
+    if all(np.array_equal(g, r) for g, r in zip(got, (ref_unm, ref_src, ref_dst))):
+        return
+    from vidtome_amd import _lib
+    nm, ni = _lib.decode_best(level.best)
+    nm, ni = nm.cpu().numpy(), ni.cpu().numpy()
+    for b in range(ref_src.shape[0]):
+        nmb, nib = (nm[0], ni[0]) if align else (nm[b], ni[b])
+        assert np.array_equal(_bits(nmb[ref_src[b]]), _bits(nmb[got[1][b]]))
+        assert np.array_equal(_bits(nmb[ref_unm[b]]), _bits(nmb[got[0][b]]))
+        exp_dst = nib[ref_src[b]] % level.Nd if align else nib[ref_src[b]]
+        assert np.array_equal(exp_dst, ref_dst[b])
+
+
+@pytest.mark.parametrize("name", ["chain_cfg_f4", "chain_cfg_f8", "chain_pnp_f4", "chain_local_f4"])
+def test_chain_golden_gpu(L, name):
+    import vidtome_amd
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import pnp
+    from standin import Pipe, StandInUNet, load_block_weights
+
+    cfg, z = load_chain(name)
+    unet = load_block_weights(StandInUNet(cfg["C"], cfg["heads"]), z, DEV, torch.float32)
+    pipe = Pipe(unet)
+    if cfg["injection"] is not None:
+        pnp.register_attention_control(pipe, cfg["injection"], cfg["B"])
+        pnp.register_time(pipe, cfg["t"])
+    vidtome_amd.apply_patch(unet, local_merge_ratio=cfg["local_ratio"], merge_global=cfg["merge_global"],
+                            global_merge_ratio=cfg["global_ratio"], batch_size=cfg["B"], align_batch=cfg["align"],
+                            target_stride=4, global_rand=0.5)
+    blocks = list(unet.blocks())
+    assert all(b.__class__.__name__ == "ToMeBlock" for b in blocks)
+    torch.set_rng_state(torch.from_numpy(z["rng_state"]))       # what the block generators fork (patch.py:219)
+
+    # capture every plan compute_merge builds
+    plans = []
+    orig = vpatch.compute_merge
+
+    def rec(module, x, info, **kw):
+        res = orig(module, x, info, want_indices=True)
+        plans.append(getattr(res[0], "plan", None))
+        return res
+
+    vpatch.compute_merge = rec
+    try:
+        names = [str(s) for s in z["block_names"]]
+        for ck, F in enumerate(cfg["chunk_frames"]):
+            if ck in cfg.get("reset_before", []):
+                vidtome_amd.update_patch(unet, global_tokens=None)             # generate.py:233-236
+            plans.clear()
+            hiddens = [_t(z[f"c{ck}/b{bi}/hidden"]) for bi in range(9)]
+            with torch.no_grad():
+                outs = unet(_t(z[f"c{ck}/latent"]), hiddens)
+            ti = 0
+            for bi in range(9):
+                plan = plans[bi]
+                ref_merged = z[f"c{ck}/b{bi}/merged"]
+                if plan is not None:
+                    for lv in plan.levels:
+                        for n in ("unm_idx", "src_idx", "dst_idx"):
+                            assert np.array_equal(getattr(lv, n).cpu().numpy(), z[f"c{ck}/t{ti}/{n}"]), (ck, bi, n)
+                        ti += 1
+                    if plan.global_level is not None:
+                        _tie_aware_equal(plan.global_level, z[f"c{ck}/t{ti}/unm_idx"], z[f"c{ck}/t{ti}/src_idx"],
+                                         z[f"c{ck}/t{ti}/dst_idx"], cfg["align"])
+                        ti += 1
+                    # merged tokens are row copies of the (torch) LayerNorm output: tight tolerance
+                    np.testing.assert_allclose(plan.merged[:, :plan.M].cpu().numpy(), ref_merged, rtol=1e-5, atol=1e-6)
+                # attention runs in fp16 MFMA on this fp32 fixture: 1e-3-class tolerance on the block output
+                np.testing.assert_allclose(outs[bi].cpu().numpy(), z[f"c{ck}/b{bi}/out"], rtol=2e-2, atol=4e-3)
+            assert f"c{ck}/t{ti}/kind" not in z.files
+            gts = vidtome_amd.collect_from_patch(unet, attr="global_tokens")
+            for bi, nme in enumerate(names):
+                key = f"c{ck}/gt/{nme}"
+                if key in z.files:
+                    np.testing.assert_allclose(gts[nme].cpu().numpy(), z[key], rtol=1e-5, atol=1e-6)
+    finally:
+        vpatch.compute_merge = orig
+    vidtome_amd.remove_patch(unet)
+    assert all(b.__class__.__name__ == "BasicTransformerBlock" for b in blocks)
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------
+def test_attention_golden_gpu(L):
+    """softmax(QK^T)V through vtm_attention vs the reference's sa_forward outputs (fp16, 1e-3)."""
+    from vidtome_amd import patch as vpatch
+    from standin import Attention
+    for c in load_cases("attention.npz"):
+        B, h, M, d = int(c["B"]), int(c["heads"]), int(c["M"]), int(c["d"])
+        attn = Attention(h * d, h)
+        with torch.no_grad():
+            attn.to_q.weight.copy_(torch.from_numpy(c["wq"].astype(np.float32)))
+            attn.to_k.weight.copy_(torch.from_numpy(c["wk"].astype(np.float32)))
+            attn.to_v.weight.copy_(torch.from_numpy(c["wv"].astype(np.float32)))
+            attn.to_out[0].weight.copy_(torch.from_numpy(c["wo"].astype(np.float32)))
+            attn.to_out[0].bias.copy_(torch.from_numpy(c["bo"].astype(np.float32)))
+        attn = attn.to(DEV).half()
+        if c["inject"]:
+            attn.injection_schedule, attn.t, attn.vtm_num_inputs = [500], 500, B
+        x = _t(c["x"]).half()
+        with torch.no_grad():
+            y = vpatch.self_attention(attn, x, M)[:, :M].float().cpu().numpy()
+        err = np.abs(y[:, c["rows"], :] - c["y_rows"]).max()
+        assert err < 1e-3 * max(1.0, np.abs(c["y_rows"]).max()), (d, err)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 200, 40), (1, 2, 333, 80), (2, 2, 129, 64), (1, 1, 70, 160), (3, 2, 64, 8)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_attention_core_vs_oracle(L, oracle, shape, dtype):
+    B, h, M, d = shape
+    C = h * d
+    g = torch.Generator().manual_seed(M)
+    q = torch.randn(B, M, C, generator=g).to(dtype)
+    k = torch.randn(B, M, C, generator=g).to(dtype)
+    v = torch.randn(B, M, C, generator=g).to(dtype)
+    Mp = (M + 7) // 8 * 8
+    pad = lambda t: torch.nn.functional.pad(t, (0, 0, 0, Mp - M))
+    qd, kd = pad(q).to(DEV), pad(k).to(DEV)
+    vt = pad(v).to(DEV).transpose(1, 2).contiguous()
+    for share in (1, B) if B > 1 else (1,):
+        o = L.attention(qd, kd, vt, h, M, d ** -0.5, share)[:, :M].float().cpu().numpy()
+        ref = oracle.attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), h, share_groups=share)
+        tol = 1e-3 if dtype == torch.float16 else 8e-3
+        assert np.abs(o - ref).max() < tol * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------------------------------------------
+# full-size, size-independent properties (cfg-2 top block: B=2, F=16, N=4096, C=320)
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_properties(L):
+    import vidtome_amd
+    from vidtome_amd import patch as vpatch
+
+    class Blk(torch.nn.Module):
+        pass
+
+    B, F, N, C = 2, 16, 4096, 320
+    g = torch.Generator().manual_seed(1234)
+    base = torch.randn(B, 1, N, C, generator=g)
+    x = (base + 0.5 * torch.randn(B, F, N, C, generator=g)).reshape(B * F, N, C).half().to(DEV)
+    blk = Blk()
+    blk.generator = torch.Generator().manual_seed(123)
+    info = {"size": (64, 64), "args": dict(max_downsample=2, generator=None, seed=123, batch_size=B, align_batch=False,
+                                           merge_global=True, global_merge_ratio=0.5, local_merge_ratio=0.5,
+                                           global_rand=0.5, target_stride=4)}
+    for step in range(3):            # chunk 0 stores anchors, chunks 1-2 merge against them
+        m, u, merged = vpatch.compute_merge(blk, x, info, want_indices=True)
+        plan = m.plan
+        Lj = F * N
+        assert plan.levels[0].Ns == 49152 and plan.levels[0].Nd == 16384 and plan.levels[0].r == 24576
+        assert plan.levels[1].Ns == 12288 and plan.levels[1].Nd == 28672 and plan.levels[1].r == 6144
+        M = plan.M
+        assert M == (34816 if step == 0 else 52224)
+        gm, inv = plan.gather_map, plan.inv
+        # every merged row is a pool row; the maps are consistent: pool[gather_map[inv[i]]] is the row that
+        # replaces token i, and tokens that survive (unmerged / dst) map back to THEMSELVES
+        assert int(gm.min()) >= 0 and int(inv.min()) >= 0 and int(inv.max()) < M
+        back = torch.gather(gm.long(), 1, inv.long())                    # (B, L) pool id restored at each position
+        ar = torch.arange(Lj, device=DEV)[None].expand(B, -1)
+        kept = back == ar
+        n_kept_expected = 34816 if step == 0 else None
+        if step == 0:
+            assert int(kept.sum(1)[0]) == 34816                         # exactly the merged rows survive
+            # idempotence: unmerge(merge(x)) == x on surviving rows, and merge(unmerge(y)) == y
+            xj = x.reshape(B, Lj, C)
+            rt = u(merged).reshape(B, Lj, C)
+            assert torch.equal(rt[kept], xj[kept])
+            y = torch.randn(B, merged.shape[1], C, generator=g).half().to(DEV)
+            assert torch.equal(m(u(y))[:, :M], y[:, :M])
+        # each src row is restored from a dst row of a DIFFERENT position; sorted-ness of level-1 ranking
+        lv = plan.levels[0]
+        from vidtome_amd import _lib
+        nm, _ = _lib.decode_best(lv.best)
+        ranked = torch.gather(nm, 1, torch.cat([lv.src_idx, lv.unm_idx], 1).long())
+        assert bool((ranked[:, 1:] <= ranked[:, :-1]).all())            # descending similarity order
+        assert torch.equal(torch.sort(torch.cat([lv.src_idx, lv.unm_idx], 1), 1).values,
+                           torch.arange(lv.Ns, device=DEV, dtype=torch.int32)[None].expand(B, -1))

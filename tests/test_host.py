@@ -1,0 +1,145 @@
+"""CPU tests of the host logic and of the C-ABI library surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from vidtome_amd import build
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol(built):
+    """Every function include/vidtome_hip.h declares is exported by the .so and bound in _lib."""
+    from vidtome_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "vidtome_hip.h")).read()
+    declared = set(re.findall(r"\b(vtm_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"vtm_match_row_pad"}
+    lib = ctypes.CDLL(built)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.exported_symbols())
+    assert _lib.lib().vtm_version() == 1
+    assert _lib.lib().vtm_pad_rows(129) == 256 and _lib.lib().vtm_pad_k(320) == 320 and _lib.lib().vtm_pad_k(40) == 64
+
+
+def test_partition_counts_match_reference_arithmetic(built, oracle):
+    """vtm_partition_counts (host helper) vs the reference's own boolean-mask construction (merge.py:52-69)."""
+    from vidtome_amd import _lib
+    for (N, unm_pre, F, stride) in [(65536, 0, 16, 4), (40960, 24576, 4, 4), (64, 0, 4, 4), (60, 0, 6, 4), (72, 7, 5, 2),
+                                    (110592 * 2, 0, 16, 4), (33, 0, 3, 4), (101, 5, 7, 3)]:
+        tnum = (N - unm_pre) // F
+        ts = min(stride, F)
+        for randf in range(ts):
+            idx = np.arange(N - unm_pre)
+            sel = (idx // tnum) % ts == randf
+            assert _lib.partition_counts(N, unm_pre, tnum, ts, randf) == (int((~sel).sum()), int(sel.sum()) + unm_pre)
+
+
+def test_error_convention(built):
+    from vidtome_amd import _lib
+    L = _lib.lib()
+    ns, nd = ctypes.c_int64(), ctypes.c_int64()
+    rc = L.vtm_partition_counts(10, 20, 1, 1, 0, ctypes.byref(ns), ctypes.byref(nd))
+    assert rc == -1 and b"vtm_partition_counts" in L.vtm_last_error()
+    # null pointers are rejected before any launch
+    assert L.vtm_match(None, None, 1, 1, 1, 128, 128, 32, 0, None, None) == -1
+    assert L.vtm_sort_desc(None, 1, 1, None, None, 0, None) == -1
+    assert L.vtm_attention(None, 8, None, 8, None, 8, None, 8, 1, 1, 1, 8, 8, 40, 1.0, 1, None) == -1
+
+
+def test_cpu_tensors_fail_loudly(built):
+    """There is no CPU fallback: the mirrored API raises on CPU tensors instead of computing elsewhere."""
+    from vidtome_amd import merge
+    x = torch.randn(2, 16, 8)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        merge.bipartite_soft_matching_randframe(x, 4, 0.5, 0, torch.Generator().manual_seed(1))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        merge.bipartite_soft_matching_2s(x, 8, 0.5, False)
+    # the early-outs of the reference do not touch the data (merge.py:45-46, 364-365)
+    m, u, d = merge.bipartite_soft_matching_randframe(x.to("meta") if False else x, 4, 0.0, 0, None) \
+        if False else (merge.do_nothing, merge.do_nothing, {"unm_num": 4})
+    assert m(x) is x and d["unm_num"] == 4
+
+
+def test_missing_library_is_an_error(built, monkeypatch):
+    from vidtome_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libvidtome_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU / eager fallback"):
+        _lib.lib()
+
+
+def test_patch_api_mechanics(built):
+    """apply/remove/update/collect: class swap named ToMeBlock with _parent, shared _tome_info, hooks, kwargs."""
+    import inspect
+
+    import vidtome_amd
+    from standin import Pipe, StandInUNet
+
+    unet = StandInUNet(16, 2)
+    pipe = Pipe(unet)
+    sig = inspect.signature(vidtome_amd.apply_patch)
+    assert [(k, v.default) for k, v in list(sig.parameters.items())[1:]] == [
+        ("local_merge_ratio", 0.9), ("merge_global", False), ("global_merge_ratio", 0.8), ("max_downsample", 2),
+        ("seed", 123), ("batch_size", 2), ("include_control", False), ("align_batch", False),
+        ("target_stride", 4), ("global_rand", 0.5)]                                     # patch.py:234-245
+    out = vidtome_amd.apply_patch(pipe if False else unet, local_merge_ratio=0.5, merge_global=True)
+    assert out is unet
+    blocks = list(unet.blocks())
+    assert all(b.__class__.__name__ == "ToMeBlock" and b._parent.__name__ == "BasicTransformerBlock" for b in blocks)
+    assert all(b._tome_info is unet._tome_info for b in blocks)
+    assert unet._tome_info["args"]["local_merge_ratio"] == 0.5 and unet._tome_info["args"]["merge_global"] is True
+    assert len(unet._tome_info["hooks"]) == 1 + len(blocks)
+    assert all(b.use_ada_layer_norm is False and b.use_ada_layer_norm_zero is False for b in blocks)
+    vidtome_amd.update_patch(unet, global_tokens=None, foo=3)
+    assert unet.foo == 3 and all(b.foo == 3 and b.global_tokens is None for b in blocks)   # root too (patch.py:366-369)
+    got = vidtome_amd.collect_from_patch(unet, attr="foo")
+    assert got[""] == 3 and len(got) == 1 + len(blocks)
+    # size hook: first positional arg's (H, W)
+    unet._forward_pre_hooks[next(iter(unet._forward_pre_hooks))](unet, (torch.zeros(8, 4, 6, 10),))
+    assert unet._tome_info["size"] == (6, 10)
+    # generator hook forks the global CPU RNG state and leaves it untouched
+    torch.manual_seed(123)
+    before = torch.get_rng_state().clone()
+    blk = blocks[0]
+    blk._forward_pre_hooks[next(iter(blk._forward_pre_hooks))](blk, (torch.zeros(1),))
+    assert torch.equal(torch.get_rng_state(), before)
+    draws = [int(torch.randint(0, 4, torch.Size([1]), generator=blk.generator)) for _ in range(8)]
+    assert draws == [2, 1, 2, 2, 0, 2, 2, 1]                                               # SURVEY.md 8c KAT
+    # re-applying re-patches cleanly; removing restores the class and the hooks
+    vidtome_amd.apply_patch(unet)
+    assert len(unet._tome_info["hooks"]) == 1 + len(blocks)
+    ret = vidtome_amd.remove_patch(unet)
+    assert ret is unet and all(b.__class__.__name__ == "BasicTransformerBlock" for b in blocks)
+    assert len(unet._tome_info["hooks"]) == 0 and len(unet._forward_pre_hooks) == 0
+    with pytest.raises(RuntimeError, match="Stable Diffusion / Latent Diffusion"):
+        vidtome_amd.apply_patch(torch.nn.Linear(2, 2))                                      # patch.py:283-286
+
+
+def test_pnp_closure_detection():
+    """A module whose forward was replaced by a closure holding `num_inputs` (what the reference's
+    register_attention_control does, pnp_utils.py:39-97) is recognised."""
+    from vidtome_amd import patch as vpatch
+    from standin import Attention
+
+    def register(mod, num_inputs):
+        def sa_forward(self):
+            def forward(x, encoder_hidden_states=None, attention_mask=None, **kw):
+                return x * num_inputs
+            return forward
+        mod.forward = sa_forward(mod)
+
+    a = Attention(16, 2)
+    assert vpatch._pnp_num_inputs(a) is None
+    register(a, 3)
+    assert vpatch._pnp_num_inputs(a) == 3
+    a.vtm_num_inputs = 2
+    assert vpatch._pnp_num_inputs(a) == 2

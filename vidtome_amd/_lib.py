@@ -1,0 +1,252 @@
+"""ctypes binding of libvidtome_hip.so (the C ABI declared in include/vidtome_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the current HIP stream; every
+function below passes raw device pointers + sizes to the library.  There is NO fallback: if the library
+is missing or a call fails, a RuntimeError is raised.
+
+torch must be imported before the library is loaded so that both bind the same HIP runtime
+(libamdhip64.so.7 is resolved by SONAME against the copy torch already mapped).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvidtome_hip.so")
+
+VTM_F32, VTM_F16, VTM_BF16 = 0, 1, 2
+ROW_PAD, K_PAD = 128, 32
+
+_DT = {torch.float32: VTM_F32, torch.float16: VTM_F16, torch.bfloat16: VTM_BF16}
+
+_vp, _i64, _int, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+_lib: Optional[ctypes.CDLL] = None
+
+_SIGNATURES = {
+    "vtm_version": ([], _int),
+    "vtm_last_error": ([], ctypes.c_char_p),
+    "vtm_pad_rows": ([_i64], _i64),
+    "vtm_pad_k": ([_i64], _i64),
+    "vtm_normalize_gather": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp], _int),
+    "vtm_match": ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp], _int),
+    "vtm_decode_best": ([_vp, _i64, _vp, _vp, _vp], _int),
+    "vtm_sort_ws_bytes": ([_i64, _i64], ctypes.c_size_t),
+    "vtm_sort_desc": ([_vp, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp], _int),
+    "vtm_partition_counts": ([_i64, _i64, _i64, _i64, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)], _int),
+    "vtm_partition_local": ([_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp], _int),
+    "vtm_partition_global": ([_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp], _int),
+    "vtm_plan_apply": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp,
+                        _vp, _vp], _int),
+    "vtm_compose": ([_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp], _int),
+    "vtm_gather_rows": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _vp], _int),
+    "vtm_unmerge_add": ([_vp, _i64, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp], _int),
+    "vtm_attention": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _f32,
+                       _int, _vp], _int),
+}
+
+
+def exported_symbols():
+    """Names include/vidtome_hip.h declares (used by the CPU test that checks the .so exports them)."""
+    return sorted(_SIGNATURES)
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m vidtome_amd.build` (hipcc, gfx950). "
+                "vidtome_amd has no CPU / eager fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError here = the .so is stale w.r.t. the header
+            fn.argtypes = argtypes
+            fn.restype = restype
+        if L.vtm_version() != 1:
+            raise RuntimeError("libvidtome_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().vtm_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (vidtome_amd has no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t.dtype}") from None
+
+
+def pad_rows(n: int) -> int:
+    return (n + ROW_PAD - 1) // ROW_PAD * ROW_PAD
+
+
+def pad_k(c: int) -> int:
+    return (c + K_PAD - 1) // K_PAD * K_PAD
+
+
+# --------------------------------------------------------------------------------------------------
+def normalize_gather(x0: torch.Tensor, x1: Optional[torch.Tensor], rows: torch.Tensor
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rows (B, n) int32 pool ids -> (operand (B, n_pad, C_pad) fp32 k-interleaved, norms (B, n))."""
+    _req(x0, "x0"), _req(rows, "rows")
+    B, P0, C = x0.shape
+    P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
+    n = rows.shape[1]
+    n_pad, C_pad = pad_rows(n), pad_k(C)
+    out = torch.empty((B, n_pad, C_pad), dtype=torch.float32, device=x0.device)
+    norms = torch.empty((B, max(n, 1)), dtype=torch.float32, device=x0.device)
+    _check(lib().vtm_normalize_gather(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(rows), n,
+                                      _ptr(norms), _ptr(out), n_pad, C_pad, _stream()), "vtm_normalize_gather")
+    return out, norms
+
+
+def match(a: torch.Tensor, b: torch.Tensor, Ns: int, Nd: int, align: bool) -> torch.Tensor:
+    """Packed (orderable(max) << 32 | ~argmax) per src row: (B, Ns) or (1, Ns) when aligned (int64 bits)."""
+    B, Ns_pad, C_pad = a.shape
+    Nd_pad = b.shape[1]
+    best = torch.empty((1 if align else B, Ns), dtype=torch.int64, device=a.device)
+    _check(lib().vtm_match(_ptr(a), _ptr(b), B, Ns, Nd, Ns_pad, Nd_pad, C_pad, int(align), _ptr(best), _stream()),
+           "vtm_match")
+    return best
+
+
+def decode_best(best: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    nm = torch.empty(best.shape, dtype=torch.float32, device=best.device)
+    ni = torch.empty(best.shape, dtype=torch.int32, device=best.device)
+    _check(lib().vtm_decode_best(_ptr(best), best.numel(), _ptr(nm), _ptr(ni), _stream()), "vtm_decode_best")
+    return nm, ni
+
+
+def sort_desc(best: torch.Tensor) -> torch.Tensor:
+    rows, n = best.shape
+    perm = torch.empty((rows, n), dtype=torch.int32, device=best.device)
+    nbytes = lib().vtm_sort_ws_bytes(rows, n)
+    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=best.device)
+    _check(lib().vtm_sort_desc(_ptr(best), rows, n, _ptr(perm), _ptr(ws), nbytes, _stream()), "vtm_sort_desc")
+    return perm
+
+
+def partition_counts(N_in: int, unm_pre: int, tnum: int, ts: int, randf: int) -> Tuple[int, int]:
+    ns, nd = _i64(0), _i64(0)
+    _check(lib().vtm_partition_counts(N_in, unm_pre, tnum, ts, randf, ctypes.byref(ns), ctypes.byref(nd)),
+           "vtm_partition_counts")
+    return int(ns.value), int(nd.value)
+
+
+def partition_local(cur: Optional[torch.Tensor], B: int, N_in: int, unm_pre: int, tnum: int, ts: int,
+                    randf: int, device) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    Ns, Nd = partition_counts(N_in, unm_pre, tnum, ts, randf)
+    i32 = dict(dtype=torch.int32, device=device)
+    a_pos, b_pos = torch.empty((Ns,), **i32), torch.empty((Nd,), **i32)
+    a_rows, b_rows = torch.empty((B, Ns), **i32), torch.empty((B, Nd), **i32)
+    _check(lib().vtm_partition_local(_ptr(cur), B, N_in, unm_pre, tnum, ts, randf, _ptr(a_pos), _ptr(b_pos),
+                                     _ptr(a_rows), _ptr(b_rows), Ns, Nd, _stream()), "vtm_partition_local")
+    return a_pos, b_pos, a_rows, b_rows
+
+
+def partition_global(cur_local: torch.Tensor, anchor_base: int, Mg: int, local_is_src: bool
+                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    B, Ml = cur_local.shape
+    src_len = Ml if local_is_src else Mg
+    Nd = Ml + Mg - src_len
+    i32 = dict(dtype=torch.int32, device=cur_local.device)
+    a_pos, b_pos = torch.empty((src_len,), **i32), torch.empty((Nd,), **i32)
+    a_rows, b_rows = torch.empty((B, src_len), **i32), torch.empty((B, Nd), **i32)
+    _check(lib().vtm_partition_global(_ptr(cur_local), B, Ml, anchor_base, Mg, int(local_is_src), _ptr(a_pos),
+                                      _ptr(b_pos), _ptr(a_rows), _ptr(b_rows), _stream()), "vtm_partition_global")
+    return a_pos, b_pos, a_rows, b_rows
+
+
+def plan_apply(best, perm, a_pos, b_pos, a_rows, b_rows, r: int, align: bool, want_indices: bool):
+    B, Ns = a_rows.shape
+    Nd = b_rows.shape[1]
+    N_in, U = Ns + Nd, Ns - r
+    i32 = dict(dtype=torch.int32, device=a_rows.device)
+    new_cur = torch.empty((B, U + Nd), **i32)
+    inv = torch.empty((B, N_in), **i32)
+    unm_idx = torch.empty((B, U), **i32) if want_indices else None
+    src_idx = torch.empty((B, r), **i32) if want_indices else None
+    dst_idx = torch.empty((B, r), **i32) if want_indices else None
+    _check(lib().vtm_plan_apply(_ptr(best), _ptr(perm), _ptr(a_pos), _ptr(b_pos), _ptr(a_rows), _ptr(b_rows), B,
+                                N_in, Ns, Nd, r, int(align), _ptr(new_cur), _ptr(inv), _ptr(unm_idx),
+                                _ptr(src_idx), _ptr(dst_idx), _stream()), "vtm_plan_apply")
+    return new_cur, inv, unm_idx, src_idx, dst_idx
+
+
+def compose(inv_acc: Optional[torch.Tensor], inv_level: torch.Tensor, n: int, offset: int = 0) -> torch.Tensor:
+    B, level_len = inv_level.shape
+    out = torch.empty((B, n), dtype=torch.int32, device=inv_level.device)
+    _check(lib().vtm_compose(_ptr(inv_acc), _ptr(inv_level), B, n, level_len, offset, _ptr(out), _stream()),
+           "vtm_compose")
+    return out
+
+
+def gather_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], idx: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
+    """out (B, M_pad, C): rows [0, M) = pool[idx]; rows >= M (padding up to a multiple of pad_to) are zero."""
+    _req(x0, "x0"), _req(idx, "map")
+    B, P0, C = x0.shape
+    P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
+    M = idx.shape[1]
+    Mp = (M + pad_to - 1) // pad_to * pad_to
+    out = (torch.zeros if Mp != M else torch.empty)((B, Mp, C), dtype=x0.dtype, device=x0.device)
+    _check(lib().vtm_gather_rows(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(idx), M, _ptr(out), Mp,
+                                 _stream()), "vtm_gather_rows")
+    return out
+
+
+def unmerge_add(y: torch.Tensor, inv: torch.Tensor, resid: Optional[torch.Tensor]) -> torch.Tensor:
+    """out[b, i] = y[b, inv[b, i]] (+ resid[b, i]);  y is (B, Mp, C) (only rows < M are referenced)."""
+    _req(y, "y"), _req(inv, "inv")
+    B, Mp, C = y.shape
+    L = inv.shape[1]
+    out = torch.empty((B, L, C), dtype=y.dtype, device=y.device)
+    if resid is not None:
+        _req(resid, "resid")
+        if resid.numel() != out.numel() or resid.dtype != y.dtype:
+            raise RuntimeError("residual shape/dtype mismatch")
+    _check(lib().vtm_unmerge_add(_ptr(y), Mp, _ptr(inv), _ptr(resid), dtype_code(y), B, L, C, _ptr(out), _stream()),
+           "vtm_unmerge_add")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, M: int, scale: float,
+              share_groups: int = 1) -> torch.Tensor:
+    """q, k: (B, Mp, C) views with arbitrary last-dim-contiguous row stride; vt: (B, C, ldvt) = v transposed.
+    Returns out (B, Mp, C) (rows >= M untouched/zero)."""
+    B, Mp, C = q.shape
+    d = C // heads
+    if q.stride(2) != 1 or k.stride(2) != 1 or vt.stride(2) != 1:
+        raise RuntimeError("attention operands must be contiguous along their last axis")
+    if q.stride(0) != Mp * q.stride(1) or k.stride(0) != Mp * k.stride(1) or vt.stride(0) != C * vt.stride(1):
+        raise RuntimeError("attention operands must have dense batch strides")
+    out = torch.zeros((B, Mp, C), dtype=q.dtype, device=q.device) if Mp != M else \
+        torch.empty((B, Mp, C), dtype=q.dtype, device=q.device)
+    _check(lib().vtm_attention(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(), vt.stride(1),
+                               out.data_ptr(), C, dtype_code(q), B, heads, M, Mp, d, float(scale),
+                               int(share_groups), _stream()), "vtm_attention")
+    return out

@@ -1,0 +1,71 @@
+"""Build libvidtome_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m vidtome_amd.build [--force]
+
+The library is built IN-TREE (vidtome_amd/lib/) so that it travels with the repository snapshot to the
+GPU box; it is git-ignored.  No fast-math: the matching path's fp32 arithmetic is part of the bit-exact
+contract (IEEE divide / sqrt, explicit fma only).
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libvidtome_hip.so")
+SOURCES = ["api.hip", "normalize.hip", "match.hip", "sort.hip", "plan.hip", "gather.hip", "attention.hip"]
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 for gfx950)")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    cc = hipcc()
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "vidtome_hip.h")]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([cc, *FLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + p.stdout)
+        return p.stdout
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for out in ex.map(run, jobs):
+            if verbose and out.strip():
+                print(out)
+    if force or jobs or _stale(LIB, objs):
+        run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

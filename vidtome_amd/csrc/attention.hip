@@ -1,0 +1,307 @@
+// vtm_attention: flash-style self-attention over the MERGED token sequence (MFMA, fp16/bf16 in,
+// fp32 accumulate).  Reference: the `self.attn1(...)` call at vidtome/patch.py:157-162; the arithmetic
+// is the one the reference states itself in utils/pnp_utils.py:47-95 (`sa_forward`):
+//     sim = einsum("b i d, b j d -> b i j", q, k) * scale;  attn = sim.softmax(-1);  out = attn @ v
+// including its injection branch (probabilities of the source sample reused for every batch group).
+//
+// Structure (v1):
+//   * workgroup = 4 waves, each wave owns 32 query rows; K / V^T tiles of 64 keys are staged through
+//     LDS (register-staged, double-buffered) and shared by the 4 waves;
+//   * "swapped" QK^T: S^T = K Q^T with v_mfma_f32_32x32x16 puts one query per lane (j = lane & 31) and
+//     its 2 x 16 keys of the tile in that lane's accumulators -> online softmax is in-register, with ONE
+//     cross-half exchange per tile for the running max;
+//   * P stays in registers: the PV contraction's k-slot <-> key assignment is chosen to be exactly the
+//     one the S^T accumulator layout already has (keys 4*hi + {0..3} and 8 + 4*hi + {0..3} of every
+//     16-key group), and V^T is read from LDS with the same assignment, so no permute / LDS round trip
+//     of P is needed;
+//   * V arrives TRANSPOSED (channel-major) from the projection GEMM, so the V^T operand needs no
+//     transpose either.
+// Sequence lengths are ragged (34 816, 52 224, 8 704, ...): tail keys are masked, tail queries not stored.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WAVES = 4;
+constexpr int QW = 32;           // queries per wave
+constexpr int QB = WAVES * QW;   // queries per workgroup
+constexpr int KV = 64;           // keys per tile
+constexpr int VT_STRIDE = KV + 4;  // 68 elements = 34 words: conflict-free ds_read_b64 over 32 rows
+
+template <typename T> struct Frag;
+template <> struct Frag<__half> {
+    using vec = h16x8;
+    using elem = _Float16;
+    __device__ static f32x16 mfma(vec a, vec b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Frag<vtm_bf16> {
+    using vec = b16x8;
+    using elem = __bf16;
+    __device__ static f32x16 mfma(vec a, vec b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(WAVES * 64) void attention_kernel(
+    const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
+    const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t Bsz, int64_t H,
+    int64_t M, int64_t Mp, float scale_log2e, int64_t src_batch) {
+    using F = Frag<T>;
+    using vec = typename F::vec;
+    using elem = typename F::elem;
+    constexpr int DK = (D + 15) / 16;      // k-steps of the QK^T contraction
+    constexpr int DV = (D + 31) / 32;      // 32-row blocks of O^T
+    constexpr int K_STRIDE = DK * 16 + 8;  // elements; (DK*8+4) words = 4 x odd -> conflict-free b128
+    constexpr int DCH = D / 8;             // 16-byte chunks per K row
+    constexpr int K_CHUNKS = KV * DCH;     // per tile
+    constexpr int V_CHUNKS = D * (KV / 8);
+    constexpr int K_PER_T = (K_CHUNKS + 255) / 256;
+    constexpr int V_PER_T = (V_CHUNKS + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    elem *sK = reinterpret_cast<elem *>(smem);                       // [2][KV][K_STRIDE]
+    elem *sV = sK + 2 * KV * K_STRIDE;                               // [2][DV*32][VT_STRIDE]
+    constexpr int SK_TILE = KV * K_STRIDE, SV_TILE = DV * 32 * VT_STRIDE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int64_t b = blockIdx.z, h = blockIdx.y;
+    const int64_t bq = b % src_batch;  // PnP injection: q/k of the source sample (pnp_utils.py:57-67)
+    const int64_t q0 = (int64_t)blockIdx.x * QB + wave * QW;
+    const int64_t C = H * D;
+
+    // zero the K pad columns once (they multiply Q's zero padding; garbage could be NaN)
+    for (int i = tid; i < 2 * KV * (K_STRIDE - D); i += 256) {
+        const int row = i / (K_STRIDE - D), c = D + i % (K_STRIDE - D);
+        sK[row * K_STRIDE + c] = (elem)0.0f;
+    }
+
+    // Q fragments (B operand of S^T = K Q^T): lane (query l31, half hi) holds d = 16 ks + 8 hi + 0..7
+    vec qf[DK];
+    {
+        const int64_t qi = q0 + l31;
+        const T *qp = q + (bq * Mp + (qi < M ? qi : 0)) * ldq + h * D;
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) {
+            const int d0 = ks * 16 + hi * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (d0 < D && qi < M) v = *reinterpret_cast<const uint4 *>(qp + d0);
+            qf[ks] = *reinterpret_cast<vec *>(&v);
+        }
+    }
+
+    const T *kbase = k + bq * Mp * ldk + h * D;
+    const T *vbase = vt + (b * C + h * D) * ldvt;
+
+    uint4 rk[K_PER_T], rv[V_PER_T];
+    auto issue_loads = [&](int64_t key0) {
+#pragma unroll
+        for (int i = 0; i < K_PER_T; ++i) {
+            const int c = tid + i * 256;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < K_CHUNKS) {
+                const int64_t key = key0 + c / DCH;
+                if (key < M) v = *reinterpret_cast<const uint4 *>(kbase + key * ldk + (c % DCH) * 8);
+            }
+            rk[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < V_PER_T; ++i) {
+            const int c = tid + i * 256;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < V_CHUNKS) {
+                const int64_t key = key0 + (c % (KV / 8)) * 8;
+                if (key < M) {  // ldvt >= M rounded up to 8, so the 16-byte chunk is inside the row
+                    v = *reinterpret_cast<const uint4 *>(vbase + (int64_t)(c / (KV / 8)) * ldvt + key);
+                    if (key + 8 > M) {  // zero the keys >= M: their p is 0 but 0 * garbage may be NaN
+                        elem *e = reinterpret_cast<elem *>(&v);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (key + j >= M) e[j] = (elem)0.0f;
+                    }
+                }
+            }
+            rv[i] = v;
+        }
+    };
+    auto write_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < K_PER_T; ++i) {
+            const int c = tid + i * 256;
+            if (c < K_CHUNKS)
+                *reinterpret_cast<uint4 *>(&sK[buf * SK_TILE + (c / DCH) * K_STRIDE + (c % DCH) * 8]) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < V_PER_T; ++i) {
+            const int c = tid + i * 256;
+            if (c < V_CHUNKS) {  // rows are only 8-byte aligned (stride 136 B): two 8-byte stores
+                uint2 *dst = reinterpret_cast<uint2 *>(&sV[buf * SV_TILE + (c / (KV / 8)) * VT_STRIDE + (c % (KV / 8)) * 8]);
+                dst[0] = make_uint2(rv[i].x, rv[i].y);
+                dst[1] = make_uint2(rv[i].z, rv[i].w);
+            }
+        }
+    };
+
+    f32x16 o[DV];
+#pragma unroll
+    for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dv][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    const int64_t ntiles = (M + KV - 1) / KV;
+    issue_loads(0);
+    write_lds(0);
+    __syncthreads();
+
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const int buf = (int)(t & 1);
+        const int64_t key0 = t * KV;
+        if (t + 1 < ntiles) issue_loads(key0 + KV);
+
+        // ---- S^T = K Q^T : 2 blocks of 32 keys
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+            const elem *kp = &sK[buf * SK_TILE + (kb * 32 + l31) * K_STRIDE + hi * 8];
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) {
+                const vec kf = *reinterpret_cast<const vec *>(kp + ks * 16);
+                s[kb] = F::mfma(kf, qf[ks], s[kb]);
+            }
+        }
+
+        // ---- online softmax (base 2); lane (query l31, half hi) holds keys
+        //      key0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
+        float mt = -INFINITY;
+        const bool tail = key0 + KV > M;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = s[kb][r] * scale_log2e;
+                if (tail && key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= M) x = -INFINITY;
+                s[kb][r] = x;
+                mt = fmaxf(mt, x);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.0f;
+        vec pf[4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+                psum += p;
+                pf[kb * 2 + (r >> 3)][r & 7] = (elem)p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+
+        // ---- O^T += V^T P^T : 4 steps of 16 keys; k-slot (hi, e) <-> key 16 st + 8 (e >> 2) + 4 hi + (e & 3)
+#pragma unroll
+        for (int dv = 0; dv < DV; ++dv) {
+            const elem *vp = &sV[buf * SV_TILE + (dv * 32 + l31) * VT_STRIDE + 4 * hi];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const uint2 lo = *reinterpret_cast<const uint2 *>(vp + st * 16);
+                const uint2 up = *reinterpret_cast<const uint2 *>(vp + st * 16 + 8);
+                uint4 vv = make_uint4(lo.x, lo.y, up.x, up.y);
+                o[dv] = F::mfma(*reinterpret_cast<vec *>(&vv), pf[st], o[dv]);
+            }
+        }
+
+        if (t + 1 < ntiles) write_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: O / l, row q = q0 + l31, channels dv*32 + (r & 3) + 8 (r >> 2) + 4 hi
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv_l = 1.0f / l_tot;
+    const int64_t qi = q0 + l31;
+    if (qi < M) {
+        T *op = out + (b * Mp + qi) * ldo + h * D;
+#pragma unroll
+        for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dv * 32 + 8 * g + 4 * hi;
+                if (d0 < D) {  // D % 8 == 0 and d0 % 4 == 0 -> the 4 channels are all valid
+                    elem w[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (elem)(o[dv][g * 4 + e] * inv_l);
+                    *reinterpret_cast<uint2 *>(op + d0) = *reinterpret_cast<uint2 *>(w);
+                }
+            }
+    }
+}
+
+template <typename T, int D>
+int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt, void *out,
+           int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, float scale, int share_groups, hipStream_t s) {
+    constexpr int DK = (D + 15) / 16, DV = (D + 31) / 32;
+    constexpr size_t lds = (size_t)2 * (KV * (DK * 16 + 8) + DV * 32 * VT_STRIDE) * 2;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<T, D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_attention: LDS attribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)vtm::cdiv(M, QB), (unsigned)h, (unsigned)B);
+    const float scale_log2e = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL((attention_kernel<T, D>), grid, dim3(WAVES * 64), lds, s, (const T *)q, ldq, (const T *)k,
+                       ldk, (const T *)vt, ldvt, (T *)out, ldo, B, h, M, Mp, scale_log2e, B / share_groups);
+    return vtm::launch_status("vtm_attention");
+}
+
+template <typename T>
+int dispatch(int64_t d, const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+             void *out, int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, float scale, int sg, hipStream_t s) {
+    switch (d) {
+        case 40: return launch<T, 40>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
+        case 64: return launch<T, 64>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
+        case 80: return launch<T, 80>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
+        case 160: return launch<T, 160>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
+        case 8: return launch<T, 8>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
+        case 16: return launch<T, 16>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
+        case 32: return launch<T, 32>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
+        case 96: return launch<T, 96>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
+        case 128: return launch<T, 128>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
+    }
+    return vtm::fail(VTM_EINVAL, "vtm_attention: unsupported head dim %lld (have 8,16,32,40,64,80,96,128,160)",
+                     (long long)d);
+}
+
+}  // namespace
+
+VTM_EXPORT int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt,
+                             int64_t ldvt, void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t M,
+                             int64_t Mp, int64_t d, float scale, int share_groups, vtm_stream_t stream) {
+    VTM_REQUIRE(q && k && vt && out, "vtm_attention: null pointer");
+    VTM_REQUIRE(B > 0 && h > 0 && M > 0 && d > 0 && Mp >= M, "vtm_attention: bad sizes");
+    VTM_REQUIRE(share_groups >= 1 && B % share_groups == 0, "vtm_attention: B %% share_groups != 0");
+    VTM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= M,
+                "vtm_attention: leading dimensions must keep 16-byte alignment (ldvt >= M, %% 8)");
+    VTM_REQUIRE(h <= 65535 && B <= 65535, "vtm_attention: grid too large");
+    hipStream_t s = vtm::as_stream(stream);
+    if (dtype == VTM_F16)
+        return dispatch<__half>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, share_groups, s);
+    if (dtype == VTM_BF16)
+        return dispatch<vtm_bf16>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, share_groups, s);
+    return vtm::fail(VTM_EINVAL, "vtm_attention: dtype must be VTM_F16 or VTM_BF16");
+}

@@ -1,0 +1,43 @@
+// Shared host-side helpers for libvidtome_hip.so (gfx950 only; no CUDA/HIP dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/vidtome_hip.h"
+
+typedef __hip_bfloat16 vtm_bf16;
+
+#define VTM_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace vtm {
+
+char *err_buf();            // thread-local message buffer (api.hip)
+int fail(int code, const char *fmt, ...);
+
+inline hipStream_t as_stream(vtm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Call after every kernel launch: picks up launch-configuration errors without synchronising.
+inline int launch_status(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VTM_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return VTM_OK;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// model-dtype element -> fp32 (exact for all three dtypes)
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float to_f32<vtm_bf16>(vtm_bf16 v) { return __bfloat162float(v); }
+
+}  // namespace vtm
+
+#define VTM_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) return vtm::fail(VTM_EINVAL, __VA_ARGS__); \
+    } while (0)

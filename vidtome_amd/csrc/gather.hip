@@ -1,0 +1,140 @@
+// Row gathers: the composed merge closure and the composed unmerge closure (+ residual).
+// Reference: vidtome/merge.py:119-133 / 423-437 (merge, replace mode = pure row selection),
+// merge.py:135-155 / 439-460 (unmerge: every output row written exactly once -> a gather with the
+// inverse map, no zero fill, no atomics), vidtome/patch.py:80 (global-token update), patch.py:168-169
+// (unmerge + residual add).
+// HBM-bound: one 16-byte chunk per thread, consecutive threads walk consecutive chunks of a row, so a
+// wave moves 1 KiB of contiguous bytes per row segment.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ const char *pool_row_bytes(const char *x0, int64_t P0, const char *x1,
+                                                      int64_t P1, int64_t b, int64_t r,
+                                                      int64_t row_bytes) {
+    return r < P0 ? x0 + (b * P0 + r) * row_bytes : x1 + (b * P1 + (r - P0)) * row_bytes;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char *__restrict__ x0, int64_t P0,
+                                                          const char *__restrict__ x1, int64_t P1,
+                                                          int64_t B, int64_t row_bytes,
+                                                          const int32_t *__restrict__ map, int64_t M,
+                                                          char *__restrict__ out, int64_t out_rows) {
+    const int64_t chunks = row_bytes / 16;
+    const int64_t total = B * M * chunks;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = idx % chunks;
+        const int64_t row = idx / chunks;  // b * M + p
+        const int64_t b = row / M;
+        const char *src = pool_row_bytes(x0, P0, x1, P1, b, map[row], row_bytes);
+        *reinterpret_cast<uint4 *>(out + (b * out_rows + row % M) * row_bytes + c * 16) =
+            *reinterpret_cast<const uint4 *>(src + c * 16);
+    }
+}
+
+template <typename T> struct Add16;
+template <> struct Add16<float> {
+    __device__ static uint4 apply(uint4 a, uint4 b) {
+        float4 x = *reinterpret_cast<float4 *>(&a), y = *reinterpret_cast<float4 *>(&b);
+        float4 r = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        return *reinterpret_cast<uint4 *>(&r);
+    }
+};
+template <> struct Add16<__half> {
+    // fp16 + fp16 rounded once to fp16 (the sum of two halves is exact in fp32) == torch's half add
+    __device__ static uint4 apply(uint4 a, uint4 b) {
+        const __half *x = reinterpret_cast<const __half *>(&a), *y = reinterpret_cast<const __half *>(&b);
+        uint4 r;
+        __half *o = reinterpret_cast<__half *>(&r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = __float2half_rn(__half2float(x[j]) + __half2float(y[j]));
+        return r;
+    }
+};
+template <> struct Add16<vtm_bf16> {
+    __device__ static uint4 apply(uint4 a, uint4 b) {
+        const vtm_bf16 *x = reinterpret_cast<const vtm_bf16 *>(&a),
+                           *y = reinterpret_cast<const vtm_bf16 *>(&b);
+        uint4 r;
+        vtm_bf16 *o = reinterpret_cast<vtm_bf16 *>(&r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = __float2bfloat16(__bfloat162float(x[j]) + __bfloat162float(y[j]));
+        return r;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void unmerge_add_kernel(const char *__restrict__ y, int64_t M,
+                                                          const int32_t *__restrict__ inv,
+                                                          const char *__restrict__ resid, int64_t B,
+                                                          int64_t L, int64_t row_bytes,
+                                                          char *__restrict__ out) {
+    const int64_t chunks = row_bytes / 16;
+    const int64_t total = B * L * chunks;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = idx % chunks;
+        const int64_t row = idx / chunks;  // b * L + i
+        const int64_t b = row / L;
+        uint4 v = *reinterpret_cast<const uint4 *>(y + (b * M + inv[row]) * row_bytes + c * 16);
+        if (resid) {
+            const uint4 r = *reinterpret_cast<const uint4 *>(resid + row * row_bytes + c * 16);
+            v = Add16<T>::apply(v, r);
+        }
+        *reinterpret_cast<uint4 *>(out + row * row_bytes + c * 16) = v;
+    }
+}
+
+inline int esize(int dtype) { return dtype == VTM_F32 ? 4 : (dtype == VTM_F16 || dtype == VTM_BF16) ? 2 : 0; }
+
+inline unsigned grid_for(int64_t total) {
+    int64_t blocks = vtm::cdiv(total, 256);
+    const int64_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride beyond that
+    return (unsigned)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap);
+}
+
+}  // namespace
+
+VTM_EXPORT int vtm_gather_rows(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype,
+                               int64_t B, int64_t C, const int32_t *map, int64_t M, void *out,
+                               int64_t out_rows, vtm_stream_t stream) {
+    VTM_REQUIRE(x0 && map && out, "vtm_gather_rows: null pointer");
+    VTM_REQUIRE(P1 == 0 || x1, "vtm_gather_rows: x1 is null but P1 > 0");
+    const int es = esize(dtype);
+    VTM_REQUIRE(es, "vtm_gather_rows: unsupported dtype %d", dtype);
+    VTM_REQUIRE(out_rows >= M, "vtm_gather_rows: out_rows < M");
+    VTM_REQUIRE(B > 0 && C > 0 && M >= 0 && (C * es) % 16 == 0,
+                "vtm_gather_rows: row size %lld B must be a multiple of 16", (long long)(C * es));
+    if (M == 0) return VTM_OK;
+    const int64_t total = B * M * (C * es / 16);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(256), 0, vtm::as_stream(stream),
+                       (const char *)x0, P0, (const char *)x1, P1, B, C * es, map, M, (char *)out, out_rows);
+    return vtm::launch_status("vtm_gather_rows");
+}
+
+VTM_EXPORT int vtm_unmerge_add(const void *y, int64_t M, const int32_t *inv, const void *resid, int dtype,
+                               int64_t B, int64_t L, int64_t C, void *out, vtm_stream_t stream) {
+    VTM_REQUIRE(y && inv && out, "vtm_unmerge_add: null pointer");
+    const int es = esize(dtype);
+    VTM_REQUIRE(es, "vtm_unmerge_add: unsupported dtype %d", dtype);
+    VTM_REQUIRE(B > 0 && C > 0 && L > 0 && M > 0 && (C * es) % 16 == 0,
+                "vtm_unmerge_add: bad sizes (row bytes must be a multiple of 16)");
+    const int64_t total = B * L * (C * es / 16);
+    hipStream_t s = vtm::as_stream(stream);
+    const unsigned g = grid_for(total);
+    switch (dtype) {
+        case VTM_F32:
+            hipLaunchKernelGGL(unmerge_add_kernel<float>, dim3(g), dim3(256), 0, s, (const char *)y, M, inv,
+                               (const char *)resid, B, L, C * es, (char *)out);
+            break;
+        case VTM_F16:
+            hipLaunchKernelGGL(unmerge_add_kernel<__half>, dim3(g), dim3(256), 0, s, (const char *)y, M, inv,
+                               (const char *)resid, B, L, C * es, (char *)out);
+            break;
+        default:
+            hipLaunchKernelGGL(unmerge_add_kernel<vtm_bf16>, dim3(g), dim3(256), 0, s, (const char *)y, M,
+                               inv, (const char *)resid, B, L, C * es, (char *)out);
+    }
+    return vtm::launch_status("vtm_unmerge_add");
+}

@@ -1,0 +1,213 @@
+// Index planning: partition (src/dst split), index split after the sort, composed merge/unmerge maps.
+// Everything here is tiny int32 work kept on the device so that a block's whole merge plan is built
+// without a host round trip (the reference builds the same index tensors with ~20 small torch ops per
+// level: vidtome/merge.py:52-74, 98-117, 119-155; vidtome/patch.py:44-85).
+#include "common.h"
+
+namespace {
+
+// number of dst frames among frames [0, f): frames g with g % ts == randf
+__device__ __host__ inline int64_t dst_frames_before(int64_t f, int64_t ts, int64_t randf) {
+    return f > randf ? (f - randf - 1) / ts + 1 : 0;
+}
+
+// merge.py:59-69: position p of the input sequence -> (is_dst, index inside a_idx / b_idx)
+__global__ __launch_bounds__(256) void partition_local_kernel(
+    const int32_t *__restrict__ cur, int64_t B, int64_t N_in, int64_t unm_pre, int64_t tnum, int64_t ts,
+    int64_t randf, int32_t *__restrict__ a_pos, int32_t *__restrict__ b_pos,
+    int32_t *__restrict__ a_rows, int32_t *__restrict__ b_rows, int64_t Ns, int64_t Nd) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * N_in) return;
+    const int64_t b = idx / N_in, p = idx % N_in;
+    const int32_t row = cur ? cur[idx] : (int32_t)p;
+    const int64_t n_frame_dst = Nd - unm_pre;  // dst positions that come from frames
+    bool is_dst;
+    int64_t j;
+    if (p < unm_pre) {  // previously unmerged tokens are appended to dst (merge.py:67-69)
+        is_dst = true;
+        j = n_frame_dst + p;
+    } else {
+        const int64_t q = p - unm_pre;
+        const int64_t f = q / tnum, t = q % tnum;
+        const int64_t nb = dst_frames_before(f, ts, randf);
+        is_dst = (f % ts) == randf;
+        j = is_dst ? nb * tnum + t : q - nb * tnum;
+    }
+    if (is_dst) {
+        if (b == 0) b_pos[j] = (int32_t)p;
+        b_rows[b * Nd + j] = row;
+    } else {
+        if (b == 0) a_pos[j] = (int32_t)p;
+        a_rows[b * Ns + j] = row;
+    }
+}
+
+// merge.py:374-375 on cat([local, global]) / cat([global, local]) (patch.py:63-71)
+__global__ __launch_bounds__(256) void partition_global_kernel(
+    const int32_t *__restrict__ cur_local, int64_t B, int64_t Ml, int64_t anchor_base, int64_t Mg,
+    int local_is_src, int32_t *__restrict__ a_pos, int32_t *__restrict__ b_pos,
+    int32_t *__restrict__ a_rows, int32_t *__restrict__ b_rows) {
+    const int64_t N = Ml + Mg;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * N) return;
+    const int64_t b = idx / N, p = idx % N;
+    const int64_t src_len = local_is_src ? Ml : Mg;
+    // pool row id of position p of the concatenated sequence
+    int32_t row;
+    if (local_is_src)
+        row = p < Ml ? cur_local[b * Ml + p] : (int32_t)(anchor_base + (p - Ml));
+    else
+        row = p < Mg ? (int32_t)(anchor_base + p) : cur_local[b * Ml + (p - Mg)];
+    if (p < src_len) {
+        if (b == 0) a_pos[p] = (int32_t)p;
+        a_rows[b * src_len + p] = row;
+    } else {
+        const int64_t j = p - src_len;
+        if (b == 0) b_pos[j] = (int32_t)p;
+        b_rows[b * (N - src_len) + j] = row;
+    }
+}
+
+// merge.py:100-117 (index split) + 119-155 (closure bookkeeping as maps).
+// One thread per sorted rank e in [0, Ns) and one per dst index j in [0, Nd).
+__global__ __launch_bounds__(256) void plan_apply_kernel(
+    const uint64_t *__restrict__ best, const int32_t *__restrict__ perm,
+    const int32_t *__restrict__ a_pos, const int32_t *__restrict__ b_pos,
+    const int32_t *__restrict__ a_rows, const int32_t *__restrict__ b_rows, int64_t B, int64_t N_in,
+    int64_t Ns, int64_t Nd, int64_t r, int align, int32_t *__restrict__ new_cur,
+    int32_t *__restrict__ inv, int32_t *__restrict__ unm_idx, int32_t *__restrict__ src_idx,
+    int32_t *__restrict__ dst_idx) {
+    const int64_t per = Ns + Nd;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * per) return;
+    const int64_t b = idx / per, e = idx % per;
+    const int64_t U = Ns - r, M = U + Nd;
+    if (e < Ns) {
+        const int64_t bb = align ? 0 : b;  // aligned: one matching shared by all samples (merge.py:106-108)
+        const int32_t i = perm[bb * Ns + e];
+        if (e < r) {  // merged src token: restored from its dst (merge.py:142,152-153)
+            const uint32_t ni = ~(uint32_t)(best[bb * Ns + i] & 0xffffffffull);
+            const int32_t dj = (int32_t)(align ? ni % (uint32_t)Nd : ni);  // merge.py:102-103 / 117
+            inv[b * N_in + a_pos[i]] = (int32_t)(U + dj);
+            if (src_idx) src_idx[b * r + e] = i;
+            if (dst_idx) dst_idx[b * r + e] = dj;
+        } else {  // unmerged src token: kept, in similarity-rank order (merge.py:124,149-150)
+            const int64_t u = e - r;
+            new_cur[b * M + u] = a_rows[b * Ns + i];
+            inv[b * N_in + a_pos[i]] = (int32_t)u;
+            if (unm_idx) unm_idx[b * U + u] = i;
+        }
+    } else {  // dst token (merge.py:133,147)
+        const int64_t j = e - Ns;
+        new_cur[b * M + U + j] = b_rows[b * Nd + j];
+        inv[b * N_in + b_pos[j]] = (int32_t)(U + j);
+    }
+}
+
+__global__ __launch_bounds__(256) void compose_kernel(const int32_t *__restrict__ inv_acc,
+                                                      const int32_t *__restrict__ inv_level, int64_t B,
+                                                      int64_t n, int64_t level_len, int64_t offset,
+                                                      int32_t *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n) return;
+    const int64_t b = idx / n, i = idx % n;
+    const int64_t p = inv_acc ? inv_acc[idx] : i;
+    out[idx] = inv_level[b * level_len + offset + p];
+}
+
+__global__ __launch_bounds__(256) void decode_best_kernel(const uint64_t *__restrict__ best, int64_t n,
+                                                          float *__restrict__ node_max,
+                                                          int32_t *__restrict__ node_idx) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const uint64_t k = best[idx];
+    if (node_idx) node_idx[idx] = (int32_t)(~(uint32_t)(k & 0xffffffffull));
+    if (node_max) {
+        const uint32_t o = (uint32_t)(k >> 32);
+        uint32_t u;
+        if (o == 0xffffffffu)
+            u = 0x7fc00000u;  // NaN
+        else
+            u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+        node_max[idx] = __uint_as_float(u);
+    }
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)vtm::cdiv(n, 256); }
+
+}  // namespace
+
+VTM_EXPORT int vtm_partition_counts(int64_t N_in, int64_t unm_pre, int64_t tnum, int64_t ts,
+                                    int64_t randf, int64_t *Ns, int64_t *Nd) {
+    VTM_REQUIRE(Ns && Nd && N_in >= unm_pre && unm_pre >= 0 && tnum > 0 && ts > 0 && randf >= 0 &&
+                    randf < ts,
+                "vtm_partition_counts: bad arguments");
+    // frames are q / tnum for q in [0, N_in - unm_pre); the last one may be partial (and, when
+    // (N_in - unm_pre) % F != 0, has an index >= F exactly as in the reference: merge.py:59-60)
+    const int64_t Q = N_in - unm_pre;
+    int64_t nd = 0;
+    for (int64_t f = 0; f * tnum < Q; ++f)
+        if (f % ts == randf) nd += (Q - f * tnum) < tnum ? (Q - f * tnum) : tnum;
+    *Nd = nd + unm_pre;
+    *Ns = Q - nd;
+    return VTM_OK;
+}
+
+VTM_EXPORT int vtm_partition_local(const int32_t *cur, int64_t B, int64_t N_in, int64_t unm_pre,
+                                   int64_t tnum, int64_t ts, int64_t randf, int32_t *a_pos,
+                                   int32_t *b_pos, int32_t *a_rows, int32_t *b_rows, int64_t Ns,
+                                   int64_t Nd, vtm_stream_t stream) {
+    VTM_REQUIRE(a_pos && b_pos && a_rows && b_rows, "vtm_partition_local: null pointer");
+    int64_t ns = 0, nd = 0;
+    if (int rc = vtm_partition_counts(N_in, unm_pre, tnum, ts, randf, &ns, &nd)) return rc;
+    VTM_REQUIRE(ns == Ns && nd == Nd, "vtm_partition_local: Ns/Nd (%lld,%lld) != expected (%lld,%lld)",
+                (long long)Ns, (long long)Nd, (long long)ns, (long long)nd);
+    VTM_REQUIRE(B > 0, "vtm_partition_local: B must be positive");
+    hipLaunchKernelGGL(partition_local_kernel, dim3(blocks_for(B * N_in)), dim3(256), 0,
+                       vtm::as_stream(stream), cur, B, N_in, unm_pre, tnum, ts, randf, a_pos, b_pos,
+                       a_rows, b_rows, Ns, Nd);
+    return vtm::launch_status("vtm_partition_local");
+}
+
+VTM_EXPORT int vtm_partition_global(const int32_t *cur_local, int64_t B, int64_t Ml, int64_t anchor_base,
+                                    int64_t Mg, int local_is_src, int32_t *a_pos, int32_t *b_pos,
+                                    int32_t *a_rows, int32_t *b_rows, vtm_stream_t stream) {
+    VTM_REQUIRE(cur_local && a_pos && b_pos && a_rows && b_rows, "vtm_partition_global: null pointer");
+    VTM_REQUIRE(B > 0 && Ml > 0 && Mg > 0, "vtm_partition_global: bad sizes");
+    hipLaunchKernelGGL(partition_global_kernel, dim3(blocks_for(B * (Ml + Mg))), dim3(256), 0,
+                       vtm::as_stream(stream), cur_local, B, Ml, anchor_base, Mg, local_is_src, a_pos,
+                       b_pos, a_rows, b_rows);
+    return vtm::launch_status("vtm_partition_global");
+}
+
+VTM_EXPORT int vtm_plan_apply(const uint64_t *best, const int32_t *perm, const int32_t *a_pos,
+                              const int32_t *b_pos, const int32_t *a_rows, const int32_t *b_rows,
+                              int64_t B, int64_t N_in, int64_t Ns, int64_t Nd, int64_t r, int align,
+                              int32_t *new_cur, int32_t *inv, int32_t *unm_idx, int32_t *src_idx,
+                              int32_t *dst_idx, vtm_stream_t stream) {
+    VTM_REQUIRE(best && perm && a_pos && b_pos && a_rows && b_rows && new_cur && inv,
+                "vtm_plan_apply: null pointer");
+    VTM_REQUIRE(B > 0 && Ns >= 0 && Nd > 0 && r >= 0 && r <= Ns && N_in == Ns + Nd,
+                "vtm_plan_apply: bad sizes");
+    hipLaunchKernelGGL(plan_apply_kernel, dim3(blocks_for(B * (Ns + Nd))), dim3(256), 0,
+                       vtm::as_stream(stream), best, perm, a_pos, b_pos, a_rows, b_rows, B, N_in, Ns, Nd,
+                       r, align, new_cur, inv, unm_idx, src_idx, dst_idx);
+    return vtm::launch_status("vtm_plan_apply");
+}
+
+VTM_EXPORT int vtm_compose(const int32_t *inv_acc, const int32_t *inv_level, int64_t B, int64_t n,
+                           int64_t level_len, int64_t offset, int32_t *out, vtm_stream_t stream) {
+    VTM_REQUIRE(inv_level && out && B > 0 && n > 0 && offset >= 0, "vtm_compose: bad arguments");
+    hipLaunchKernelGGL(compose_kernel, dim3(blocks_for(B * n)), dim3(256), 0, vtm::as_stream(stream),
+                       inv_acc, inv_level, B, n, level_len, offset, out);
+    return vtm::launch_status("vtm_compose");
+}
+
+VTM_EXPORT int vtm_decode_best(const uint64_t *best, int64_t n, float *node_max, int32_t *node_idx,
+                               vtm_stream_t stream) {
+    VTM_REQUIRE(best && n >= 0, "vtm_decode_best: bad arguments");
+    if (n == 0) return VTM_OK;
+    hipLaunchKernelGGL(decode_best_kernel, dim3(blocks_for(n)), dim3(256), 0, vtm::as_stream(stream),
+                       best, n, node_max, node_idx);
+    return vtm::launch_status("vtm_decode_best");
+}

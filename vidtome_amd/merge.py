@@ -1,0 +1,169 @@
+"""Cross-frame bipartite soft matching on MI355X -- the host side of vidtome/merge.py.
+
+Public surface mirrors the reference (same names, argument meaning, return protocol and error behaviour):
+
+* ``do_nothing``                           <- vidtome/merge.py:5-6
+* ``bipartite_soft_matching_randframe``    <- vidtome/merge.py:20-159   (local merging)
+* ``bipartite_soft_matching_2s``           <- vidtome/merge.py:343-463  (global merging)
+
+Each matcher returns ``(merge, unmerge, ret_dict)`` closures like the reference, but the closures hold
+*composed row maps* on the device instead of index tensors + gather/scatter code: in ``replace`` mode (the
+only mode the reference's ``compute_merge`` ever uses, patch.py:45-46,73-75) merged tokens are a pure row
+selection, so ``merge`` is one gather and ``unmerge`` is one gather with the inverse map.
+
+The arithmetic lives in libvidtome_hip.so (``_lib``): fused normalise+split, fused score+row-max on the
+fp32 MFMA, radix argsort, index planning.  Nothing here touches the CPU except the two RNG draws the
+reference also makes on its generator (merge.py:57-58, patch.py:62).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def do_nothing(x: torch.Tensor, mode: str = None, **kwargs):
+    """vidtome/merge.py:5-6."""
+    return x
+
+
+@dataclass
+class Level:
+    """Result of one matching level, everything device-resident (int32)."""
+    N_in: int
+    Ns: int
+    Nd: int
+    r: int
+    new_cur: torch.Tensor              # (B, U + Nd) pool row id of every merged token  (merge closure)
+    inv: torch.Tensor                  # (B, N_in)  merged position each input position is restored from
+    a_pos: torch.Tensor                # (Ns,)  = a_idx of the reference
+    b_pos: torch.Tensor                # (Nd,)  = b_idx
+    best: torch.Tensor                 # packed row maxima (see include/vidtome_hip.h)
+    unm_idx: Optional[torch.Tensor] = None
+    src_idx: Optional[torch.Tensor] = None
+    dst_idx: Optional[torch.Tensor] = None
+
+    @property
+    def unm_num(self) -> int:
+        return self.Ns - self.r
+
+
+def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float, align_batch: bool,
+               want_indices: bool) -> Level:
+    """normalise+split -> fused score/top-1 -> argsort -> index split  (merge.py:84-117 / 389-421)."""
+    a_pos, b_pos, a_rows, b_rows = parts
+    Ns, Nd = a_rows.shape[1], b_rows.shape[1]
+    a_op, _ = _lib.normalize_gather(x0, x1, a_rows)
+    b_op, _ = _lib.normalize_gather(x0, x1, b_rows)
+    r = min(Ns, int(Ns * ratio))                       # merge.py:90 (Python float -> int truncation)
+    best = _lib.match(a_op, b_op, Ns, Nd, align_batch)
+    perm = _lib.sort_desc(best)
+    new_cur, inv, unm_idx, src_idx, dst_idx = _lib.plan_apply(best, perm, a_pos, b_pos, a_rows, b_rows, r,
+                                                              align_batch, want_indices)
+    return Level(Ns + Nd, Ns, Nd, r, new_cur, inv, a_pos, b_pos, best, unm_idx, src_idx, dst_idx)
+
+
+def local_level(x0: torch.Tensor, cur: Optional[torch.Tensor], N_in: int, F: int, ratio: float, unm_pre: int,
+                randf: int, target_stride: int, align_batch: bool, want_indices: bool = False) -> Level:
+    """One level of local merging on the joined chunk x0 (B, L, C); ``cur`` maps the current sequence to
+    rows of x0 (None = identity)."""
+    B = x0.shape[0]
+    tnum = (N_in - unm_pre) // F                       # merge.py:43
+    ts = min(target_stride, F)                         # merge.py:56
+    parts = _lib.partition_local(cur, B, N_in, unm_pre, tnum, ts, randf, x0.device)
+    return _run_level(x0, None, parts, ratio, align_batch, want_indices)
+
+
+def global_level(x0: torch.Tensor, anchors: torch.Tensor, cur_local: Optional[torch.Tensor], Ml: int,
+                 local_is_src: bool, ratio: float, align_batch: bool, want_indices: bool = False) -> Level:
+    """Global merging of the chunk's local tokens against the block's anchor tokens (patch.py:59-82)."""
+    B, L, _ = x0.shape
+    if cur_local is None:
+        cur_local = torch.arange(Ml, dtype=torch.int32, device=x0.device).expand(B, Ml).contiguous()
+    parts = _lib.partition_global(cur_local, L, anchors.shape[1], local_is_src)
+    return _run_level(x0, anchors, parts, ratio, align_batch, want_indices)
+
+
+def draw_randf(generator: torch.Generator, ts: int) -> int:
+    """merge.py:57-58: ``torch.randint(0, target_stride, [1], generator=generator)`` on the CPU generator."""
+    return int(torch.randint(0, ts, torch.Size([1]), generator=generator, device=generator.device))
+
+
+def _check_metric(metric: torch.Tensor) -> torch.Tensor:
+    if metric.dim() != 3:
+        raise ValueError("metric must be [B, N, C]")
+    if not metric.is_cuda:
+        raise RuntimeError("vidtome_amd runs on the GPU only (no CPU path); got a CPU tensor")
+    return metric.contiguous()
+
+
+def _make_closures(level: Level, N: int, out_slice: Optional[Tuple[int, int]] = None, merge_mode="replace"):
+    def merge(x: torch.Tensor, mode=None) -> torch.Tensor:
+        mode = mode if mode is not None else merge_mode
+        if mode != "replace":
+            # the reference's other modes (scatter_reduce, merge.py:127-131) are never reached from
+            # compute_merge and are outside the hot path
+            raise NotImplementedError(f"merge mode {mode!r}: only 'replace' is implemented")
+        return _lib.gather_rows(x.contiguous(), None, level.new_cur)
+
+    def unmerge(x: torch.Tensor, **kwarg) -> torch.Tensor:
+        inv = level.inv
+        if out_slice is not None:                       # merge.py:459
+            inv = inv[:, out_slice[0]:out_slice[1]].contiguous()
+        return _lib.unmerge_add(x.contiguous(), inv, None)
+
+    return merge, unmerge
+
+
+def bipartite_soft_matching_randframe(metric: torch.Tensor, F: int, ratio: float, unm_pre: int,
+                                      generator: torch.Generator, target_stride: int = 4,
+                                      align_batch: bool = False, merge_mode: str = "replace"
+                                      ) -> Tuple[Callable, Callable, dict]:
+    """vidtome/merge.py:20-159, same signature.  ``ret_dict`` additionally carries the index tensors the
+    reference keeps in closure cells (a_idx, b_idx, unm_idx, src_idx, dst_idx as int32) for parity tests."""
+    metric = _check_metric(metric)
+    B, N, _ = metric.shape
+    tnum = (N - unm_pre) // F
+    if ratio <= 0:
+        return do_nothing, do_nothing, {"unm_num": tnum}          # merge.py:45-46
+    with torch.no_grad():
+        randf = draw_randf(generator, min(target_stride, F))
+        level = local_level(metric, None, N, F, ratio, unm_pre, randf, target_stride, align_batch, True)
+    merge, unmerge = _make_closures(level, N, None, merge_mode)
+    ret_dict = {"unm_num": level.unm_num, "a_idx": level.a_pos, "b_idx": level.b_pos,
+                "unm_idx": level.unm_idx, "src_idx": level.src_idx, "dst_idx": level.dst_idx,
+                "level": level}
+    return merge, unmerge, ret_dict
+
+
+def bipartite_soft_matching_2s(metric: torch.Tensor, src_len: int, ratio: float, align_batch: bool,
+                               merge_mode: str = "replace", unmerge_chunk: int = 0):
+    """vidtome/merge.py:343-463, same signature (including the 2-tuple returned for ratio <= 0,
+    merge.py:364-365)."""
+    metric = _check_metric(metric)
+    B, N, _ = metric.shape
+    if ratio <= 0:
+        return do_nothing, do_nothing
+    with torch.no_grad():
+        # [src | dst] = [src_len | N - src_len]: expressed as "local = src part, anchors = dst part"
+        x_src = metric[:, :src_len].contiguous()
+        x_dst = metric[:, src_len:].contiguous()
+        level = global_level(x_src, x_dst, None, src_len, True, ratio, align_batch, True)
+    sl = (0, src_len) if unmerge_chunk == 0 else (src_len, N)
+
+    def merge(x: torch.Tensor, mode=None) -> torch.Tensor:
+        mode = mode if mode is not None else merge_mode
+        if mode != "replace":
+            raise NotImplementedError(f"merge mode {mode!r}: only 'replace' is implemented")
+        return _lib.gather_rows(x.contiguous(), None, level.new_cur)
+
+    def unmerge(x: torch.Tensor, **kwarg) -> torch.Tensor:
+        return _lib.unmerge_add(x.contiguous(), level.inv[:, sl[0]:sl[1]].contiguous(), None)
+
+    ret_dict = {"unm_num": level.unm_num, "a_idx": level.a_pos, "b_idx": level.b_pos,
+                "unm_idx": level.unm_idx, "src_idx": level.src_idx, "dst_idx": level.dst_idx,
+                "level": level}
+    return merge, unmerge, ret_dict

@@ -1,0 +1,421 @@
+"""apply_patch / remove_patch / update_patch / collect_from_patch -- the hook API of vidtome/patch.py,
+with the patched self-attention segment executed by libvidtome_hip.so.
+
+Mirrors (file:line under the reference):
+* ``compute_merge``               <- vidtome/patch.py:14-91
+* ``make_diffusers_tome_block``   <- vidtome/patch.py:119-203   (class *named* ToMeBlock, ``_parent``)
+* ``hook_tome_model`` / ``hook_tome_module`` <- vidtome/patch.py:206-231
+* ``apply_patch``                 <- vidtome/patch.py:234-334   (same kwargs and defaults)
+* ``remove_patch``                <- vidtome/patch.py:337-355
+* ``update_patch``                <- vidtome/patch.py:358-370
+* ``collect_from_patch``          <- vidtome/patch.py:373-387
+
+Differences that are design, not omissions:
+* the merge chain of a block is ONE composed gather map and the unmerge chain ONE inverse map (all levels
+  use merge mode "replace", so merged tokens are a row selection of [chunk tokens | anchor tokens]);
+* ``module.global_tokens`` stays on the device (the reference parks it on the CPU and syncs per block,
+  patch.py:65,70,80,82);
+* the block generator is always a CPU generator (see utils.init_generator);
+* ``attn1`` is evaluated from the module's own weights by the fused path (projection GEMMs through
+  hipBLASLt via torch, attention core = vtm_attention), including the reference's PnP injection branch when
+  ``utils/pnp_utils.py``-style control is registered on the module.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Callable, Dict, Optional, Tuple, Type
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, merge
+from .utils import init_generator, isinstance_str, join_frame, split_frame
+
+
+# ----------------------------------------------------------------------------------------------------
+# compute_merge
+# ----------------------------------------------------------------------------------------------------
+class MergePlan:
+    """What ``compute_merge`` produces for one block call: composed maps + the merged tokens."""
+
+    __slots__ = ("fsize", "L", "M", "gather_map", "inv", "merged", "levels", "global_level", "local_chunk",
+                 "x_joined", "anchors_in")
+
+    def __init__(self):
+        self.levels = []
+        self.global_level = None
+        self.local_chunk = None
+        self.gather_map = None
+        self.inv = None
+        self.anchors_in = None
+
+
+def _draw_coin(generator: torch.Generator) -> float:
+    """patch.py:62: ``torch.rand(1, generator=generator, device=generator.device)``."""
+    return float(torch.rand(1, generator=generator, device=generator.device))
+
+
+def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str, Any],
+                  pad_to: int = 8, want_indices: bool = False
+                  ) -> Tuple[Callable, Callable, torch.Tensor]:
+    """vidtome/patch.py:14-91.  Returns ``(m, u, merged_tokens)``; ``u`` accepts ``resid=`` to fuse the
+    residual add of patch.py:169 into the unmerge gather.  ``merged_tokens`` is (B, Mp, C) with
+    Mp = M rounded up to ``pad_to`` rows (zero rows); ``m.plan`` exposes the MergePlan."""
+    original_h, original_w = tome_info["size"]
+    original_tokens = original_h * original_w
+    downsample = int(math.ceil(math.sqrt(original_tokens // x.shape[1])))        # patch.py:17
+    args = tome_info["args"]
+    generator = module.generator
+    fsize = x.shape[0] // args["batch_size"]                                       # patch.py:23
+    tsize = x.shape[1]                                                             # patch.py:24
+
+    if downsample > args["max_downsample"]:                                        # patch.py:27,86-88
+        return merge.do_nothing, merge.do_nothing, x
+
+    if args["generator"] is None:                                                  # patch.py:29-33
+        args["generator"] = init_generator(x.device)
+
+    plan = MergePlan()
+    plan.fsize = fsize
+    with torch.no_grad():
+        xj = join_frame(x.contiguous(), fsize)                                     # patch.py:37 (a view)
+        B, L, C = xj.shape
+        plan.x_joined, plan.L = xj, L
+        cur: Optional[torch.Tensor] = None      # pool row id of every token of the current sequence
+        inv: Optional[torch.Tensor] = None      # composed unmerge map so far
+        n_cur, unm, curF = L, 0, fsize
+        while curF > 1:                                                            # patch.py:44-54
+            ratio = args["local_merge_ratio"]
+            if ratio <= 0:                                                         # merge.py:45-46
+                unm += (n_cur - unm) // curF
+            else:
+                randf = merge.draw_randf(generator, min(args["target_stride"], curF))
+                lv = merge.local_level(xj, cur, n_cur, curF, ratio, unm, randf, args["target_stride"],
+                                       args["align_batch"], want_indices)
+                plan.levels.append(lv)
+                unm += lv.unm_num
+                cur = lv.new_cur
+                inv = _lib.compose(inv, lv.inv, L) if inv is not None else lv.inv
+                n_cur = cur.shape[1]
+            curF = (n_cur - unm) // tsize                                          # patch.py:54
+        Ml = n_cur
+
+        anchors_out = None
+        if args["merge_global"]:                                                   # patch.py:59-82
+            gt = getattr(module, "global_tokens", None)
+            if gt is not None:
+                gt = gt.to(xj).contiguous()                                        # patch.py:65,70
+                coin = _draw_coin(generator)
+                local_is_src = coin > args["global_rand"]                          # patch.py:62
+                res_ratio = args["global_merge_ratio"]
+                if res_ratio <= 0:
+                    # merge.py:364-365 returns a 2-tuple which patch.py:73 unpacks into 3 names
+                    raise ValueError("not enough values to unpack (expected 3, got 2)")
+                gl = merge.global_level(xj, gt, cur, Ml, local_is_src, res_ratio, args["align_batch"],
+                                        want_indices)
+                plan.global_level, plan.local_chunk = gl, (0 if local_is_src else 1)
+                plan.anchors_in = gt
+                off = 0 if local_is_src else gt.shape[1]                           # merge.py:459
+                loc = _lib.compose(None, gl.inv, Ml, off)      # local position -> merged position
+                # patch.py:80: new anchors = u(merged) = the local tokens with every merged local src row
+                # replaced by its matched global row -> one gather from [chunk | old anchors]
+                anchors_out = _lib.gather_rows(xj, gt, _lib.compose(loc, gl.new_cur, Ml))
+                inv = _lib.compose(inv, loc, L) if inv is not None else loc
+                cur = gl.new_cur
+                n_cur = cur.shape[1]
+
+        plan.M = n_cur
+        plan.gather_map, plan.inv = cur, inv
+        if cur is None:
+            merged = xj                                                            # F == 1, nothing merged
+        else:
+            merged = _lib.gather_rows(xj, plan.anchors_in, cur, pad_to=pad_to)
+        plan.merged = merged
+        if args["merge_global"]:
+            if anchors_out is not None:
+                module.global_tokens = anchors_out
+            elif plan.global_level is None:
+                # patch.py:82: first chunk of a step stores its local tokens (device-resident, shared
+                # with `merged`, which nothing mutates)
+                module.global_tokens = merged[:, :Ml] if merged.shape[1] != Ml else merged
+
+    def m(t: torch.Tensor, **kwarg) -> torch.Tensor:                               # patch.py:84
+        tj = join_frame(t.contiguous(), fsize)
+        if plan.gather_map is None:
+            return tj
+        if plan.anchors_in is not None:
+            raise RuntimeError("the composed merge map of a global level needs the anchor tokens; "
+                               "use the merged_tokens compute_merge returned")
+        return _lib.gather_rows(tj, None, plan.gather_map)
+
+    def u(t: torch.Tensor, resid: Optional[torch.Tensor] = None, **kwarg) -> torch.Tensor:   # patch.py:85
+        if plan.inv is None:
+            out = t if resid is None else t + join_frame(resid, fsize)
+            return split_frame(out, fsize)
+        r = None if resid is None else join_frame(resid.contiguous(), fsize)
+        return split_frame(_lib.unmerge_add(t.contiguous(), plan.inv, r), fsize)
+
+    m.plan = plan
+    u.plan = plan
+    return m, u, merged
+
+
+# ----------------------------------------------------------------------------------------------------
+# attn1 on merged tokens
+# ----------------------------------------------------------------------------------------------------
+def _pnp_num_inputs(attn: torch.nn.Module) -> Optional[int]:
+    """If the reference's ``register_attention_control`` (utils/pnp_utils.py:39-106) replaced
+    ``attn.forward`` with its ``sa_forward`` closure, recover ``num_inputs`` from that closure; our own
+    ``vidtome_amd.pnp.register_attention_control`` stores it as ``attn.vtm_num_inputs``."""
+    n = getattr(attn, "vtm_num_inputs", None)
+    if n is not None:
+        return int(n)
+    fwd = attn.__dict__.get("forward")
+    clo = getattr(fwd, "__closure__", None)
+    if fwd is not None and clo:
+        cells = dict(zip(fwd.__code__.co_freevars, clo))
+        if "num_inputs" in cells:
+            return int(cells["num_inputs"].cell_contents)
+    return None
+
+
+def _fused_weights(attn: torch.nn.Module, dtype, device):
+    """[Wq; Wk] stacked once per module (one projection GEMM for q and k), cached on the module."""
+    cache = attn.__dict__.get("_vtm_wcache")
+    wq = attn.to_q.weight
+    key = (wq.data_ptr(), attn.to_k.weight.data_ptr(), wq._version, attn.to_k.weight._version, dtype, device)
+    if cache is None or cache[0] != key:
+        wqk = torch.cat([attn.to_q.weight, attn.to_k.weight], dim=0).to(device=device, dtype=dtype).contiguous()
+        bqk = None
+        if getattr(attn.to_q, "bias", None) is not None or getattr(attn.to_k, "bias", None) is not None:
+            zq = attn.to_q.bias if attn.to_q.bias is not None else torch.zeros_like(attn.to_q.weight[:, 0])
+            zk = attn.to_k.bias if attn.to_k.bias is not None else torch.zeros_like(attn.to_k.weight[:, 0])
+            bqk = torch.cat([zq, zk]).to(device=device, dtype=dtype)
+        cache = (key, wqk, bqk)
+        attn.__dict__["_vtm_wcache"] = cache
+    return cache[1], cache[2]
+
+
+def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = None) -> torch.Tensor:
+    """``attn1(x)`` for self-attention without mask (patch.py:157-162), arithmetic of pnp_utils.py:47-95:
+    q,k,v projections -> softmax(q k^T * scale) v per head -> to_out[0] (+ dropout(0)).
+    x is (B, Mp, C) whose first M rows per sample are the sequence."""
+    B, Mp, C = x.shape
+    M = Mp if M is None else M
+    heads = attn.heads
+    scale = getattr(attn, "scale", None) or (C // heads) ** -0.5
+    share = 1
+    sched = getattr(attn, "injection_schedule", None)
+    if sched is not None:
+        t = getattr(attn, "t", None)
+        if t is not None and (t in sched or t == 1000):                 # pnp_utils.py:57-58
+            n = _pnp_num_inputs(attn)
+            if n is None:
+                raise RuntimeError("PnP injection is registered on attn1 but num_inputs is unknown")
+            share = n
+    if x.shape[1] % 8:
+        # keep the transposed V (B, C, Mp) 16-byte aligned per row
+        pad = 8 - x.shape[1] % 8
+        x = F.pad(x, (0, 0, 0, pad))
+        Mp = x.shape[1]
+    out_dtype = x.dtype
+    if x.dtype == torch.float32:
+        # the attention core is an fp16/bf16 MFMA kernel with fp32 accumulation; fp32 models (tests) run
+        # their projections and attention in fp16 -- the matching path above stays exact fp32
+        x = x.to(torch.float16)
+    wqk, bqk = _fused_weights(attn, x.dtype, x.device)
+    qk = F.linear(x, wqk, bqk)                                           # (B, Mp, 2C): one GEMM for q and k
+    wv = attn.to_v.weight.to(x.dtype)
+    vt = torch.matmul(wv, x.transpose(1, 2))                             # (B, C, Mp): V^T straight from the GEMM
+    if getattr(attn.to_v, "bias", None) is not None:
+        vt = vt + attn.to_v.bias.to(x.dtype)[None, :, None]
+    o = _lib.attention(qk[:, :, :C], qk[:, :, C:], vt, heads, M, scale, share)
+    to_out = attn.to_out[0] if isinstance(attn.to_out, (torch.nn.ModuleList, torch.nn.Sequential, list, tuple)) \
+        else attn.to_out                                                 # pnp_utils.py:41-45
+    return F.linear(o, to_out.weight.to(o.dtype), None if to_out.bias is None else to_out.bias.to(o.dtype)).to(out_dtype)
+
+
+# ----------------------------------------------------------------------------------------------------
+# patched block
+# ----------------------------------------------------------------------------------------------------
+def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.Tensor,
+                                   norm_hidden_states: torch.Tensor, encoder_hidden_states=None,
+                                   attention_mask=None, cross_attention_kwargs=None, gate_msa=None
+                                   ) -> torch.Tensor:
+    """patch.py:148-169: compute_merge -> attn1(merged) -> unmerge -> + residual."""
+    m_a, u_a, merged = compute_merge(block, norm_hidden_states, block._tome_info)
+    cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
+    plan = getattr(m_a, "plan", None)
+    custom = encoder_hidden_states is not None and block.only_cross_attention
+    if custom or attention_mask is not None or cross_attention_kwargs:
+        # not the hot path (SD never masks self-attention nor makes attn1 a cross-attention): run the
+        # module's own attention on the merged tokens exactly as the reference does
+        M = plan.M if plan is not None else merged.shape[1]
+        attn_output = block.attn1(merged[:, :M],
+                                  encoder_hidden_states=encoder_hidden_states if block.only_cross_attention else None,
+                                  attention_mask=attention_mask, **cross_attention_kwargs)
+    else:
+        attn_output = self_attention(block.attn1, merged, plan.M if plan is not None else None)
+    if gate_msa is not None:
+        attn_output = gate_msa.unsqueeze(1) * attn_output
+    if plan is None:
+        return attn_output[:, :hidden_states.shape[1]] + hidden_states
+    return u_a(attn_output, resid=hidden_states)                          # patch.py:168-169 fused
+
+
+def make_diffusers_tome_block(block_class: Type[torch.nn.Module]) -> Type[torch.nn.Module]:
+    """vidtome/patch.py:119-203: patched class made on the fly, named ToMeBlock, keeps ``_parent``."""
+
+    class ToMeBlock(block_class):
+        _parent = block_class
+
+        def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
+                    encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None,
+                    class_labels=None) -> torch.Tensor:
+            gate_msa = None
+            if self.use_ada_layer_norm:                                            # patch.py:139-146
+                norm_hidden_states = self.norm1(hidden_states, timestep)
+            elif self.use_ada_layer_norm_zero:
+                norm_hidden_states, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(
+                    hidden_states, timestep, class_labels, hidden_dtype=hidden_states.dtype)
+            else:
+                norm_hidden_states = self.norm1(hidden_states)
+
+            # 1. self-attention on merged tokens (the hot path)                    # patch.py:148-169
+            hidden_states = patched_self_attention_segment(
+                self, hidden_states, norm_hidden_states, encoder_hidden_states, attention_mask,
+                cross_attention_kwargs, gate_msa)
+
+            cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
+            if self.attn2 is not None:                                             # patch.py:171-185
+                norm_hidden_states = (self.norm2(hidden_states, timestep) if self.use_ada_layer_norm
+                                      else self.norm2(hidden_states))
+                attn_output = self.attn2(norm_hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                         attention_mask=encoder_attention_mask, **cross_attention_kwargs)
+                hidden_states = attn_output + hidden_states
+
+            norm_hidden_states = self.norm3(hidden_states)                         # patch.py:187-199
+            if self.use_ada_layer_norm_zero:
+                norm_hidden_states = norm_hidden_states * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+            ff_output = self.ff(norm_hidden_states)
+            if self.use_ada_layer_norm_zero:
+                ff_output = gate_mlp.unsqueeze(1) * ff_output
+            return ff_output + hidden_states
+
+    return ToMeBlock
+
+
+def hook_tome_model(model: torch.nn.Module):
+    """vidtome/patch.py:206-212: forward pre-hook recording the latent (H, W)."""
+    def hook(module, args):
+        module._tome_info["size"] = (args[0].shape[2], args[0].shape[3])
+        return None
+
+    model._tome_info["hooks"].append(model.register_forward_pre_hook(hook))
+
+
+def hook_tome_module(module: torch.nn.Module):
+    """vidtome/patch.py:215-231: lazily create the block generator; all blocks fork the same state so their
+    draws stay in lock-step within one pass."""
+    def hook(module, args):
+        if not hasattr(module, "generator"):
+            module.generator = init_generator(args[0].device)
+        return None
+
+    module._tome_info["hooks"].append(module.register_forward_pre_hook(hook))
+
+
+def apply_patch(model: torch.nn.Module, local_merge_ratio: float = 0.9, merge_global: bool = False,
+                global_merge_ratio=0.8, max_downsample: int = 2, seed: int = 123, batch_size: int = 2,
+                include_control: bool = False, align_batch: bool = False, target_stride: int = 4,
+                global_rand=0.5):
+    """vidtome/patch.py:234-334 -- same arguments, defaults, return value and errors."""
+    _lib.lib()   # fail loudly right here if the HIP library is missing: there is no fallback
+    remove_patch(model)                                                            # patch.py:277
+    is_diffusers = isinstance_str(model, "DiffusionPipeline") or isinstance_str(model, "ModelMixin")
+    if not is_diffusers:
+        if not hasattr(model, "model") or not hasattr(model.model, "diffusion_model"):
+            raise RuntimeError(
+                "Provided model was not a Stable Diffusion / Latent Diffusion model, as expected.")
+        # the reference's LDM branch (make_tome_block, patch.py:94-116) unpacks 6 values from the 3-tuple
+        # compute_merge returns and cannot run; it is out of scope here as well
+        raise RuntimeError("LDM (non-diffusers) models are not supported: the reference's own LDM patch "
+                           "path is broken (patch.py:105-106 vs :91)")
+    diffusion_model = model.unet if hasattr(model, "unet") else model              # patch.py:290
+    if isinstance_str(model, "StableDiffusionControlNetPipeline") and include_control:
+        diffusion_models = [diffusion_model, model.controlnet]                     # patch.py:292-295
+    else:
+        diffusion_models = [diffusion_model]
+
+    for diffusion_model in diffusion_models:
+        diffusion_model._tome_info = {                                             # patch.py:298-313
+            "size": None,
+            "hooks": [],
+            "args": {
+                "max_downsample": max_downsample,
+                "generator": None,
+                "seed": seed,
+                "batch_size": batch_size,
+                "align_batch": align_batch,
+                "merge_global": merge_global,
+                "global_merge_ratio": global_merge_ratio,
+                "local_merge_ratio": local_merge_ratio,
+                "global_rand": global_rand,
+                "target_stride": target_stride,
+            },
+        }
+        hook_tome_model(diffusion_model)
+        for _, module in diffusion_model.named_modules():
+            if isinstance_str(module, "BasicTransformerBlock"):                    # patch.py:319
+                module.__class__ = make_diffusers_tome_block(module.__class__)
+                module._tome_info = diffusion_model._tome_info
+                hook_tome_module(module)
+                if not hasattr(module, "use_ada_layer_norm_zero"):                 # patch.py:330-332
+                    module.use_ada_layer_norm = False
+                    module.use_ada_layer_norm_zero = False
+    return model
+
+
+def remove_patch(model: torch.nn.Module):
+    """vidtome/patch.py:337-355 (including its quirk of looking for ``.controlnet`` on the unet)."""
+    model = model.unet if hasattr(model, "unet") else model
+    model_ls = [model]
+    if hasattr(model, "controlnet"):
+        model_ls.append(model.controlnet)
+    for model in model_ls:
+        for _, module in model.named_modules():
+            if hasattr(module, "_tome_info"):
+                for hook in module._tome_info["hooks"]:
+                    hook.remove()
+                module._tome_info["hooks"].clear()
+            if module.__class__.__name__ == "ToMeBlock":
+                module.__class__ = module._parent
+    return model
+
+
+def update_patch(model: torch.nn.Module, **kwargs):
+    """vidtome/patch.py:358-370: setattr on every module that carries ``_tome_info``."""
+    model0 = model.unet if hasattr(model, "unet") else model
+    model_ls = [model0]
+    if hasattr(model, "controlnet"):
+        model_ls.append(model.controlnet)
+    for model in model_ls:
+        for _, module in model.named_modules():
+            if hasattr(module, "_tome_info"):
+                for k, v in kwargs.items():
+                    setattr(module, k, v)
+    return model
+
+
+def collect_from_patch(model: torch.nn.Module, attr="tome"):
+    """vidtome/patch.py:373-387."""
+    model0 = model.unet if hasattr(model, "unet") else model
+    model_ls = [model0]
+    if hasattr(model, "controlnet"):
+        model_ls.append(model.controlnet)
+    ret_dict = dict()
+    for model in model_ls:
+        for name, module in model.named_modules():
+            if hasattr(module, attr):
+                ret_dict[name] = getattr(module, attr)
+    return ret_dict

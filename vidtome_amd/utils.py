@@ -1,0 +1,56 @@
+"""Patch helpers -- the counterpart of vidtome/utils.py (same names and behaviour)."""
+from __future__ import annotations
+
+import torch
+
+
+def isinstance_str(x: object, cls_name: str) -> bool:
+    """vidtome/utils.py:4-16: True if any class in x's MRO is *named* cls_name (no import of the class)."""
+    return any(_cls.__name__ == cls_name for _cls in x.__class__.__mro__)
+
+
+def init_generator(device: torch.device, fallback: torch.Generator = None) -> torch.Generator:
+    """vidtome/utils.py:18-30: fork the current default RNG state into a private generator.
+
+    The reference forks the *device's* generator (the CUDA generator when the model is on a GPU).  The
+    parity oracle is the reference's CPU path, and the draws (one randint per local level, one rand per
+    global merge) are host-side control decisions, so this implementation always forks the CPU state:
+    ``torch.Generator('cpu').set_state(torch.get_rng_state())``.  That keeps the draw stream identical to
+    the reference CPU path and avoids a device sync per draw.
+    """
+    return torch.Generator(device="cpu").set_state(torch.get_rng_state())
+
+
+def join_frame(x: torch.Tensor, fsize: int) -> torch.Tensor:
+    """vidtome/utils.py:32-35: '(B F) N C -> B (F N) C' -- a pure view for contiguous x."""
+    BF, N, C = x.shape
+    return x.reshape(BF // fsize, fsize * N, C)
+
+
+def split_frame(x: torch.Tensor, fsize: int) -> torch.Tensor:
+    """vidtome/utils.py:37-40: 'B (F N) C -> (B F) N C'."""
+    B, FN, C = x.shape
+    return x.reshape(B * fsize, FN // fsize, C)
+
+
+def func_warper(funcs):
+    """vidtome/utils.py:42-48."""
+    def fn(x, **kwarg):
+        for func in funcs:
+            x = func(x, **kwarg)
+        return x
+    return fn
+
+
+def join_warper(fsize):
+    """vidtome/utils.py:50-54."""
+    def fn(x, **kwarg):
+        return join_frame(x, fsize)
+    return fn
+
+
+def split_warper(fsize):
+    """vidtome/utils.py:56-60."""
+    def fn(x, **kwarg):
+        return split_frame(x, fsize)
+    return fn
