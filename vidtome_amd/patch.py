@@ -150,6 +150,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
 
     def u(t: torch.Tensor, resid: Optional[torch.Tensor] = None, **kwarg) -> torch.Tensor:   # patch.py:85
         if plan.inv is None:
+            t = t[:, :plan.L]                                  # drop the 8-row padding of the attention path
             out = t if resid is None else t + join_frame(resid, fsize)
             return split_frame(out, fsize)
         r = None if resid is None else join_frame(resid.contiguous(), fsize)
