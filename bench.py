@@ -168,6 +168,11 @@ def main():
     vidtome_amd.apply_patch(unet, local_merge_ratio=LOCAL_RATIO, merge_global=not args.local_only,
                             global_merge_ratio=GLOBAL_RATIO, batch_size=BATCH, target_stride=4, global_rand=0.5)
     unet.set_size(LATENT)
+    if world > 1 and not args.local_only:
+        # north-star multi-GPU mode: every rank owns one chunk; per merging block the ranks all-gather their
+        # local merged tokens over RCCL/xGMI and merge against the previous rank's (chunk_parallel.py)
+        from vidtome_amd import chunk_parallel as cp
+        cp.enable(unet, cp.AllGatherExchange())
     torch.manual_seed(123)           # the block generators fork this state (default.yaml seed)
     # each rank works on its own chunk of the video: different synthetic frames per rank
     hiddens = [sites.synthetic_hidden(s, BATCH, FRAMES, LATENT, torch.float16, dev, seed=1234 + 97 * rank + i)
@@ -214,7 +219,8 @@ def main():
                                    "sites, batch 2 (CFG), local merge 0.5" +
                                    ("" if args.local_only else " + global merge 0.5 (steady state)"),
                        "sites": 16, "merged_sites": 10, "chunk_frames": FRAMES, "batch": BATCH,
-                       "parallelism": f"chunk-parallel x{world}"},
+                       "parallelism": f"chunk-parallel x{world}" + (", RCCL all-gather of the anchor tokens per merging "
+                                                                     "block" if world > 1 else "")},
             "roofline": {"kernel": "match_kernel (fused cosine score + row top-1, v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,

@@ -102,7 +102,12 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
 
         anchors_out = None
         if args["merge_global"]:                                                   # patch.py:59-82
-            gt = getattr(module, "global_tokens", None)
+            exchange = getattr(module, "_vtm_exchange", None)     # chunk-parallel runs (chunk_parallel.py)
+            if exchange is not None:
+                gt = exchange.anchors_for(getattr(module, "_vtm_key", ""),
+                                          lambda: xj if cur is None else _lib.gather_rows(xj, None, cur), xj)
+            else:
+                gt = getattr(module, "global_tokens", None)
             if gt is not None:
                 gt = gt.to(xj).contiguous()                                        # patch.py:65,70
                 coin = _draw_coin(generator)
@@ -138,6 +143,9 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 # patch.py:82: first chunk of a step stores its local tokens (device-resident, shared
                 # with `merged`, which nothing mutates)
                 module.global_tokens = merged[:, :Ml] if merged.shape[1] != Ml else merged
+            exchange = getattr(module, "_vtm_exchange", None)
+            if exchange is not None:
+                exchange.publish(getattr(module, "_vtm_key", ""), module.global_tokens)
 
     def m(t: torch.Tensor, **kwarg) -> torch.Tensor:                               # patch.py:84
         tj = join_frame(t.contiguous(), fsize)
