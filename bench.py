@@ -64,7 +64,7 @@ class MatchTimer:
             e0.record()
             out = self.orig(a, b, Ns, Nd, align)
             e1.record()
-            B, _, C_pad = a.shape
+            B, C_pad = a.shape[0], a.shape[1] * 8
             self.records.append((2.0 * B * Ns * Nd * C_pad, e0, e1))
             return out
         self.lib_mod.match = timed

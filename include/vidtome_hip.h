@@ -51,7 +51,7 @@ const char *vtm_last_error(void);
 
 /* Tile geometry the operand matrices of vtm_match must be padded to (rows to VTM_MATCH_ROW_PAD,
  * channels to VTM_MATCH_K_PAD). */
-#define VTM_MATCH_ROW_PAD 128
+#define VTM_MATCH_ROW_PAD 256
 #define VTM_MATCH_K_PAD 32
 int64_t vtm_pad_rows(int64_t n);
 int64_t vtm_pad_k(int64_t C);
@@ -61,10 +61,12 @@ int64_t vtm_pad_k(int64_t C);
  * (vidtome/merge.py:76-85 and 383-390).
  * The token pool is two row segments: x0 = the joined chunk (B, P0, C) and x1 = the block's global
  * anchor tokens (B, P1, C) (x1 may be NULL when P1 == 0); pool row id p < P0 addresses x0, else x1.
- * rows (B, n) int32 are pool row ids.  out (B, n_pad, C_pad) fp32 receives the normalised rows in the
- * operand layout of vtm_match: within every group of 8 channels the order is [0,2,4,6,1,3,5,7]
- * (so one 16-byte LDS read feeds four consecutive v_mfma_f32_32x32x2_f32 k-steps in ascending k
- * order); rows >= n and channels >= C are zero.  norms (B, n) fp32 receives the row norms (it doubles
+ * rows (B, n) int32 are pool row ids.  out receives the normalised rows in the k-PANEL operand layout of
+ * vtm_match, B * C_pad * n_pad floats indexed [b][g = k/8][kh = k%2][row][e = (k%8)/2]: a panel (g, kh)
+ * holds, for every row, the 4 channels 8g + kh + {0,2,4,6} as one 16-byte entry, so that (i) lane
+ * (row, kh)'s 16-byte read feeds four consecutive v_mfma_f32_32x32x2_f32 k-steps in ascending k order,
+ * (ii) a tile's panel slice is one contiguous run of rows (LDS-DMA friendly, fully coalesced);
+ * rows >= n and channels >= C are zero.  norms (B, n) fp32 receives the row norms (it doubles
  * as the scratch between the two kernels of the call).
  * ---------------------------------------------------------------------------------------------- */
 int vtm_normalize_gather(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
@@ -76,7 +78,7 @@ int vtm_normalize_gather(const void *x0, int64_t P0, const void *x1, int64_t P1,
  * (vidtome/merge.py:87,109-113 and 392,413-417) and, with align != 0, the aligned variant
  * `torch.cat([*scores], dim=-1).max(dim=-1)` (merge.py:93-97 / 397-401).  The (B, Ns, Nd) score
  * matrix is never materialised.
- * a (B, Ns_pad, C_pad), b (B, Nd_pad, C_pad): outputs of vtm_normalize_gather.
+ * a (src, Ns_pad rows), b (dst, Nd_pad rows): k-panel operands written by vtm_normalize_gather.
  * best: (B, Ns) uint64 when align == 0, (Ns) when align != 0.  Each entry is a packed key
  *     (orderable(node_max) << 32) | ~node_idx
  * whose unsigned maximum implements "largest value, first index, first NaN wins"; node_idx is in

@@ -29,9 +29,9 @@ def _t(a, dtype=None):
 
 
 def _deinterleave(op, n, C):
-    """(B, n_pad, C_pad) k-interleaved operand -> (B, n, C) plain."""
-    B, n_pad, C_pad = op.shape
-    g = op.reshape(B, n_pad, C_pad // 8, 2, 4).permute(0, 1, 2, 4, 3).reshape(B, n_pad, C_pad)
+    """(B, G, 2, n_pad, 4) k-panel operand [b][g][kh][row][e] (channel 8g + 2e + kh) -> (B, n, C) plain."""
+    B, G, _, n_pad, _ = op.shape
+    g = op.permute(0, 3, 1, 4, 2).reshape(B, n_pad, G * 8)
     return g[:, :n, :C]
 
 
@@ -56,7 +56,7 @@ def test_normalize_gather_bitwise(L, oracle, dtype):
     ref = oracle.normalize_gather(pool, rows.numpy())
     got = _deinterleave(op, n, C).cpu().numpy()
     assert np.array_equal(_bits(got), _bits(ref))
-    assert torch.count_nonzero(op[:, n:]) == 0 and torch.count_nonzero(op.reshape(B, -1, op.shape[2] // 8, 8)[:, :, C // 8:]) == 0
+    assert torch.count_nonzero(op[:, :, :, n:]) == 0 and torch.count_nonzero(op[:, C // 8:]) == 0
 
 
 @pytest.mark.parametrize("shape", [(2, 37, 29, 24), (3, 300, 513, 40), (1, 129, 128, 320), (2, 1000, 700, 64)])

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.exported_symbols())
     assert _lib.lib().vtm_version() == 1
-    assert _lib.lib().vtm_pad_rows(129) == 256 and _lib.lib().vtm_pad_k(320) == 320 and _lib.lib().vtm_pad_k(40) == 64
+    assert _lib.lib().vtm_pad_rows(257) == 512 and _lib.lib().vtm_pad_k(320) == 320 and _lib.lib().vtm_pad_k(40) == 64
 
 
 def test_partition_counts_match_reference_arithmetic(built, oracle):

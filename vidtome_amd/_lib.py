@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvidtome_hip.so")
 
 VTM_F32, VTM_F16, VTM_BF16 = 0, 1, 2
-ROW_PAD, K_PAD = 128, 32
+ROW_PAD, K_PAD = 256, 32
 
 _DT = {torch.float32: VTM_F32, torch.float16: VTM_F16, torch.bfloat16: VTM_BF16}
 
@@ -112,13 +112,13 @@ def pad_k(c: int) -> int:
 # --------------------------------------------------------------------------------------------------
 def normalize_gather(x0: torch.Tensor, x1: Optional[torch.Tensor], rows: torch.Tensor
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """rows (B, n) int32 pool ids -> (operand (B, n_pad, C_pad) fp32 k-interleaved, norms (B, n))."""
+    """rows (B, n) int32 pool ids -> (operand (B, C_pad/8, 2, n_pad, 4) fp32 k-panels, norms (B, n))."""
     _req(x0, "x0"), _req(rows, "rows")
     B, P0, C = x0.shape
     P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
     n = rows.shape[1]
     n_pad, C_pad = pad_rows(n), pad_k(C)
-    out = torch.empty((B, n_pad, C_pad), dtype=torch.float32, device=x0.device)
+    out = torch.empty((B, C_pad // 8, 2, n_pad, 4), dtype=torch.float32, device=x0.device)
     norms = torch.empty((B, max(n, 1)), dtype=torch.float32, device=x0.device)
     _check(lib().vtm_normalize_gather(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(rows), n,
                                       _ptr(norms), _ptr(out), n_pad, C_pad, _stream()), "vtm_normalize_gather")
@@ -127,8 +127,8 @@ def normalize_gather(x0: torch.Tensor, x1: Optional[torch.Tensor], rows: torch.T
 
 def match(a: torch.Tensor, b: torch.Tensor, Ns: int, Nd: int, align: bool) -> torch.Tensor:
     """Packed (orderable(max) << 32 | ~argmax) per src row: (B, Ns) or (1, Ns) when aligned (int64 bits)."""
-    B, Ns_pad, C_pad = a.shape
-    Nd_pad = b.shape[1]
+    B, G, _, Ns_pad, _ = a.shape
+    C_pad, Nd_pad = G * 8, b.shape[3]
     best = torch.empty((1 if align else B, Ns), dtype=torch.int64, device=a.device)
     _check(lib().vtm_match(_ptr(a), _ptr(b), B, Ns, Nd, Ns_pad, Nd_pad, C_pad, int(align), _ptr(best), _stream()),
            "vtm_match")

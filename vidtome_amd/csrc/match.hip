@@ -4,7 +4,7 @@
 //            merge.py:93-97 (aligned: scores of all samples concatenated on the dst axis);
 //            same statements at merge.py:392-417 for the global matcher.
 // The reference materialises (B, Ns, Nd) fp32 (6.4 GB at the cfg-2 top block) and spends 90 % of the
-// matching time in that bmm; here a 128(dst) x 128(src) score tile lives only in MFMA accumulators.
+// matching time in that bmm; here a 128(dst) x 256(src) score tile lives only in MFMA accumulators.
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 -- exact fp32, bit-for-bit the k-ascending fmaf chain of the
 // oracle (CDNA4 guide section 3), at the fp32 vector peak (157.3 TFLOP/s), so this kernel is bound by
@@ -17,17 +17,28 @@
 // ascending order, so "strictly greater" keeps the first index (torch max semantics); partial results
 // of lanes / waves / workgroups / batch samples (aligned mode) are combined with one 64-bit
 // atomicMax on the packed key (orderable(value) << 32 | ~index), which is order-independent.
+//
+// Data movement (v2): operands are stored as k-panels  [C_pad/8][2][rows][4]  (see vidtome_hip.h):
+//   * the dst tile of a K-step (128 rows x 32 channels = 8 panels x 2 KiB) goes HBM/L2 -> LDS directly
+//     (global_load_lds_dwordx4, no VGPR round trip, no ds_write), lane-linear = conflict-free for the
+//     ds_read_b128 fragment reads, double-buffered, one barrier per K-step;
+//   * every wave owns 64 src rows and streams its B fragments straight into registers (two fully
+//     coalesced 512-byte segments per load), double-buffered in VGPRs -- no LDS, no sharing needed.
+// Per wave and K-step: 128 MFMAs (8192 matrix-pipe cycles) against 4 LDS-DMA issues, 8 global loads and
+// 16 LDS reads.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128;  // dst rows per tile (MFMA A operand)
-constexpr int BN = 128;  // src rows per tile (MFMA B operand)
-constexpr int BK = 32;   // channels per pipeline step
-constexpr int LDS_STRIDE = BK + 4;  // 36 floats: 16-byte aligned rows, conflict-free ds_read_b128
+constexpr int BD = 128;   // dst rows per tile (MFMA A operand, via LDS)
+constexpr int BS = 256;   // src rows per workgroup (MFMA B operand, registers): 64 per wave
+constexpr int BK = 32;    // channels per pipeline step = 4 groups of 8
 constexpr int THREADS = 256;
+constexpr int PANEL_ROWS_BYTES = 16;  // one row of one panel: 4 floats
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
 
 __device__ __forceinline__ uint32_t orderable(float f) {
     // monotone map fp32 -> uint32 (NaN largest, -0 == +0)
@@ -36,17 +47,17 @@ __device__ __forceinline__ uint32_t orderable(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// One thread block: src tile `st` of sample `bi`, dst tiles [jt0, jt1).
+// One workgroup: src rows [st*256, st*256+256) of sample `bi`, dst tiles [jt0, jt1).
 __global__ __launch_bounds__(THREADS, 2) void match_kernel(
     const float *__restrict__ a, const float *__restrict__ b, int64_t Ns, int64_t Nd, int64_t Ns_pad,
     int64_t Nd_pad, int64_t C_pad, int align, int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split,
     unsigned long long *__restrict__ best) {
-    __shared__ __attribute__((aligned(16))) float sA[2][BM * LDS_STRIDE];  // dst tile, double-buffered
-    __shared__ __attribute__((aligned(16))) float sB[2][BN * LDS_STRIDE];  // src tile
+    // dst tile of one K-step as 8 panels [g][kh][128 rows][4 floats], double-buffered (2 x 16 KiB)
+    __shared__ __attribute__((aligned(16))) float sA[2][8 * BD * 4];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;  // wave's 64 dst rows / 64 src rows inside the tile
-    const int l31 = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
 
     int id = blockIdx.x;
     const int split = id % nsplit;
@@ -57,115 +68,113 @@ __global__ __launch_bounds__(THREADS, 2) void match_kernel(
     const int jt1 = min(jt0 + tiles_per_split, nd_tiles);
     if (jt0 >= jt1) return;
 
-    const float *srcmat = a + ((int64_t)bi * Ns_pad + (int64_t)st * BN) * C_pad;
-    const float *dstmat = b + (int64_t)bi * Nd_pad * C_pad;
     const int KT = (int)(C_pad / BK);
     const int steps = (jt1 - jt0) * KT;
+    const float *srcmat = a + (int64_t)bi * C_pad * Ns_pad;   // panels of the src operand
+    const float *dstmat = b + (int64_t)bi * C_pad * Nd_pad;   // panels of the dst operand
+    const int64_t srow0 = (int64_t)st * BS + wave * 64;
 
-    // staging: thread t moves 4 + 4 float4 per step: rows (t >> 3) + 32 q, 16-byte chunk (t & 7)
-    const int ld_row = tid >> 3, ld_chunk = tid & 7;
-    float4 ra[4], rb[4];
-    auto issue_loads = [&](int s) {
+    // B fragments of one 8-channel group: [src block sb] float4 = k-pairs (8g + 2e + kh), e = 0..3;
+    // double-buffered in registers at GROUP granularity (32 MFMAs = 2048 matrix-pipe cycles of cover)
+    float4 rb[2][2];
+    auto load_b = [&](int gi, float4 (&dst)[2]) {
+        const int kt = (gi >> 2) % KT, g = gi & 3;
+        const float *p = srcmat + (((int64_t)(kt * 4 + g) * 2 + kh) * Ns_pad + srow0 + l31) * 4;
+        dst[0] = *reinterpret_cast<const float4 *>(p);
+        dst[1] = *reinterpret_cast<const float4 *>(p + 32 * 4);
+    };
+    // A tile of one K-step: 16 LDS-DMA wave-instructions of 1 KiB (8 panels x 2 halves of 64 rows); wave w
+    // issues 4 of them.  LDS image is lane-linear, i.e. exactly [panel][row][4].
+    auto load_a = [&](int s, int buf) {
         const int jt = jt0 + s / KT, kt = s % KT;
-        const float *pa = dstmat + ((int64_t)jt * BM + ld_row) * C_pad + kt * BK + ld_chunk * 4;
-        const float *pb = srcmat + (int64_t)ld_row * C_pad + kt * BK + ld_chunk * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ra[q] = *reinterpret_cast<const float4 *>(pa + (int64_t)q * 32 * C_pad);
-            rb[q] = *reinterpret_cast<const float4 *>(pb + (int64_t)q * 32 * C_pad);
-        }
-    };
-    auto write_lds = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<float4 *>(&sA[buf][(ld_row + 32 * q) * LDS_STRIDE + ld_chunk * 4]) = ra[q];
-            *reinterpret_cast<float4 *>(&sB[buf][(ld_row + 32 * q) * LDS_STRIDE + ld_chunk * 4]) = rb[q];
+        for (int t = 0; t < 4; ++t) {
+            const int q = wave * 4 + t, p = q >> 1, half = q & 1;
+            const float *gp = dstmat + (((int64_t)kt * 8 + p) * Nd_pad + (int64_t)jt * BD + half * 64 + lane) * 4;
+            float *lp = &sA[buf][(p * BD + half * 64) * 4];
+            __builtin_amdgcn_global_load_lds((glb_void *)gp, (lds_void *)lp, 16, 0, 0);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+        for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[ib][sb][r] = 0.0f;
 
     float bestv[2] = {-INFINITY, -INFINITY};
     uint32_t besti[2] = {0xffffffffu, 0xffffffffu};
     const uint32_t idx_base = align ? (uint32_t)((int64_t)bi * Nd) : 0u;
 
-    issue_loads(0);
-    write_lds(0);
-    __syncthreads();
+    load_a(0, 0);
+    load_b(0, rb[0]);
+    __syncthreads();   // (drains the LDS-DMA: vmcnt(0) + barrier)
 
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < steps) issue_loads(s + 1);
-
-        const float *pA = &sA[buf][(wr * 64 + l31) * LDS_STRIDE + hi * 4];
-        const float *pB = &sB[buf][(wc * 64 + l31) * LDS_STRIDE + hi * 4];
+        if (s + 1 < steps) load_a(s + 1, buf ^ 1);
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            // one 16-byte read = this lane's operand for 4 consecutive k-pairs (k-interleaved layout)
-            const float4 a0 = *reinterpret_cast<const float4 *>(pA + g * 8);
-            const float4 a1 = *reinterpret_cast<const float4 *>(pA + 32 * LDS_STRIDE + g * 8);
-            const float4 b0 = *reinterpret_cast<const float4 *>(pB + g * 8);
-            const float4 b1 = *reinterpret_cast<const float4 *>(pB + 32 * LDS_STRIDE + g * 8);
-            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+        for (int g = 0; g < 4; ++g) {
+            const int gi = s * 4 + g;
+            if (gi + 1 < steps * 4) load_b(gi + 1, rb[(g + 1) & 1]);
+            float4 af[4];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+                af[ib] = *reinterpret_cast<const float4 *>(&sA[buf][((g * 2 + kh) * BD + ib * 32 + l31) * 4]);
+            const float4 b0 = rb[g & 1][0], b1 = rb[g & 1][1];
             const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
+                for (int ib = 0; ib < 4; ++ib) {
+                    const float av = e == 0 ? af[ib].x : e == 1 ? af[ib].y : e == 2 ? af[ib].z : af[ib].w;
 #pragma unroll
-                    for (int tj = 0; tj < 2; ++tj)
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ti][e], bv[tj][e],
-                                                                          acc[ti][tj], 0, 0, 0);
+                    for (int sb = 0; sb < 2; ++sb)
+                        acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[sb][e], acc[ib][sb], 0, 0, 0);
+                }
             }
         }
-
         if ((s + 1) % KT == 0) {
-            // dst tile finished: fold its 64 x 64 wave tile into the per-lane running (max, argmax)
+            // dst tile finished: fold the wave's 128 x 64 scores into the per-lane running (max, argmax)
             const int jt = jt0 + s / KT;
-            const int dst0 = jt * BM + wr * 64 + 4 * hi;
-            const bool full = (int64_t)(jt + 1) * BM <= Nd;
+            const int dst0 = jt * BD + 4 * kh;
+            const bool full = (int64_t)(jt + 1) * BD <= Nd;
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj) {
-                float bv_ = bestv[tj];
-                uint32_t bi_ = besti[tj];
+            for (int sb = 0; sb < 2; ++sb) {
+                float bv_ = bestv[sb];
+                uint32_t bi_ = besti[sb];
 #pragma unroll
-                for (int ti = 0; ti < 2; ++ti) {
+                for (int ib = 0; ib < 4; ++ib) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int d = dst0 + ti * 32 + (r & 3) + 8 * (r >> 2);
-                        const float sc = acc[ti][tj][r];
+                        const int d = dst0 + ib * 32 + (r & 3) + 8 * (r >> 2);
+                        const float sc = acc[ib][sb][r];
                         // s > best, or s is NaN while best is not (first NaN sticks: torch max)
                         bool upd = !(sc <= bv_) && (bv_ == bv_);
                         if (!full) upd = upd && (d < Nd);
                         bv_ = upd ? sc : bv_;
                         bi_ = upd ? (uint32_t)d : bi_;
-                        acc[ti][tj][r] = 0.0f;
+                        acc[ib][sb][r] = 0.0f;
                     }
                 }
-                bestv[tj] = bv_;
-                besti[tj] = bi_;
+                bestv[sb] = bv_;
+                besti[sb] = bi_;
             }
         }
-
-        if (s + 1 < steps) write_lds(buf ^ 1);
-        __syncthreads();
+        __syncthreads();   // next K-step's dst tile has landed (vmcnt(0)) and this one is fully consumed
     }
 
-    // publish: one atomicMax per (lane, src row); combines lane halves, waves, splits and -- in aligned
-    // mode -- the samples of the batch (merge.py:96-97)
+    // publish: one atomicMax per (lane, src row); combines lane halves, splits and -- in aligned mode --
+    // the samples of the batch (merge.py:96-97)
     const int64_t out_row0 = align ? 0 : (int64_t)bi * Ns;
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        const int64_t srow = (int64_t)st * BN + wc * 64 + tj * 32 + l31;
-        if (srow < Ns && besti[tj] != 0xffffffffu) {
+    for (int sb = 0; sb < 2; ++sb) {
+        const int64_t srow = srow0 + sb * 32 + l31;
+        if (srow < Ns && besti[sb] != 0xffffffffu) {
             const unsigned long long key =
-                ((unsigned long long)orderable(bestv[tj]) << 32) | (uint32_t)(~(besti[tj] + idx_base));
+                ((unsigned long long)orderable(bestv[sb]) << 32) | (uint32_t)(~(besti[sb] + idx_base));
             atomicMax(&best[out_row0 + srow], key);
         }
     }
@@ -178,8 +187,8 @@ VTM_EXPORT int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, 
                          vtm_stream_t stream) {
     VTM_REQUIRE(a && b && best, "vtm_match: null pointer");
     VTM_REQUIRE(B > 0 && Ns > 0 && Nd > 0, "vtm_match: bad sizes");
-    VTM_REQUIRE(Ns_pad >= Ns && Ns_pad % BN == 0 && Nd_pad >= Nd && Nd_pad % BM == 0,
-                "vtm_match: row padding must be a multiple of %d", BM);
+    VTM_REQUIRE(Ns_pad >= Ns && Ns_pad % BS == 0 && Nd_pad >= Nd && Nd_pad % BD == 0,
+                "vtm_match: rows must be padded to a multiple of %d", VTM_MATCH_ROW_PAD);
     VTM_REQUIRE(C_pad > 0 && C_pad % BK == 0, "vtm_match: C_pad must be a multiple of %d", BK);
     VTM_REQUIRE(B * Nd < (1ll << 32) - 1, "vtm_match: index space overflow");
     hipStream_t s = vtm::as_stream(stream);
@@ -187,7 +196,7 @@ VTM_EXPORT int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, 
     hipError_t e = hipMemsetAsync(best, 0, (size_t)out_rows * sizeof(uint64_t), s);
     if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match: memset: %s", hipGetErrorString(e));
 
-    const int ns_tiles = (int)(Ns_pad / BN), nd_tiles = (int)(Nd_pad / BM);
+    const int ns_tiles = (int)(Ns_pad / BS), nd_tiles = (int)(Nd_pad / BD);
     // enough workgroups to fill 256 CUs x 2 resident blocks a few times over, but keep >= 4 dst tiles
     // per block so the running-max epilogue and the atomics stay amortised
     int64_t want = vtm::cdiv(1536, (int64_t)ns_tiles * B);

@@ -54,12 +54,14 @@ __global__ __launch_bounds__(256) void write_operand(const T *__restrict__ x0, i
                                                      int64_t n, const float *__restrict__ norms,
                                                      float *__restrict__ out, int64_t n_pad,
                                                      int64_t C_pad) {
+    // one thread per (8-channel group g, row i), rows fastest -> the two 16-byte panel stores of a wave are
+    // contiguous 1 KiB segments.  Panel layout: out[b][g][kh][i][e] = xhat[b, i, 8g + 2e + kh].
     const int64_t G = C_pad / 8;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * n_pad * G) return;
-    const int64_t g = idx % G;
-    const int64_t row = idx / G;  // b * n_pad + i
-    const int64_t b = row / n_pad, i = row % n_pad;
+    const int64_t i = idx % n_pad;
+    const int64_t bg = idx / n_pad;  // b * G + g
+    const int64_t g = bg % G, b = bg / G;
     float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
     if (i < n && g * 8 < C) {
         const T *src = pool_row(x0, P0, x1, P1, b, rows[b * n + i], C) + g * 8;
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(256) void write_operand(const T *__restrict__ x0, i
         lo = make_float4(f[0], f[2], f[4], f[6]);
         hi = make_float4(f[1], f[3], f[5], f[7]);
     }
-    float4 *dst = reinterpret_cast<float4 *>(out + row * C_pad + g * 8);
+    float4 *dst = reinterpret_cast<float4 *>(out) + (bg * 2) * n_pad + i;
     dst[0] = lo;
-    dst[1] = hi;
+    dst[n_pad] = hi;
 }
 
 template <typename T>
