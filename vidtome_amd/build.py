@@ -21,7 +21,10 @@ LIB = os.path.join(LIBDIR, "libvidtome_hip.so")
 SOURCES = ["api.hip", "normalize.hip", "match.hip", "sort.hip", "plan.hip", "gather.hip", "attention.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         # MFMA results straight into VGPRs (gfx950 has a unified file): no v_accvgpr_read/write traffic
+         # between the matrix results and the VALU softmax / running-max code
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def hipcc() -> str:

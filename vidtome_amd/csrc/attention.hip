@@ -4,25 +4,30 @@
 //     sim = einsum("b i d, b j d -> b i j", q, k) * scale;  attn = sim.softmax(-1);  out = attn @ v
 // including its injection branch (probabilities of the source sample reused for every batch group).
 //
-// Structure (v1):
+// Structure:
 //   * workgroup = 4 waves, each wave owns 32 query rows; K / V^T tiles of 64 keys are staged through
-//     LDS (register-staged, double-buffered) and shared by the 4 waves;
+//     LDS (register-staged, double-buffered) and shared by the 4 waves; all per-thread global pointers
+//     and LDS offsets are hoisted, full tiles run without any bounds logic, the ragged last tile has its
+//     own masked path (sequence lengths are 34 816, 52 224, 8 704, 64 513 ...);
 //   * "swapped" QK^T: S^T = K Q^T with v_mfma_f32_32x32x16 puts one query per lane (j = lane & 31) and
 //     its 2 x 16 keys of the tile in that lane's accumulators -> online softmax is in-register, with ONE
 //     cross-half exchange per tile for the running max;
+//   * per score: one v_fma (scale folded, base 2) + one v_exp; the running max is only raised when it grew
+//     by more than 2^8 (deferred rescale: P <= 256 is exact enough in fp16 and the O-rescale, which would
+//     drag the accumulators through VALU every tile, becomes rare);
 //   * P stays in registers: the PV contraction's k-slot <-> key assignment is chosen to be exactly the
 //     one the S^T accumulator layout already has (keys 4*hi + {0..3} and 8 + 4*hi + {0..3} of every
-//     16-key group), and V^T is read from LDS with the same assignment, so no permute / LDS round trip
-//     of P is needed;
-//   * V arrives TRANSPOSED (channel-major) from the projection GEMM, so the V^T operand needs no
-//     transpose either.
-// Sequence lengths are ragged (34 816, 52 224, 8 704, ...): tail keys are masked, tail queries not stored.
+//     16-key group), and V^T is read from LDS with the same assignment -- no permute / LDS round trip;
+//   * V arrives TRANSPOSED (channel-major) from the projection GEMM, so V^T needs no transpose; when the
+//     head dim leaves a spare row in the last 32-row block of O^T (d = 40, 80), that V^T row is set to
+//     ones, so the MFMA itself accumulates the softmax denominator from the SAME fp16-rounded P.
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WAVES = 4;
@@ -30,6 +35,7 @@ constexpr int QW = 32;           // queries per wave
 constexpr int QB = WAVES * QW;   // queries per workgroup
 constexpr int KV = 64;           // keys per tile
 constexpr int VT_STRIDE = KV + 4;  // 68 elements = 34 words: conflict-free ds_read_b64 over 32 rows
+constexpr float DEFER_THR = 8.0f;  // log2 units
 
 template <typename T> struct Frag;
 template <> struct Frag<__half> {
@@ -38,6 +44,12 @@ template <> struct Frag<__half> {
     __device__ static f32x16 mfma(vec a, vec b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
+    __device__ static void pack8(vec &dst, const float (&p)[8]) {
+        // round-to-nearest (v_cvt_pk_f16_f32): a truncating pack would bias the numerator against the fp32
+        // denominator of the head dims without a spare O^T row
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = (_Float16)p[i];
+    }
 };
 template <> struct Frag<vtm_bf16> {
     using vec = b16x8;
@@ -45,29 +57,34 @@ template <> struct Frag<vtm_bf16> {
     __device__ static f32x16 mfma(vec a, vec b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    __device__ static void pack8(vec &dst, const float (&p)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = (__bf16)p[i];
+    }
 };
 
 template <typename T, int D>
-__global__ __launch_bounds__(WAVES * 64) void attention_kernel(
+__global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void attention_kernel(
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
-    const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t Bsz, int64_t H,
+    const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
     int64_t M, int64_t Mp, float scale_log2e, int64_t src_batch) {
     using F = Frag<T>;
     using vec = typename F::vec;
     using elem = typename F::elem;
     constexpr int DK = (D + 15) / 16;      // k-steps of the QK^T contraction
     constexpr int DV = (D + 31) / 32;      // 32-row blocks of O^T
+    constexpr bool SPARE = (D % 32) != 0;  // O^T row D is free -> softmax denominator through the MFMA
     constexpr int K_STRIDE = DK * 16 + 8;  // elements; (DK*8+4) words = 4 x odd -> conflict-free b128
     constexpr int DCH = D / 8;             // 16-byte chunks per K row
     constexpr int K_CHUNKS = KV * DCH;     // per tile
     constexpr int V_CHUNKS = D * (KV / 8);
     constexpr int K_PER_T = (K_CHUNKS + 255) / 256;
     constexpr int V_PER_T = (V_CHUNKS + 255) / 256;
+    constexpr int SK_TILE = KV * K_STRIDE, SV_TILE = DV * 32 * VT_STRIDE;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    elem *sK = reinterpret_cast<elem *>(smem);                       // [2][KV][K_STRIDE]
-    elem *sV = sK + 2 * KV * K_STRIDE;                               // [2][DV*32][VT_STRIDE]
-    constexpr int SK_TILE = KV * K_STRIDE, SV_TILE = DV * 32 * VT_STRIDE;
+    elem *sK = reinterpret_cast<elem *>(smem);   // [2][KV][K_STRIDE]
+    elem *sV = sK + 2 * SK_TILE;                 // [2][DV*32][VT_STRIDE]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -76,10 +93,18 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(
     const int64_t q0 = (int64_t)blockIdx.x * QB + wave * QW;
     const int64_t C = H * D;
 
-    // zero the K pad columns once (they multiply Q's zero padding; garbage could be NaN)
+    // one-time LDS init: K pad columns = 0 (they meet Q's zero padding; garbage could be NaN), V^T pad rows
+    // = 0 except row D = 1 (denominator row) -- tile loads never touch these
     for (int i = tid; i < 2 * KV * (K_STRIDE - D); i += 256) {
         const int row = i / (K_STRIDE - D), c = D + i % (K_STRIDE - D);
         sK[row * K_STRIDE + c] = (elem)0.0f;
+    }
+    if constexpr (DV * 32 > D) {
+        for (int i = tid; i < 2 * (DV * 32 - D) * VT_STRIDE; i += 256) {
+            const int bufi = i / ((DV * 32 - D) * VT_STRIDE), rem = i % ((DV * 32 - D) * VT_STRIDE);
+            const int row = D + rem / VT_STRIDE, c = rem % VT_STRIDE;
+            sV[bufi * SV_TILE + row * VT_STRIDE + c] = (elem)((row == D) ? 1.0f : 0.0f);
+        }
     }
 
     // Q fragments (B operand of S^T = K Q^T): lane (query l31, half hi) holds d = 16 ks + 8 hi + 0..7
@@ -96,56 +121,77 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(
         }
     }
 
-    const T *kbase = k + bq * Mp * ldk + h * D;
-    const T *vbase = vt + (b * C + h * D) * ldvt;
+    // hoisted staging addresses: chunk c = tid + 256 i ; K: (row c / DCH, 16-byte piece c % DCH);
+    // V^T: (channel row c / 8, key piece c % 8).  Per tile the K pointers advance by 64 rows, the V^T
+    // pointers by 64 keys.
+    const T *kptr[K_PER_T];
+    const T *vptr[V_PER_T];
+    int koff[K_PER_T], voff[V_PER_T], krow[K_PER_T], vkey[V_PER_T];
+    bool kok[K_PER_T], vok[V_PER_T];
+#pragma unroll
+    for (int i = 0; i < K_PER_T; ++i) {
+        const int c = tid + i * 256;
+        kok[i] = c < K_CHUNKS;
+        krow[i] = c / DCH;
+        kptr[i] = k + (bq * Mp + krow[i]) * ldk + h * D + (c % DCH) * 8;
+        koff[i] = krow[i] * K_STRIDE + (c % DCH) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < V_PER_T; ++i) {
+        const int c = tid + i * 256;
+        vok[i] = c < V_CHUNKS;
+        vkey[i] = (c % (KV / 8)) * 8;
+        vptr[i] = vt + (b * C + h * D + c / (KV / 8)) * ldvt + vkey[i];
+        voff[i] = (c / (KV / 8)) * VT_STRIDE + vkey[i];
+    }
+    const int64_t kstep = (int64_t)KV * ldk;
 
     uint4 rk[K_PER_T], rv[V_PER_T];
-    auto issue_loads = [&](int64_t key0) {
+    auto issue_full = [&]() {   // tile completely inside [0, M): no bounds logic
 #pragma unroll
         for (int i = 0; i < K_PER_T; ++i) {
-            const int c = tid + i * 256;
+            if (kok[i]) rk[i] = *reinterpret_cast<const uint4 *>(kptr[i]);
+            kptr[i] += kstep;
+        }
+#pragma unroll
+        for (int i = 0; i < V_PER_T; ++i) {
+            if (vok[i]) rv[i] = *reinterpret_cast<const uint4 *>(vptr[i]);
+            vptr[i] += KV;
+        }
+    };
+    auto issue_tail = [&](int64_t key0) {   // ragged last tile: rows / keys >= M read as zero
+#pragma unroll
+        for (int i = 0; i < K_PER_T; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < K_CHUNKS) {
-                const int64_t key = key0 + c / DCH;
-                if (key < M) v = *reinterpret_cast<const uint4 *>(kbase + key * ldk + (c % DCH) * 8);
-            }
+            if (kok[i] && key0 + krow[i] < M) v = *reinterpret_cast<const uint4 *>(kptr[i]);
             rk[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < V_PER_T; ++i) {
-            const int c = tid + i * 256;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < V_CHUNKS) {
-                const int64_t key = key0 + (c % (KV / 8)) * 8;
-                if (key < M) {  // ldvt >= M rounded up to 8, so the 16-byte chunk is inside the row
-                    v = *reinterpret_cast<const uint4 *>(vbase + (int64_t)(c / (KV / 8)) * ldvt + key);
-                    if (key + 8 > M) {  // zero the keys >= M: their p is 0 but 0 * garbage may be NaN
-                        elem *e = reinterpret_cast<elem *>(&v);
+            const int64_t key = key0 + vkey[i];
+            if (vok[i] && key < M) {   // ldvt >= M rounded up to 8: the 16-byte piece is inside the row
+                v = *reinterpret_cast<const uint4 *>(vptr[i]);
+                elem *e = reinterpret_cast<elem *>(&v);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (key + j >= M) e[j] = (elem)0.0f;
-                    }
-                }
+                for (int j = 0; j < 8; ++j)
+                    if (key + j >= M) e[j] = (elem)0.0f;   // p is 0 there, but 0 * garbage may be NaN
             }
             rv[i] = v;
         }
     };
     auto write_lds = [&](int buf) {
+        elem *dk = sK + buf * SK_TILE, *dv = sV + buf * SV_TILE;
 #pragma unroll
-        for (int i = 0; i < K_PER_T; ++i) {
-            const int c = tid + i * 256;
-            if (c < K_CHUNKS)
-                *reinterpret_cast<uint4 *>(&sK[buf * SK_TILE + (c / DCH) * K_STRIDE + (c % DCH) * 8]) = rk[i];
-        }
+        for (int i = 0; i < K_PER_T; ++i)
+            if (kok[i]) *reinterpret_cast<uint4 *>(dk + koff[i]) = rk[i];
 #pragma unroll
-        for (int i = 0; i < V_PER_T; ++i) {
-            const int c = tid + i * 256;
-            if (c < V_CHUNKS) {  // rows are only 8-byte aligned (stride 136 B): two 8-byte stores
-                uint2 *dst = reinterpret_cast<uint2 *>(&sV[buf * SV_TILE + (c / (KV / 8)) * VT_STRIDE + (c % (KV / 8)) * 8]);
+        for (int i = 0; i < V_PER_T; ++i)
+            if (vok[i]) {   // rows are only 8-byte aligned (stride 136 B): two 8-byte stores
+                uint2 *dst = reinterpret_cast<uint2 *>(dv + voff[i]);
                 dst[0] = make_uint2(rv[i].x, rv[i].y);
                 dst[1] = make_uint2(rv[i].z, rv[i].w);
             }
-        }
     };
 
     f32x16 o[DV];
@@ -153,17 +199,18 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(
     for (int dv = 0; dv < DV; ++dv)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dv][r] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
+    float m_run = -INFINITY;   // running max in scaled (log2) units
+    float l_run = 0.0f;        // only used when there is no spare O^T row
 
-    const int64_t ntiles = (M + KV - 1) / KV;
-    issue_loads(0);
+    const int64_t ntiles = (M + KV - 1) / KV, nfull = M / KV;
+    if (nfull > 0) issue_full(); else issue_tail(0);
     write_lds(0);
     __syncthreads();
 
     for (int64_t t = 0; t < ntiles; ++t) {
         const int buf = (int)(t & 1);
-        const int64_t key0 = t * KV;
-        if (t + 1 < ntiles) issue_loads(key0 + KV);
+        if (t + 1 < nfull) issue_full();
+        else if (t + 1 < ntiles) issue_tail((t + 1) * KV);
 
         // ---- S^T = K Q^T : 2 blocks of 32 keys
         f32x16 s[2];
@@ -171,51 +218,51 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
-            const elem *kp = &sK[buf * SK_TILE + (kb * 32 + l31) * K_STRIDE + hi * 8];
+            const elem *kp = sK + buf * SK_TILE + (kb * 32 + l31) * K_STRIDE + hi * 8;
 #pragma unroll
-            for (int ks = 0; ks < DK; ++ks) {
-                const vec kf = *reinterpret_cast<const vec *>(kp + ks * 16);
-                s[kb] = F::mfma(kf, qf[ks], s[kb]);
-            }
+            for (int ks = 0; ks < DK; ++ks)
+                s[kb] = F::mfma(*reinterpret_cast<const vec *>(kp + ks * 16), qf[ks], s[kb]);
+        }
+        if (t >= nfull) {   // ragged tile: keys >= M get -inf; lane (l31, hi) holds keys 32kb+(r&3)+8(r>>2)+4hi
+            const int64_t key0 = t * KV;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= M) s[kb][r] = -INFINITY;
         }
 
-        // ---- online softmax (base 2); lane (query l31, half hi) holds keys
-        //      key0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
-        float mt = -INFINITY;
-        const bool tail = key0 + KV > M;
+        // ---- online softmax, base 2, deferred rescale
+        float mt = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[0][r]), s[1][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
+        if (!__all(mt <= m_run + DEFER_THR)) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
+            m_run = m_new;
+            l_run *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = s[kb][r] * scale_log2e;
-                if (tail && key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= M) x = -INFINITY;
-                s[kb][r] = x;
-                mt = fmaxf(mt, x);
-            }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
-        m_run = m_new;
-        float psum = 0.0f;
+            for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+        }
         vec pf[4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int st = 0; st < 4; ++st) {
+            float p[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-                psum += p;
-                pf[kb * 2 + (r >> 3)][r & 7] = (elem)p;
+            for (int e = 0; e < 8; ++e) {
+                p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st >> 1][8 * (st & 1) + e], scale_log2e, -m_run));
+                if constexpr (!SPARE) l_run += p[e];
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dv = 0; dv < DV; ++dv)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+            F::pack8(pf[st], p);
+        }
 
         // ---- O^T += V^T P^T : 4 steps of 16 keys; k-slot (hi, e) <-> key 16 st + 8 (e >> 2) + 4 hi + (e & 3)
 #pragma unroll
         for (int dv = 0; dv < DV; ++dv) {
-            const elem *vp = &sV[buf * SV_TILE + (dv * 32 + l31) * VT_STRIDE + 4 * hi];
+            const elem *vp = sV + buf * SV_TILE + (dv * 32 + l31) * VT_STRIDE + 4 * hi;
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const uint2 lo = *reinterpret_cast<const uint2 *>(vp + st * 16);
@@ -230,7 +277,15 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(
     }
 
     // ---- epilogue: O / l, row q = q0 + l31, channels dv*32 + (r & 3) + 8 (r >> 2) + 4 hi
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if constexpr (SPARE) {
+        // denominator row D of O^T: block D/32, in-block row D%32 = (r&3) + 8(r>>2) + 4hi
+        constexpr int LB = D / 32, LR = D % 32;
+        constexpr int LHI = (LR >> 2) & 1, LREG = (LR & 3) + 4 * (LR >> 3);
+        l_tot = __shfl(o[LB][LREG], l31 + 32 * LHI, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv_l = 1.0f / l_tot;
     const int64_t qi = q0 + l31;
     if (qi < M) {
@@ -265,7 +320,7 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
     const dim3 grid((unsigned)vtm::cdiv(M, QB), (unsigned)h, (unsigned)B);
     const float scale_log2e = scale * 1.4426950408889634f;
     hipLaunchKernelGGL((attention_kernel<T, D>), grid, dim3(WAVES * 64), lds, s, (const T *)q, ldq, (const T *)k,
-                       ldk, (const T *)vt, ldvt, (T *)out, ldo, B, h, M, Mp, scale_log2e, B / share_groups);
+                       ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, scale_log2e, B / share_groups);
     return vtm::launch_status("vtm_attention");
 }
 
