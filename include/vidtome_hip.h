@@ -88,6 +88,24 @@ int vtm_normalize_gather(const void *x0, int64_t P0, const void *x1, int64_t P1,
 int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd, int64_t Ns_pad,
               int64_t Nd_pad, int64_t C_pad, int align, uint64_t *best, vtm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * vtm_match_filtered -- the same packed result as vtm_normalize_gather x2 + vtm_match, BIT FOR BIT, several
+ * times faster: an fp16-MFMA filter pass (hi/lo split operands, 3 products) collects for every src row
+ * the dst rows whose approximate score lies within a rigorous error window of the row's running maximum,
+ * and an fp32 refine pass evaluates the canonical fmaf chain on those candidates only.  Rows with
+ * non-finite normalised components (zero tokens) or with more than 32 candidates raise a device flag that
+ * makes a gated launch of the plain fp32 kernel recompute the whole call (exact, no host round trip).
+ * Inputs are the token pool (x0 | x1, as vtm_normalize_gather) and the gathered pool ids a_rows (B, Ns),
+ * b_rows (B, Nd).  ws: >= vtm_match_filtered_ws_bytes(...) bytes.  flags_out (optional, 4 int32):
+ * [0] = 1 if the whole-call exact fallback ran (non-finite component, = [1]), [2] = number of rows
+ * recomputed exactly because their candidate list overflowed.  Derivation of the window: vidtome_amd/csrc/match_filter.hip.
+ * ---------------------------------------------------------------------------------------------- */
+size_t vtm_match_filtered_ws_bytes(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align);
+int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                       int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
+                       int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
+                       vtm_stream_t stream);
+
 /* node_max (fp32, -0 canonicalised to +0) and node_idx (int32) out of packed keys; either output may
  * be NULL. */
 int vtm_decode_best(const uint64_t *best, int64_t n, float *node_max, int32_t *node_idx,

@@ -100,6 +100,76 @@ def test_match_nan_semantics(L, oracle):
         assert np.array_equal(perm.reshape(rm.shape), oracle.sort_desc(rm))
 
 
+def _filtered_vs_exact(L, x, Ns, Nd, align, expect_flag=None):
+    """vtm_match_filtered (fp16 filter + fp32 refine) must equal vtm_match (plain fp32 MFMA) bit for bit."""
+    B = x.shape[0]
+    ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+    rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+    a_op, _ = L.normalize_gather(x, None, ra)
+    b_op, _ = L.normalize_gather(x, None, rb)
+    exact = L.match(a_op, b_op, Ns, Nd, align)
+    got, flag = L.match_filtered(x, None, ra, rb, align, want_flag=True)
+    assert torch.equal(got, exact)
+    if expect_flag is not None:
+        assert int(flag[0].item()) == expect_flag, flag.tolist()
+    return int(flag[0].item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("align", [False, True])
+def test_match_filtered_equals_exact(L, dtype, align):
+    g = torch.Generator().manual_seed(11)
+    for (B, Ns, Nd, C) in [(2, 37, 29, 24), (3, 300, 513, 40), (2, 1000, 700, 64), (2, 2048, 1500, 320), (1, 700, 3000, 640)]:
+        x = torch.randn(B, Ns + Nd, C, generator=g).to(dtype).to(DEV)
+        _filtered_vs_exact(L, x, Ns, Nd, align, expect_flag=0)
+
+
+def test_match_filtered_hard_cases(L):
+    g = torch.Generator().manual_seed(12)
+    B, Ns, Nd, C = 2, 600, 900, 320
+    # (1) frame-correlated tokens: many near-maximal scores per row
+    base = torch.randn(B, 1, C, generator=g)
+    x = (base + 0.05 * torch.randn(B, Ns + Nd, C, generator=g)).half().to(DEV)
+    _filtered_vs_exact(L, x, Ns, Nd, False)
+    _filtered_vs_exact(L, x, Ns, Nd, True)
+    # (2) exact duplicates among dst rows (anchors hold copies, patch.py:80): first index must win
+    x = torch.randn(B, Ns + Nd, C, generator=g).half()
+    x[:, Ns + 100:Ns + 120] = x[:, Ns + 7:Ns + 8]
+    x[:, 5] = x[:, Ns + 7]                     # a src row identical to the duplicated dst row -> score ~1, 21-way tie
+    _filtered_vs_exact(L, x.to(DEV), Ns, Nd, False, expect_flag=0)
+    # (3) near ties far below fp16 resolution: dst rows differing by one fp32 ulp-scale perturbation
+    xf = torch.randn(B, Ns + Nd, C, generator=g)
+    xf[:, Ns + 1] = xf[:, Ns] * (1 + 1e-7) + 1e-7 * torch.randn(B, C, generator=g)
+    xf[:, Ns + 2] = xf[:, Ns] + 3e-7 * torch.randn(B, C, generator=g)
+    xf[:, 0] = xf[:, Ns] + 1e-3 * torch.randn(B, C, generator=g)
+    _filtered_vs_exact(L, xf.to(DEV), Ns, Nd, False, expect_flag=0)
+    # (4) zero token -> NaN row -> device flag -> gated exact kernel
+    x = torch.randn(B, Ns + Nd, C, generator=g).half()
+    x[0, 3] = 0
+    x[1, Ns + 50] = 0
+    _filtered_vs_exact(L, x.to(DEV), Ns, Nd, False, expect_flag=1)
+    _filtered_vs_exact(L, x.to(DEV), Ns, Nd, True, expect_flag=1)
+    # (5) candidate overflow: every dst row identical -> more than 32 candidates per row -> those rows are
+    #     recomputed by the exact row pass (no whole-call fallback)
+    x = torch.randn(B, Ns + Nd, C, generator=g).half()
+    x[:, Ns:] = x[:, Ns:Ns + 1]
+    for align in (False, True):
+        ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+        rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+        _filtered_vs_exact(L, x.to(DEV), Ns, Nd, align, expect_flag=0)
+        _, flag = L.match_filtered(x.to(DEV), None, ra, rb, align, want_flag=True)
+        assert int(flag[2].item()) == (Ns if align else B * Ns)
+
+
+def test_match_filtered_full_size(L):
+    """cfg-2 top-block level-1 size on frame-correlated fp16 tokens: filtered == exact, no fallback."""
+    g = torch.Generator().manual_seed(13)
+    B, Ns, Nd, C = 2, 49152, 16384, 320
+    base = torch.randn(B, 4096, C, generator=g)
+    x = (base.repeat(1, 16, 1) + 0.5 * torch.randn(B, Ns + Nd, C, generator=g)).half().to(DEV)
+    _filtered_vs_exact(L, x, Ns, Nd, False, expect_flag=0)
+
+
 @pytest.mark.parametrize("n", [1, 17, 1000, 1024, 5000, 49152, 110592])
 def test_sort_desc(L, oracle, n):
     rng = np.random.default_rng(n)

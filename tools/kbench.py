@@ -56,6 +56,11 @@ def main():
         bop, _ = _lib.normalize_gather(x, None, rb)
         med, best = timeit(lambda: _lib.match(aop, bop, Ns, Nd, a.align), a.iters)
         fl = 2.0 * B * Ns * Nd * C
+        medf, bestf = timeit(lambda: _lib.match_filtered(x, None, ra, rb, a.align), a.iters)
+        _, fl_ = _lib.match_filtered(x, None, ra, rb, a.align, want_flag=True)
+        print("flags [whole-call exact, non-finite, overflow rows, -]:", fl_.tolist())
+        print(f"match_filtered {a.shape}: median {medf:.3f} ms ({2.0 * B * Ns * Nd * C / medf / 1e9:.1f} algorithmic "
+              f"TFLOP/s), best {bestf:.3f} ms")
         print(f"match {a.shape} B={B} Ns={Ns} Nd={Nd} C={C}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), "
               f"best {best:.3f} ms ({fl / best / 1e9:.1f} TFLOP/s)")
     elif a.what == "attn":

@@ -33,6 +33,9 @@ _SIGNATURES = {
     "vtm_pad_k": ([_i64], _i64),
     "vtm_normalize_gather": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp], _int),
     "vtm_match": ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp], _int),
+    "vtm_match_filtered_ws_bytes": ([_i64, _i64, _i64, _i64, _int], ctypes.c_size_t),
+    "vtm_match_filtered": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
+                            _vp, _vp, _vp], _int),
     "vtm_decode_best": ([_vp, _i64, _vp, _vp, _vp], _int),
     "vtm_sort_ws_bytes": ([_i64, _i64], ctypes.c_size_t),
     "vtm_sort_desc": ([_vp, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp], _int),
@@ -133,6 +136,23 @@ def match(a: torch.Tensor, b: torch.Tensor, Ns: int, Nd: int, align: bool) -> to
     _check(lib().vtm_match(_ptr(a), _ptr(b), B, Ns, Nd, Ns_pad, Nd_pad, C_pad, int(align), _ptr(best), _stream()),
            "vtm_match")
     return best
+
+
+def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.Tensor, b_rows: torch.Tensor,
+                   align: bool, want_flag: bool = False):
+    """Same packed result as normalize_gather x2 + match, through the fp16-filter / fp32-refine path."""
+    _req(x0, "x0"), _req(a_rows, "a_rows"), _req(b_rows, "b_rows")
+    B, P0, C = x0.shape
+    P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
+    Ns, Nd = a_rows.shape[1], b_rows.shape[1]
+    nbytes = lib().vtm_match_filtered_ws_bytes(B, C, Ns, Nd, int(align))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x0.device)
+    best = torch.empty((1 if align else B, Ns), dtype=torch.int64, device=x0.device)
+    flag = torch.zeros((4,), dtype=torch.int32, device=x0.device) if want_flag else None   # any, special, fifo, cap
+    _check(lib().vtm_match_filtered(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(a_rows), Ns, _ptr(b_rows),
+                                    Nd, int(align), _ptr(ws), nbytes, _ptr(best), _ptr(flag), _stream()),
+           "vtm_match_filtered")
+    return (best, flag) if want_flag else best
 
 
 def decode_best(best: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

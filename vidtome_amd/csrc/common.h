@@ -35,6 +35,16 @@ template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; 
 template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
 template <> __device__ __forceinline__ float to_f32<vtm_bf16>(vtm_bf16 v) { return __bfloat162float(v); }
 
+// internal cross-file launchers (not part of the C ABI)
+int launch_row_norms(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B, int64_t C,
+                     const int32_t *rows, int64_t n, float *norms, hipStream_t s);
+int launch_write_operand(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                         int64_t C, const int32_t *rows, int64_t n, const float *norms, float *out,
+                         int64_t n_pad, int64_t C_pad, const int *gate, hipStream_t s);
+int launch_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd, int64_t Ns_pad,
+                 int64_t Nd_pad, int64_t C_pad, int align, uint64_t *best, const int *gate, bool zero_best,
+                 hipStream_t s);
+
 }  // namespace vtm
 
 #define VTM_REQUIRE(cond, ...)                                   \

@@ -1,0 +1,532 @@
+// vtm_match_filtered: the SAME result as vtm_match (canonical fp32 row max / first argmax, bit for bit),
+// obtained ~4x faster: an fp16-MFMA *filter* pass finds, for every src row, the few dst rows that can
+// possibly be the fp32 argmax, and an exact fp32 *refine* pass evaluates the canonical fmaf chain only on
+// those candidates.  Reference: vidtome/merge.py:87-113 / 392-417 (scores + max), as vtm_match.
+//
+// Why it is exact.  Let s_ij be the canonical fp32 chain value and t_ij the filter's approximation with
+// |t_ij - s_ij| <= EPS for all i, j (bound below).  If j* attains max_j s_ij (including every tied j), then
+// t_ij* >= s_ij* - EPS >= s_ij - EPS >= t_ij - 2 EPS for every j, i.e. j* lies within W = 2 EPS of every
+// approximate score of the row -- in particular of any running maximum.  So "collect every j with
+// t_ij >= running_max - W" collects all true argmax columns; the refine pass computes their exact scores
+// and combines them with the same packed atomicMax as vtm_match (largest value, first index).
+//
+// Approximation.  xhat (fp32) is split as 1024*xhat = hi + lo (+ dropped 2^-22 tail), hi, lo fp16; the
+// filter accumulates hi_a*hi_b + hi_a*lo_b + lo_a*hi_b with v_mfma_f32_32x32x16_f16 (exact products, fp32
+// accumulation).  Error budget per score (unit vectors, sum |a_k b_k| <= 1): representation 3 * 2^-22 ~
+// 7e-7, fp32 accumulation of 3C <= 3840 terms <= 2.3e-4 worst case (observed ~1e-6), canonical chain
+// <= 7.7e-5 worst case at C = 1280.  EPS = 2.5e-4 (W = 5e-4) covers the worst case; tests measure the
+// observed error.  The 1024 scale keeps lo out of the fp16 subnormal range for every component that
+// matters (a flushed subnormal costs <= 1e-6, inside EPS).
+//
+// Escapes (all exact, no host round trip): a row whose candidate list overflows CAP (massively duplicated
+// dst rows) is recomputed exactly by exact_rows_kernel (all Nd chains of that row); any non-finite xhat
+// component (zero token -> 0/0, merge.py:84 has no eps) raises a device flag that turns a *gated* launch of
+// the ordinary fp32 kernel (match.hip) from a no-op into a full recomputation of the call.
+#include "common.h"
+
+namespace {
+
+constexpr int FBD = 128;      // dst rows per tile (MFMA A operand, LDS)
+constexpr int FBS = 256;      // src rows per workgroup (B operand, registers), 64 per wave
+constexpr int FBK = 64;       // channels per pipeline step = 4 MFMA k-steps = 8 panels
+constexpr int THREADS = 256;
+constexpr int CAP = 64;       // candidate slots per src row
+constexpr float SCALE = 1024.0f;
+constexpr float INV_S2 = 1.0f / (1024.0f * 1024.0f);
+constexpr float WINDOW = 5.0e-4f;   // 2 * EPS
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+using vtm::to_f32;
+
+template <typename T>
+__device__ __forceinline__ const T *pool_row(const T *x0, int64_t P0, const T *x1, int64_t P1, int64_t b,
+                                             int64_t r, int64_t C) {
+    return r < P0 ? x0 + (b * P0 + r) * C : x1 + (b * P1 + (r - P0)) * C;
+}
+
+template <typename T>
+__device__ __forceinline__ void load8(const T *src, float (&f)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(src);
+        const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+        f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
+        f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src);
+        const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = to_f32(e[j]);
+    }
+}
+
+__device__ __forceinline__ uint32_t orderable(float f) {
+    if (f != f) return 0xffffffffu;
+    const uint32_t u = __float_as_uint(f + 0.0f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_orderable(uint32_t o) {   // 0 (never written) -> -inf
+    if (o == 0u) return -INFINITY;
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// ---- operand writer: hi / lo fp16 panels [b][g = k/8][row][8], one thread per (g, row), rows fastest ----
+template <typename T>
+__global__ __launch_bounds__(256) void split_operand(const T *__restrict__ x0, int64_t P0,
+                                                     const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
+                                                     const int32_t *__restrict__ rows, int64_t n,
+                                                     const float *__restrict__ norms, uint4 *__restrict__ out_hi,
+                                                     uint4 *__restrict__ out_lo, int64_t n_pad, int64_t C_pad,
+                                                     int *__restrict__ flags) {
+    const int64_t G = C_pad / 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n_pad * G) return;
+    const int64_t i = idx % n_pad;
+    const int64_t bg = idx / n_pad;
+    const int64_t g = bg % G, b = bg / G;
+    uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
+    if (i < n && g * 8 < C) {
+        const T *src = pool_row(x0, P0, x1, P1, b, rows[b * n + i], C) + g * 8;
+        const float nrm = norms[b * n + i];
+        float f[8];
+        load8(src, f);
+        _Float16 *ph = reinterpret_cast<_Float16 *>(&vh), *pl = reinterpret_cast<_Float16 *>(&vl);
+        bool special = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = f[j] / nrm;                 // the canonical xhat (IEEE divide)
+            special |= !(__builtin_fabsf(xh) <= 3.0e38f);   // NaN or inf
+            const float sc = xh * SCALE;
+            const _Float16 h = (_Float16)sc;
+            ph[j] = h;
+            pl[j] = (_Float16)(sc - (float)h);            // exact difference, rounded once
+        }
+        if (special) { flags[0] = 1; flags[1] = 1; }
+    }
+    out_hi[bg * n_pad + i] = vh;
+    out_lo[bg * n_pad + i] = vl;
+}
+
+// ---- filter: approximate scores on the fp16 MFMA, candidate collection ----
+__global__ __launch_bounds__(THREADS, 2) void filter_kernel(
+    const uint4 *__restrict__ ah, const uint4 *__restrict__ al, const uint4 *__restrict__ bh,
+    const uint4 *__restrict__ bl, int64_t Ns, int64_t Nd, int64_t Ns_pad, int64_t Nd_pad, int64_t C_pad, int align,
+    int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split, unsigned int *__restrict__ amax,
+    int *__restrict__ cnt, uint2 *__restrict__ cand, int *__restrict__ flags) {
+    // dst tile of one step: 8 panels x 128 rows x 16 B, hi and lo, double-buffered: 2 x 2 x 16 KiB
+    __shared__ __attribute__((aligned(16))) uint4 sA[2][2][8 * FBD];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    int id = blockIdx.x;
+    const int split = id % nsplit;
+    id /= nsplit;
+    const int st_ = id % ns_tiles;
+    const int bi = id / ns_tiles;
+    const int jt0 = split * tiles_per_split;
+    const int jt1 = min(jt0 + tiles_per_split, nd_tiles);
+    if (jt0 >= jt1) return;
+
+    const int KT = (int)(C_pad / FBK);
+    const int64_t G = C_pad / 8;
+    const int steps = (jt1 - jt0) * KT;
+    const uint4 *srch = ah + (int64_t)bi * G * Ns_pad, *srcl = al + (int64_t)bi * G * Ns_pad;
+    const uint4 *dsth = bh + (int64_t)bi * G * Nd_pad, *dstl = bl + (int64_t)bi * G * Nd_pad;
+    const int64_t srow0 = (int64_t)st_ * FBS + wave * 64;
+
+    // B fragments of one MFMA k-step: [src block sb][hi|lo], double-buffered at k-step granularity
+    uint4 rb[2][2][2];
+    auto load_b = [&](int gi, uint4 (&dst)[2][2]) {
+        const int kt = (gi >> 2) % KT, s = gi & 3;
+        const int64_t off = ((int64_t)(kt * 8 + s * 2 + kh)) * Ns_pad + srow0 + l31;
+        dst[0][0] = srch[off];
+        dst[1][0] = srch[off + 32];
+        dst[0][1] = srcl[off];
+        dst[1][1] = srcl[off + 32];
+    };
+    // A tile of one step: 2 x 16 LDS-DMA wave-instructions of 1 KiB; wave w issues 8 of them
+    auto load_a = [&](int st, int buf) {
+        const int jt = jt0 + st / KT, kt = st % KT;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int q = wave * 8 + t, which = q >> 4, qq = q & 15, p = qq >> 1, half = qq & 1;
+            const uint4 *gp = (which ? dstl : dsth) + ((int64_t)kt * 8 + p) * Nd_pad + (int64_t)jt * FBD + half * 64 + lane;
+            uint4 *lp = &sA[buf][which][p * FBD + half * 64];
+            __builtin_amdgcn_global_load_lds((glb_void *)gp, (lds_void *)lp, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ib][sb][r] = 0.0f;
+
+    const int64_t out_row0 = align ? 0 : (int64_t)bi * Ns;
+    const uint32_t idx_base = align ? (uint32_t)((int64_t)bi * Nd) : 0u;
+    // per lane and src block: running max (in units of S^2) and the last 4 scores that came within the
+    // window of it (a FIFO in registers; an evicted entry that is still inside the window = overflow)
+    constexpr float WS = WINDOW * SCALE * SCALE;
+    float runmax[2], cv[2][4];
+    uint32_t ci[2][4];
+    auto push = [&](int64_t srow, float v_scaled, uint32_t d) {   // append to the row's global candidate list
+        const int slot = atomicAdd(&cnt[out_row0 + srow], 1);     // cnt > CAP marks the row for the exact row pass
+        if (slot < CAP)
+            cand[(out_row0 + srow) * CAP + slot] = make_uint2(__float_as_uint(v_scaled * INV_S2), d + idx_base);
+    };
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+        const int64_t srow = srow0 + sb * 32 + l31;
+        // start from what other workgroups already found for this row: fewer early candidates
+        runmax[sb] = srow < Ns ? from_orderable(amax[out_row0 + srow]) * (SCALE * SCALE)
+                               : INFINITY;   // padding rows (all-zero operands) never collect anything
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cv[sb][e] = -INFINITY;
+            ci[sb][e] = 0;
+        }
+    }
+
+    load_a(0, 0);
+    load_b(0, rb[0]);
+    __syncthreads();
+
+    for (int st = 0; st < steps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < steps) load_a(st + 1, buf ^ 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int gi = st * 4 + s;
+            if (gi + 1 < steps * 4) load_b(gi + 1, rb[(s + 1) & 1]);
+            h16x8 fh[4], fl[4];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const uint4 vh = sA[buf][0][(s * 2 + kh) * FBD + ib * 32 + l31];
+                const uint4 vl = sA[buf][1][(s * 2 + kh) * FBD + ib * 32 + l31];
+                fh[ib] = __builtin_bit_cast(h16x8, vh);
+                fl[ib] = __builtin_bit_cast(h16x8, vl);
+            }
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s & 1][sb][0]);
+                const h16x8 blf = __builtin_bit_cast(h16x8, rb[s & 1][sb][1]);
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], bhf, acc[ib][sb], 0, 0, 0);
+                    acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], blf, acc[ib][sb], 0, 0, 0);
+                    acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ib], bhf, acc[ib][sb], 0, 0, 0);
+                }
+            }
+        }
+        if ((st + 1) % KT == 0) {
+            // dst tile finished: every score within the window of the lane's running max becomes a candidate
+            const int jt = jt0 + st / KT;
+            const int dst0 = jt * FBD + 4 * kh;
+            const bool full = (int64_t)(jt + 1) * FBD <= Nd;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                float rm = runmax[sb];
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    if (!full) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (dst0 + ib * 32 + (r & 3) + 8 * (r >> 2) >= Nd) acc[ib][sb][r] = -INFINITY;
+                    }
+                    // cheap common path: the block's maximum decides whether anything can qualify
+                    float gm = fmaxf(acc[ib][sb][0], acc[ib][sb][1]);
+#pragma unroll
+                    for (int r = 2; r < 16; r += 2) gm = fmaxf(fmaxf(gm, acc[ib][sb][r]), acc[ib][sb][r + 1]);
+                    if (__any(gm >= rm - WS && gm > -INFINITY)) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = acc[ib][sb][r];
+                            if (v >= rm - WS && v > -INFINITY) {   // NaN / masked rows never pass
+                                const float nrm_ = fmaxf(rm, v);
+                                if (cv[sb][3] >= nrm_ - WS)   // evicted entry still inside the window: spill it
+                                    push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3]);
+                                cv[sb][3] = cv[sb][2]; ci[sb][3] = ci[sb][2];
+                                cv[sb][2] = cv[sb][1]; ci[sb][2] = ci[sb][1];
+                                cv[sb][1] = cv[sb][0]; ci[sb][1] = ci[sb][0];
+                                cv[sb][0] = v;
+                                ci[sb][0] = (uint32_t)(dst0 + ib * 32 + (r & 3) + 8 * (r >> 2));
+                                rm = nrm_;
+                            }
+                        }
+                    }
+                    rm = fmaxf(rm, gm);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ib][sb][r] = 0.0f;
+                }
+                runmax[sb] = rm;
+            }
+        }
+        __syncthreads();
+    }
+
+    // flush: the entries still inside the window of this lane's final maximum
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+        const int64_t srow = srow0 + sb * 32 + l31;
+        if (srow >= Ns) continue;
+        float rm = runmax[sb];
+        if (rm > -INFINITY) {
+            // publish this partition's maximum first and prune against what the other partitions of the row
+            // have published so far: only entries within the window of the best known maximum can matter
+            const uint32_t mine = orderable(rm * INV_S2);
+            const uint32_t prev = atomicMax(&amax[out_row0 + srow], mine);
+            rm = fmaxf(rm, from_orderable(prev) * (SCALE * SCALE));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (cv[sb][e] >= rm - WS && cv[sb][e] > -INFINITY) push(srow, cv[sb][e], ci[sb][e]);
+    }
+}
+
+// ---- refine: exact canonical chain on the surviving candidates ----
+template <typename T>
+__global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1,
+                                                     int64_t P1, int64_t B, int64_t C,
+                                                     const int32_t *__restrict__ a_rows, int64_t Ns,
+                                                     const int32_t *__restrict__ b_rows, int64_t Nd,
+                                                     const float *__restrict__ na, const float *__restrict__ nb,
+                                                     int align, const unsigned int *__restrict__ amax,
+                                                     const int *__restrict__ cnt, const uint2 *__restrict__ cand,
+                                                     unsigned long long *__restrict__ best, int *__restrict__ flags,
+                                                     int *__restrict__ ovf_rows) {
+    const int64_t rows_out = align ? Ns : B * Ns;
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows_out) return;
+    if (cnt[row] > CAP) {   // candidate list overflowed: the row is recomputed exactly by exact_rows_kernel
+        ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
+        return;
+    }
+    const int n = cnt[row];
+    const float thr = from_orderable(amax[row]) - WINDOW;
+    const int64_t i = align ? row : row % Ns;
+    unsigned long long bestkey = 0;
+    for (int c = 0; c < n; ++c) {
+        const uint2 cd = cand[row * CAP + c];
+        if (!(__uint_as_float(cd.x) >= thr)) continue;   // outside the window of the row's global approx max
+        const int64_t bi = align ? (int64_t)(cd.y / (uint32_t)Nd) : row / Ns;
+        const int64_t j = align ? (int64_t)(cd.y % (uint32_t)Nd) : (int64_t)cd.y;
+        const T *pa = pool_row(x0, P0, x1, P1, bi, a_rows[bi * Ns + i], C);
+        const T *pb = pool_row(x0, P0, x1, P1, bi, b_rows[bi * Nd + j], C);
+        const float nrm_a = na[bi * Ns + i], nrm_b = nb[bi * Nd + j];
+        float acc = 0.0f;
+        for (int64_t k = 0; k < C; k += 8) {
+            float fa[8], fb[8];
+            load8(pa + k, fa);
+            load8(pb + k, fb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(fa[e] / nrm_a, fb[e] / nrm_b, acc);
+        }
+        const unsigned long long key = ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~cd.y);
+        bestkey = key > bestkey ? key : bestkey;
+    }
+    if (bestkey) atomicMax(&best[row], bestkey);
+}
+
+// ---- exact pass for the (rare) rows whose candidate list overflowed: all Nd canonical chains of the row ----
+template <typename T>
+__global__ __launch_bounds__(256) void exact_rows_kernel(const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1,
+                                                         int64_t P1, int64_t B, int64_t C,
+                                                         const int32_t *__restrict__ a_rows, int64_t Ns,
+                                                         const int32_t *__restrict__ b_rows, int64_t Nd,
+                                                         const float *__restrict__ na, const float *__restrict__ nb,
+                                                         int align, const int *__restrict__ flags,
+                                                         const int *__restrict__ ovf_rows,
+                                                         unsigned long long *__restrict__ best) {
+    extern __shared__ float sa[];   // the normalised src row (C floats)
+    const int nrows = flags[2];
+    for (int it = blockIdx.x; it < nrows; it += gridDim.x) {
+        const int64_t row = ovf_rows[it];
+        const int64_t i = align ? row : row % Ns;
+        unsigned long long bestkey = 0;
+        const int64_t b0 = align ? 0 : row / Ns, b1 = align ? B : b0 + 1;
+        for (int64_t bi = b0; bi < b1; ++bi) {
+            __syncthreads();
+            const T *pa = pool_row(x0, P0, x1, P1, bi, a_rows[bi * Ns + i], C);
+            const float nrm_a = na[bi * Ns + i];
+            for (int64_t k = threadIdx.x; k < C; k += blockDim.x) sa[k] = to_f32(pa[k]) / nrm_a;
+            __syncthreads();
+            for (int64_t j = threadIdx.x; j < Nd; j += blockDim.x) {
+                const T *pb = pool_row(x0, P0, x1, P1, bi, b_rows[bi * Nd + j], C);
+                const float nrm_b = nb[bi * Nd + j];
+                float acc = 0.0f;
+                for (int64_t k = 0; k < C; k += 8) {
+                    float fb[8];
+                    load8(pb + k, fb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(sa[k + e], fb[e] / nrm_b, acc);
+                }
+                const uint32_t col = (uint32_t)((align ? bi * Nd : 0) + j);
+                const unsigned long long key = ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col);
+                bestkey = key > bestkey ? key : bestkey;
+            }
+        }
+        if (bestkey) atomicMax(&best[row], bestkey);
+    }
+}
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Layout {
+    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf, aop, bop, total;
+    int64_t Ns_pad, Nd_pad, C64, C32;
+};
+
+Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
+    Layout L;
+    L.Ns_pad = vtm::cdiv(Ns, FBS) * FBS;
+    L.Nd_pad = vtm::cdiv(Nd, FBS) * FBS;
+    L.C64 = vtm::cdiv(C, 64) * 64;
+    L.C32 = vtm::cdiv(C, 32) * 32;
+    const int64_t rows_out = align ? Ns : B * Ns;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes); return at; };
+    L.na = take((size_t)B * Ns * 4);
+    L.nb = take((size_t)B * Nd * 4);
+    L.ah = take((size_t)B * L.C64 * L.Ns_pad * 2);
+    L.al = take((size_t)B * L.C64 * L.Ns_pad * 2);
+    L.bh = take((size_t)B * L.C64 * L.Nd_pad * 2);
+    L.bl = take((size_t)B * L.C64 * L.Nd_pad * 2);
+    L.amax = take((size_t)rows_out * 4);      // amax, cnt and flags are contiguous: one memset
+    L.cnt = take((size_t)rows_out * 4);
+    L.flags = take(256);
+    L.cand = take((size_t)rows_out * CAP * 8);
+    L.ovf = take((size_t)rows_out * 4);
+    L.aop = take((size_t)B * L.C32 * L.Ns_pad * 4);
+    L.bop = take((size_t)B * L.C32 * L.Nd_pad * 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+VTM_EXPORT size_t vtm_match_filtered_ws_bytes(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
+    if (B <= 0 || C <= 0 || Ns <= 0 || Nd <= 0) return 0;
+    return make_layout(B, C, Ns, Nd, align).total;
+}
+
+VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                                  int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
+                                  int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
+                                  vtm_stream_t stream) {
+    VTM_REQUIRE(x0 && a_rows && b_rows && ws && best, "vtm_match_filtered: null pointer");
+    VTM_REQUIRE(B > 0 && C > 0 && C % 8 == 0 && Ns > 0 && Nd > 0, "vtm_match_filtered: bad sizes");
+    VTM_REQUIRE(P1 == 0 || x1, "vtm_match_filtered: x1 is null but P1 > 0");
+    VTM_REQUIRE(B * Nd < (1ll << 32) - 1, "vtm_match_filtered: index space overflow");
+    const Layout L = make_layout(B, C, Ns, Nd, align);
+    if (ws_bytes < L.total)
+        return vtm::fail(VTM_EWORKSPACE, "vtm_match_filtered: workspace %zu < %zu bytes", ws_bytes, L.total);
+    hipStream_t s = vtm::as_stream(stream);
+    char *w = static_cast<char *>(ws);
+    float *na = (float *)(w + L.na), *nb = (float *)(w + L.nb);
+    uint4 *ah = (uint4 *)(w + L.ah), *al = (uint4 *)(w + L.al), *bh = (uint4 *)(w + L.bh), *bl = (uint4 *)(w + L.bl);
+    unsigned int *amax = (unsigned int *)(w + L.amax);
+    int *cnt = (int *)(w + L.cnt), *flags = (int *)(w + L.flags);
+    uint2 *cand = (uint2 *)(w + L.cand);
+    int *ovf_rows = (int *)(w + L.ovf);
+    float *aop = (float *)(w + L.aop), *bop = (float *)(w + L.bop);
+    const int64_t rows_out = align ? Ns : B * Ns;
+
+    hipError_t e = hipMemsetAsync(w + L.amax, 0, (L.cand - L.amax), s);   // amax, cnt, flags
+    if (e == hipSuccess) e = hipMemsetAsync(best, 0, (size_t)rows_out * 8, s);
+    if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: memset: %s", hipGetErrorString(e));
+
+    if (int rc = vtm::launch_row_norms(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, s)) return rc;
+    if (int rc = vtm::launch_row_norms(x0, P0, x1, P1, dtype, B, C, b_rows, Nd, nb, s)) return rc;
+
+    auto split = [&](const int32_t *rows, int64_t n, const float *norms, uint4 *oh, uint4 *ol, int64_t n_pad) {
+        const int64_t total = B * n_pad * (L.C64 / 8);
+        const dim3 grid((unsigned)vtm::cdiv(total, 256)), block(256);
+        switch (dtype) {
+            case VTM_F32:
+                hipLaunchKernelGGL(split_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
+                                   B, C, rows, n, norms, oh, ol, n_pad, L.C64, flags);
+                break;
+            case VTM_F16:
+                hipLaunchKernelGGL(split_operand<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
+                                   P1, B, C, rows, n, norms, oh, ol, n_pad, L.C64, flags);
+                break;
+            default:
+                hipLaunchKernelGGL(split_operand<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
+                                   (const vtm_bf16 *)x1, P1, B, C, rows, n, norms, oh, ol, n_pad, L.C64, flags);
+        }
+    };
+    VTM_REQUIRE(dtype == VTM_F32 || dtype == VTM_F16 || dtype == VTM_BF16, "vtm_match_filtered: bad dtype");
+    split(a_rows, Ns, na, ah, al, L.Ns_pad);
+    split(b_rows, Nd, nb, bh, bl, L.Nd_pad);
+
+    {
+        const int ns_tiles = (int)(L.Ns_pad / FBS), nd_tiles = (int)(L.Nd_pad / FBD);
+        int64_t want = vtm::cdiv(1536, (int64_t)ns_tiles * B);
+        int nsplit = (int)(want < 1 ? 1 : want);
+        if (nsplit > nd_tiles / 4) nsplit = nd_tiles / 4 > 0 ? nd_tiles / 4 : 1;
+        if (nsplit > 8) nsplit = 8;   // every partition contributes >= 1 candidate per row: keep the lists short
+        const int tiles_per_split = (int)vtm::cdiv(nd_tiles, nsplit);
+        nsplit = (int)vtm::cdiv(nd_tiles, tiles_per_split);
+        const int64_t grid = (int64_t)B * ns_tiles * nsplit;
+        hipLaunchKernelGGL(filter_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
+                           L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, amax, cnt, cand, flags);
+    }
+    {
+        const dim3 grid((unsigned)vtm::cdiv(rows_out, 256)), block(256);
+        unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
+        switch (dtype) {
+            case VTM_F32:
+                hipLaunchKernelGGL(refine_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
+                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, amax, cnt, cand, bp, flags, ovf_rows);
+                break;
+            case VTM_F16:
+                hipLaunchKernelGGL(refine_kernel<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
+                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, amax, cnt, cand, bp, flags, ovf_rows);
+                break;
+            default:
+                hipLaunchKernelGGL(refine_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
+                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, amax, cnt, cand,
+                                   bp, flags, ovf_rows);
+        }
+    }
+    {   // persistent-style grid over the overflow list (usually empty: the blocks exit at once)
+        const dim3 grid(512), block(256);
+        unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
+        const size_t lds = (size_t)C * sizeof(float);
+        switch (dtype) {
+            case VTM_F32:
+                hipLaunchKernelGGL(exact_rows_kernel<float>, grid, block, lds, s, (const float *)x0, P0, (const float *)x1,
+                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_rows, bp);
+                break;
+            case VTM_F16:
+                hipLaunchKernelGGL(exact_rows_kernel<__half>, grid, block, lds, s, (const __half *)x0, P0,
+                                   (const __half *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_rows, bp);
+                break;
+            default:
+                hipLaunchKernelGGL(exact_rows_kernel<vtm_bf16>, grid, block, lds, s, (const vtm_bf16 *)x0, P0,
+                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_rows,
+                                   bp);
+        }
+    }
+    if (int rc = vtm::launch_status("vtm_match_filtered")) return rc;
+
+    // gated exact fallback (no-ops unless flags[0] != 0)
+    if (int rc = vtm::launch_write_operand(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, aop, L.Ns_pad, L.C32, flags, s))
+        return rc;
+    if (int rc = vtm::launch_write_operand(x0, P0, x1, P1, dtype, B, C, b_rows, Nd, nb, bop, L.Nd_pad, L.C32, flags, s))
+        return rc;
+    if (int rc = vtm::launch_match(aop, bop, B, Ns, Nd, L.Ns_pad, L.Nd_pad, L.C32, align, best, flags, false, s))
+        return rc;
+    if (flags_out) {
+        e = hipMemcpyAsync(flags_out, flags, 4 * sizeof(int), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: copy: %s", hipGetErrorString(e));
+    }
+    return VTM_OK;
+}

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void write_operand(const T *__restrict__ x0, i
                                                      int64_t C, const int32_t *__restrict__ rows,
                                                      int64_t n, const float *__restrict__ norms,
                                                      float *__restrict__ out, int64_t n_pad,
-                                                     int64_t C_pad) {
+                                                     int64_t C_pad, const int *__restrict__ gate) {
+    if (gate && *gate == 0) return;   // exact-fallback operands are only materialised when flagged
     // one thread per (8-channel group g, row i), rows fastest -> the two 16-byte panel stores of a wave are
     // contiguous 1 KiB segments.  Panel layout: out[b][g][kh][i][e] = xhat[b, i, 8g + 2e + kh].
     const int64_t G = C_pad / 8;
@@ -101,12 +102,60 @@ int run(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, int64
     if (total > 0) {
         hipLaunchKernelGGL(write_operand<T>, dim3((unsigned)vtm::cdiv(total, 256)), dim3(256), 0, s,
                            (const T *)x0, P0, (const T *)x1, P1, B, C, rows, n, norms, out, n_pad,
-                           C_pad);
+                           C_pad, (const int *)nullptr);
     }
     return vtm::launch_status("vtm_normalize_gather");
 }
 
 }  // namespace
+
+namespace vtm {
+// shared with match_filter.hip: the canonical row norms of gathered pool rows (same kernel, same bits)
+int launch_row_norms(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B, int64_t C,
+                     const int32_t *rows, int64_t n, float *norms, hipStream_t s) {
+    if (B * n <= 0) return VTM_OK;
+    const dim3 grid((unsigned)cdiv(B * n, 256)), block(256);
+    switch (dtype) {
+        case VTM_F32:
+            hipLaunchKernelGGL(row_norms<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1, B,
+                               C, rows, n, norms);
+            break;
+        case VTM_F16:
+            hipLaunchKernelGGL(row_norms<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1, P1,
+                               B, C, rows, n, norms);
+            break;
+        case VTM_BF16:
+            hipLaunchKernelGGL(row_norms<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0, (const vtm_bf16 *)x1,
+                               P1, B, C, rows, n, norms);
+            break;
+        default: return fail(VTM_EINVAL, "unsupported dtype %d", dtype);
+    }
+    return launch_status("row_norms");
+}
+int launch_write_operand(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                         int64_t C, const int32_t *rows, int64_t n, const float *norms, float *out,
+                         int64_t n_pad, int64_t C_pad, const int *gate, hipStream_t s) {
+    const int64_t total = B * n_pad * (C_pad / 8);
+    if (total <= 0) return VTM_OK;
+    const dim3 grid((unsigned)cdiv(total, 256)), block(256);
+    switch (dtype) {
+        case VTM_F32:
+            hipLaunchKernelGGL(write_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
+                               B, C, rows, n, norms, out, n_pad, C_pad, gate);
+            break;
+        case VTM_F16:
+            hipLaunchKernelGGL(write_operand<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
+                               P1, B, C, rows, n, norms, out, n_pad, C_pad, gate);
+            break;
+        case VTM_BF16:
+            hipLaunchKernelGGL(write_operand<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
+                               (const vtm_bf16 *)x1, P1, B, C, rows, n, norms, out, n_pad, C_pad, gate);
+            break;
+        default: return fail(VTM_EINVAL, "unsupported dtype %d", dtype);
+    }
+    return launch_status("write_operand");
+}
+}  // namespace vtm
 
 VTM_EXPORT int vtm_normalize_gather(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype,
                                     int64_t B, int64_t C, const int32_t *rows, int64_t n, float *norms,

@@ -25,6 +25,12 @@ import torch
 from . import _lib
 
 
+import os
+
+# "filtered" (default) or "exact": both produce bit-identical packed results (tests/test_gpu_parity.py)
+MATCH_MODE = os.environ.get("VIDTOME_MATCH", "filtered")
+
+
 def do_nothing(x: torch.Tensor, mode: str = None, **kwargs):
     """vidtome/merge.py:5-6."""
     return x
@@ -56,10 +62,13 @@ def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float
     """normalise+split -> fused score/top-1 -> argsort -> index split  (merge.py:84-117 / 389-421)."""
     a_pos, b_pos, a_rows, b_rows = parts
     Ns, Nd = a_rows.shape[1], b_rows.shape[1]
-    a_op, _ = _lib.normalize_gather(x0, x1, a_rows)
-    b_op, _ = _lib.normalize_gather(x0, x1, b_rows)
     r = min(Ns, int(Ns * ratio))                       # merge.py:90 (Python float -> int truncation)
-    best = _lib.match(a_op, b_op, Ns, Nd, align_batch)
+    if MATCH_MODE == "exact":                          # plain fp32-MFMA kernel
+        a_op, _ = _lib.normalize_gather(x0, x1, a_rows)
+        b_op, _ = _lib.normalize_gather(x0, x1, b_rows)
+        best = _lib.match(a_op, b_op, Ns, Nd, align_batch)
+    else:                                              # fp16 filter + fp32 refine: same bits, ~4x faster
+        best = _lib.match_filtered(x0, x1, a_rows, b_rows, align_batch)
     perm = _lib.sort_desc(best)
     new_cur, inv, unm_idx, src_idx, dst_idx = _lib.plan_apply(best, perm, a_pos, b_pos, a_rows, b_rows, r,
                                                               align_batch, want_indices)
