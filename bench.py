@@ -14,8 +14,9 @@ the timed region.  N > 1: one process per GPU, each rank runs its own chunk (wea
 collective in this mode); value = chunks-steps per second over all ranks.
 
 The JSON line also carries
-  roofline:     the dominant kernel (match_kernel: fused cosine score + row top-1 on the fp32 MFMA), its
-                algorithmic FLOPs / HIP-event time over the timed region vs the 157.3 TFLOP/s fp32 peak;
+  roofline:     the dominant kernel (attention_kernel: flash attention over the merged tokens, fp16 MFMA), its
+                algorithmic FLOPs / HIP-event time over the timed region vs the 2.5 PFLOP/s dense fp16 peak;
+  matching:     the fused cosine score + row top-1 step (fp32-exact), algorithmic FLOPs / HIP-event time;
   cpu_baseline: the CPU oracle (a port of the reference's algorithm) timed on this host's cores on a
                 bounded sample of the same workload and extrapolated to a whole step.
 """
@@ -32,6 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3          # MI355X fp32 vector / fp32-MFMA peak (MI355X_MICROARCH.md)
+FP16_PEAK_TFLOPS = 2500.0         # dense fp16/bf16 MFMA peak (not the 2:1-sparse marketing figure)
 BATCH, FRAMES, LATENT = 2, 16, (64, 64)
 LOCAL_RATIO, GLOBAL_RATIO = 0.5, 0.5
 
@@ -47,36 +49,50 @@ def parse():
     return ap.parse_args()
 
 
-class MatchTimer:
-    """HIP events around every vtm_match launch on the launch stream (torch's current stream)."""
+class KernelTimer:
+    """HIP events around the hot kernels' launches, recorded on the launch stream (torch's current stream):
+    `attention` = vtm_attention (one kernel), `matching` = vtm_match_filtered / vtm_match (the fused
+    score + top-1 step; the filtered variant is filter + refine kernels)."""
 
     def __init__(self, lib_mod):
         self.lib_mod = lib_mod
-        self.orig = lib_mod.match
-        self.records = []
+        self.orig = {}
+        self.records = {"attention": [], "matching": []}
         self.enabled = False
 
-    def __enter__(self):
-        def timed(a, b, Ns, Nd, align):
+    def _wrap(self, name, kind, flops_of):
+        orig = getattr(self.lib_mod, name)
+        self.orig[name] = orig
+
+        def timed(*a, **k):
             if not self.enabled:
-                return self.orig(a, b, Ns, Nd, align)
+                return orig(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = self.orig(a, b, Ns, Nd, align)
+            out = orig(*a, **k)
             e1.record()
-            B, C_pad = a.shape[0], a.shape[1] * 8
-            self.records.append((2.0 * B * Ns * Nd * C_pad, e0, e1))
+            self.records[kind].append((flops_of(*a, **k), e0, e1))
             return out
-        self.lib_mod.match = timed
+        setattr(self.lib_mod, name, timed)
+
+    def __enter__(self):
+        # attention(q, k, vt, heads, M, scale, share): 4 * B * M^2 * C flops (QK^T + PV, all heads)
+        self._wrap("attention", "attention", lambda q, k, vt, heads, M, scale, share=1: 4.0 * q.shape[0] * M * M * q.shape[2])
+        # match_filtered(x0, x1, a_rows, b_rows, align): 2 * B * Ns * Nd * C algorithmic flops
+        self._wrap("match_filtered", "matching",
+                   lambda x0, x1, ar, br, align, want_flag=False: 2.0 * x0.shape[0] * ar.shape[1] * br.shape[1] * x0.shape[2])
+        self._wrap("match", "matching", lambda a, b, Ns, Nd, align: 2.0 * a.shape[0] * Ns * Nd * a.shape[1] * 8)
         return self
 
     def __exit__(self, *exc):
-        self.lib_mod.match = self.orig
+        for name, fn in self.orig.items():
+            setattr(self.lib_mod, name, fn)
 
-    def summary(self):
-        flops = sum(r[0] for r in self.records)
-        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        return flops, ms, len(self.records)
+    def summary(self, kind):
+        rec = self.records[kind]
+        flops = sum(r[0] for r in rec)
+        ms = sum(r[1].elapsed_time(r[2]) for r in rec)
+        return flops, ms, len(rec)
 
 
 def cpu_baseline(target_seconds: float):
@@ -191,7 +207,7 @@ def main():
     step()                            # preceding chunk: populates the anchor tokens (steady state)
     for _ in range(args.warmup):
         step()
-    with MatchTimer(_lib) as mt:
+    with KernelTimer(_lib) as mt:
         mt.enabled = True
         fence()
         t0 = time.perf_counter()
@@ -203,29 +219,43 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    flops, mms, nlaunch = mt.summary()
+    aflops, ams, an = mt.summary("attention")
+    mflops, mms, mn = mt.summary("matching")
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * args.steps / dt
-        achieved = flops / (mms * 1e-3) / 1e12 if mms > 0 else 0.0
+        att_tf = aflops / (ams * 1e-3) / 1e12 if ams > 0 else 0.0
+        mat_tf = mflops / (mms * 1e-3) / 1e12 if mms > 0 else 0.0
+        from vidtome_amd import merge as _merge
         line = {
             "metric": "denoising steps/sec, 16-frame 512x512 SD-1.5 chunk, ratio=0.5",
             "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16 tokens / f32 matching / f16 MFMA attention",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16 tokens / f32-exact matching / f16 MFMA attention",
             "data": "synthetic",
             "config": {"workload": "SD-1.5 16 frames 512x512 (cfg-2): hot-path pass over the 16 transformer-block "
                                    "sites, batch 2 (CFG), local merge 0.5" +
                                    ("" if args.local_only else " + global merge 0.5 (steady state)"),
                        "sites": 16, "merged_sites": 10, "chunk_frames": FRAMES, "batch": BATCH,
+                       "matcher": _merge.MATCH_MODE,
                        "parallelism": f"chunk-parallel x{world}" + (", RCCL all-gather of the anchor tokens per merging "
                                                                      "block" if world > 1 else "")},
-            "roofline": {"kernel": "match_kernel (fused cosine score + row top-1, v_mfma_f32_32x32x2_f32)",
-                         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                         "launches": nlaunch, "avg_launch_ms": round(mms / max(nlaunch, 1), 4),
-                         "match_ms_per_step": round(mms / args.steps, 3)},
+            # dominant single kernel of the step: the merged-token self-attention (MFMA-bound)
+            "roofline": {"kernel": "attention_kernel<half,d> (flash attention over merged tokens, "
+                                   "v_mfma_f32_32x32x16_f16)",
+                         "bound": "mfma", "achieved": round(att_tf, 1), "peak": FP16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(att_tf / FP16_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches": an, "avg_launch_ms": round(ams / max(an, 1), 4),
+                         "attention_ms_per_step": round(ams / args.steps, 3)},
+            # the fused similarity + top-1 step (second largest): algorithmic fp32 FLOPs of the reference's
+            # `a @ b.T` + max over HIP-event time; the filtered matcher produces the fp32-exact result with
+            # fp16-MFMA filtering, so its algorithmic rate may exceed the fp32 peak it is quoted against
+            "matching": {"kernels": "filter_kernel + refine_kernel (vtm_match_filtered)" if _merge.MATCH_MODE != "exact"
+                                    else "match_kernel (vtm_match)",
+                         "algorithmic_tflops": round(mat_tf, 1), "fp32_peak": FP32_PEAK_TFLOPS,
+                         "frac_of_fp32_peak": round(mat_tf / FP32_PEAK_TFLOPS, 3), "calls": mn,
+                         "matching_ms_per_step": round(mms / args.steps, 3)},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

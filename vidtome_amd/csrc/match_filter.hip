@@ -311,12 +311,36 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
     const int n = cnt[row];
     const float thr = from_orderable(amax[row]) - WINDOW;
     const int64_t i = align ? row : row % Ns;
-    unsigned long long bestkey = 0;
+    // pass 1 (cheap, divergent): compact the candidates inside the window of the row's global approx max.
+    // More than MAXS survivors: hand the row to the exact row pass instead.
+    constexpr int MAXS = 6;
+    uint32_t sel[MAXS];
+    int ns = 0;
     for (int c = 0; c < n; ++c) {
         const uint2 cd = cand[row * CAP + c];
-        if (!(__uint_as_float(cd.x) >= thr)) continue;   // outside the window of the row's global approx max
-        const int64_t bi = align ? (int64_t)(cd.y / (uint32_t)Nd) : row / Ns;
-        const int64_t j = align ? (int64_t)(cd.y % (uint32_t)Nd) : (int64_t)cd.y;
+        if (__uint_as_float(cd.x) >= thr) {
+            if (ns < MAXS) {
+#pragma unroll
+                for (int e = 0; e < MAXS; ++e)
+                    if (e == ns) sel[e] = cd.y;
+            }
+            ++ns;
+        }
+    }
+    if (ns > MAXS) {
+        ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
+        return;
+    }
+    // pass 2 (heavy, nearly uniform across the wave): the canonical chain of each survivor
+    unsigned long long bestkey = 0;
+#pragma unroll 1
+    for (int c = 0; c < ns; ++c) {
+        uint32_t col = sel[0];
+#pragma unroll
+        for (int e = 1; e < MAXS; ++e)
+            if (e == c) col = sel[e];
+        const int64_t bi = align ? (int64_t)(col / (uint32_t)Nd) : row / Ns;
+        const int64_t j = align ? (int64_t)(col % (uint32_t)Nd) : (int64_t)col;
         const T *pa = pool_row(x0, P0, x1, P1, bi, a_rows[bi * Ns + i], C);
         const T *pb = pool_row(x0, P0, x1, P1, bi, b_rows[bi * Nd + j], C);
         const float nrm_a = na[bi * Ns + i], nrm_b = nb[bi * Nd + j];
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(fa[e] / nrm_a, fb[e] / nrm_b, acc);
         }
-        const unsigned long long key = ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~cd.y);
+        const unsigned long long key = ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col);
         bestkey = key > bestkey ? key : bestkey;
     }
     if (bestkey) atomicMax(&best[row], bestkey);
