@@ -415,6 +415,90 @@ def test_attention_core_vs_oracle(L, oracle, shape, dtype):
 
 
 # ---------------------------------------------------------------------------------------------------
+# the other BASELINE.json configs at full size, through apply_patch on SD-shaped block sites
+# ---------------------------------------------------------------------------------------------------
+def _site_pass_checks(unet, sites_list, hiddens, B, F, expected_M):
+    """One hot-path pass; checks sizes, finiteness and that surviving tokens attend exactly like a dense
+    recomputation of a few of their rows (attention over the merged set, oracle-free)."""
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import sites as S
+    plans = []
+    orig = vpatch.compute_merge
+
+    def rec(module, x, info, **kw):
+        res = orig(module, x, info, **kw)
+        plans.append(getattr(res[0], "plan", None))
+        return res
+
+    vpatch.compute_merge = rec
+    try:
+        with torch.no_grad():
+            outs = S.run_segment_pass(unet, hiddens)
+    finally:
+        vpatch.compute_merge = orig
+    for site, h, o, plan in zip(sites_list, hiddens, outs, plans):
+        assert o.shape == h.shape and bool(torch.isfinite(o).all()), site.name
+        if site.downsample <= 2:
+            assert plan is not None and plan.M == expected_M[site.downsample], (site.name, plan.M)
+        else:
+            assert plan is None
+    return outs, plans
+
+
+def test_cfg5_sd21_768_full_size(L):
+    """cfg-5: SD-2.1-768, 16 frames 768x768 (latent 96x96), ratio 0.6, fp16: N = 9216 / 2304 tokens per frame,
+    head dim 64, ragged merged lengths (64 513 / 16 129 local, 90 319 / 22 581 with global merging)."""
+    import vidtome_amd
+    from vidtome_amd import sites as S
+    B, F, latent = 2, 16, (96, 96)
+    sl = [s for s in S.sd21_sites() if s.name in ("down0.0", "down1.0", "down2.0", "mid")]
+    unet = S.SiteUNet(sl, seed=1).to(device=DEV, dtype=torch.float16)
+    vidtome_amd.apply_patch(unet, local_merge_ratio=0.6, merge_global=True, global_merge_ratio=0.6, batch_size=B)
+    unet.set_size(latent)
+    torch.manual_seed(123)
+    hiddens = [S.synthetic_hidden(s, B, F, latent, torch.float16, DEV, seed=50 + i) for i, s in enumerate(sl)]
+    _site_pass_checks(unet, sl, hiddens, B, F, {1: 64513, 2: 16129})           # SURVEY.md 8d sizes
+    _site_pass_checks(unet, sl, hiddens, B, F, {1: 90319, 2: 22581})           # second chunk: + global merge
+    vidtome_amd.remove_patch(unet)
+
+
+def test_cfg3_pnp_batch3_aligned_full_size(L):
+    """cfg-3 shape: batch 3 (source | uncond | cond), align_batch=True (one matching shared by the batch,
+    merge.py:93-108) and PnP shared-probability attention (pnp_utils.py:57-67,86-90) at 16 x 512x512."""
+    import vidtome_amd
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import sites as S
+    B, F, latent = 3, 16, (64, 64)
+    sl = [s for s in S.sd15_sites() if s.name in ("up3.0", "up2.0", "up1.0")]
+    unet = S.SiteUNet(sl, seed=2).to(device=DEV, dtype=torch.float16)
+    for blk in unet.blocks:      # what pnp.register_attention_control sets on the decoder blocks
+        blk.attn1.injection_schedule, blk.attn1.t, blk.attn1.vtm_num_inputs = [981], 981, B
+    vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B,
+                            align_batch=True)
+    unet.set_size(latent)
+    torch.manual_seed(123)
+    hiddens = [S.synthetic_hidden(s, B, F, latent, torch.float16, DEV, seed=70 + i) for i, s in enumerate(sl)]
+    for expected in ({1: 34816, 2: 8704}, {1: 52224, 2: 13056}):
+        outs, plans = _site_pass_checks(unet, sl, hiddens, B, F, expected)
+        for plan in plans[:2]:
+            # aligned matching: every sample of the batch shares ONE index set
+            gm = plan.gather_map
+            assert torch.equal(gm[0], gm[1]) and torch.equal(gm[0], gm[2])
+    # shared probabilities: with identical V across the batch groups the three groups' attention outputs
+    # coincide although their own q/k differ (q/k of the source group are used for all)
+    blk = unet.blocks[0]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 1024, 320, generator=g).half().to(DEV)
+    with torch.no_grad():
+        y = vpatch.self_attention(blk.attn1, x)
+        x2 = x.clone()
+        x2[1:] = x[:1]          # same tokens in all groups -> same v; q/k come from group 0 anyway
+        y2 = vpatch.self_attention(blk.attn1, x2)
+    assert torch.allclose(y2[0], y2[1]) and torch.allclose(y2[0], y2[2]) and torch.allclose(y[0], y2[0])
+    vidtome_amd.remove_patch(unet)
+
+
+# ---------------------------------------------------------------------------------------------------
 # full-size, size-independent properties (cfg-2 top block: B=2, F=16, N=4096, C=320)
 # ---------------------------------------------------------------------------------------------------
 def test_full_size_properties(L):

@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void split_operand(const T *__restrict__ x0, i
 __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const uint4 *__restrict__ ah, const uint4 *__restrict__ al, const uint4 *__restrict__ bh,
     const uint4 *__restrict__ bl, int64_t Ns, int64_t Nd, int64_t Ns_pad, int64_t Nd_pad, int64_t C_pad, int align,
-    int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split, unsigned int *__restrict__ amax,
-    int *__restrict__ cnt, uint2 *__restrict__ cand, int *__restrict__ flags) {
+    int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split, int total_src_tiles,
+    unsigned int *__restrict__ amax, int *__restrict__ cnt, uint2 *__restrict__ cand, int *__restrict__ flags) {
     // dst tile of one step: 8 panels x 128 rows x 16 B, hi and lo, double-buffered: 2 x 2 x 16 KiB
     __shared__ __attribute__((aligned(16))) uint4 sA[2][2][8 * FBD];
 
@@ -123,11 +123,19 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
 
-    int id = blockIdx.x;
-    const int split = id % nsplit;
-    id /= nsplit;
-    const int st_ = id % ns_tiles;
-    const int bi = id / ns_tiles;
+    // XCD-aware work mapping (blocks are dispatched round-robin over the 8 XCDs): the ~64 workgroups resident
+    // on one XCD form a patch of 8 consecutive src tiles x all dst splits, so their src operands (the part
+    // that is re-read for every dst tile) stay inside that XCD's 4 MiB L2 and each dst stream is shared by
+    // 8 workgroups.  Purely a speed choice; any placement gives the same result.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_group = 8 * nsplit;
+    const int grp = (slot / per_group) * 8 + xcd;
+    const int q = slot % per_group;
+    const int stg = grp * 8 + q / nsplit;          // flattened (sample, src tile)
+    const int split = q % nsplit;
+    if (stg >= total_src_tiles) return;
+    const int st_ = stg % ns_tiles;
+    const int bi = stg / ns_tiles;
     const int jt0 = split * tiles_per_split;
     const int jt1 = min(jt0 + tiles_per_split, nd_tiles);
     if (jt0 >= jt1) return;
@@ -492,15 +500,21 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
 
     {
         const int ns_tiles = (int)(L.Ns_pad / FBS), nd_tiles = (int)(L.Nd_pad / FBD);
+        // dst splits: enough workgroups to fill the chip, >= 4 dst tiles each, at most 8 (every split
+        // contributes >= 1 candidate per row), and 8 whenever the dst axis is long enough (L2 patching)
         int64_t want = vtm::cdiv(1536, (int64_t)ns_tiles * B);
         int nsplit = (int)(want < 1 ? 1 : want);
+        if (nd_tiles >= 32) nsplit = 8;
         if (nsplit > nd_tiles / 4) nsplit = nd_tiles / 4 > 0 ? nd_tiles / 4 : 1;
-        if (nsplit > 8) nsplit = 8;   // every partition contributes >= 1 candidate per row: keep the lists short
+        if (nsplit > 8) nsplit = 8;
         const int tiles_per_split = (int)vtm::cdiv(nd_tiles, nsplit);
         nsplit = (int)vtm::cdiv(nd_tiles, tiles_per_split);
-        const int64_t grid = (int64_t)B * ns_tiles * nsplit;
+        const int total_src_tiles = (int)(B * ns_tiles);
+        const int ngroups = (int)vtm::cdiv(total_src_tiles, 8);
+        const int64_t grid = (int64_t)8 * vtm::cdiv(ngroups, 8) * 8 * nsplit;
         hipLaunchKernelGGL(filter_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
-                           L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, amax, cnt, cand, flags);
+                           L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, amax,
+                           cnt, cand, flags);
     }
     {
         const dim3 grid((unsigned)vtm::cdiv(rows_out, 256)), block(256);
