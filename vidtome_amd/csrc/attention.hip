@@ -23,6 +23,8 @@
 //     ones, so the MFMA itself accumulates the softmax denominator from the SAME fp16-rounded P.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -122,10 +124,9 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
     }
 
     // hoisted staging addresses: chunk c = tid + 256 i ; K: (row c / DCH, 16-byte piece c % DCH);
-    // V^T: (channel row c / 8, key piece c % 8).  Per tile the K pointers advance by 64 rows, the V^T
-    // pointers by 64 keys.
-    const T *kptr[K_PER_T];
-    const T *vptr[V_PER_T];
+    // V^T: (channel row c / 8, key piece c % 8).  The tile bases are wave-uniform (scalar) pointers that
+    // advance by 64 rows / 64 keys per tile; the per-thread parts are 32-bit element offsets computed once.
+    int kgo[K_PER_T], vgo[V_PER_T];      // global element offsets relative to the tile base
     int koff[K_PER_T], voff[V_PER_T], krow[K_PER_T], vkey[V_PER_T];
     bool kok[K_PER_T], vok[V_PER_T];
 #pragma unroll
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
         const int c = tid + i * 256;
         kok[i] = c < K_CHUNKS;
         krow[i] = c / DCH;
-        kptr[i] = k + (bq * Mp + krow[i]) * ldk + h * D + (c % DCH) * 8;
+        kgo[i] = krow[i] * (int)ldk + (c % DCH) * 8;
         koff[i] = krow[i] * K_STRIDE + (c % DCH) * 8;
     }
 #pragma unroll
@@ -141,29 +142,29 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
         const int c = tid + i * 256;
         vok[i] = c < V_CHUNKS;
         vkey[i] = (c % (KV / 8)) * 8;
-        vptr[i] = vt + (b * C + h * D + c / (KV / 8)) * ldvt + vkey[i];
+        vgo[i] = (c / (KV / 8)) * (int)ldvt + vkey[i];
         voff[i] = (c / (KV / 8)) * VT_STRIDE + vkey[i];
     }
+    const T *ktile = k + bq * Mp * ldk + h * D;          // uniform
+    const T *vtile = vt + (b * C + h * D) * ldvt;        // uniform
     const int64_t kstep = (int64_t)KV * ldk;
 
     uint4 rk[K_PER_T], rv[V_PER_T];
     auto issue_full = [&]() {   // tile completely inside [0, M): no bounds logic
 #pragma unroll
-        for (int i = 0; i < K_PER_T; ++i) {
-            if (kok[i]) rk[i] = *reinterpret_cast<const uint4 *>(kptr[i]);
-            kptr[i] += kstep;
-        }
+        for (int i = 0; i < K_PER_T; ++i)
+            if (kok[i]) rk[i] = *reinterpret_cast<const uint4 *>(ktile + kgo[i]);
 #pragma unroll
-        for (int i = 0; i < V_PER_T; ++i) {
-            if (vok[i]) rv[i] = *reinterpret_cast<const uint4 *>(vptr[i]);
-            vptr[i] += KV;
-        }
+        for (int i = 0; i < V_PER_T; ++i)
+            if (vok[i]) rv[i] = *reinterpret_cast<const uint4 *>(vtile + vgo[i]);
+        ktile += kstep;
+        vtile += KV;
     };
     auto issue_tail = [&](int64_t key0) {   // ragged last tile: rows / keys >= M read as zero
 #pragma unroll
         for (int i = 0; i < K_PER_T; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (kok[i] && key0 + krow[i] < M) v = *reinterpret_cast<const uint4 *>(kptr[i]);
+            if (kok[i] && key0 + krow[i] < M) v = *reinterpret_cast<const uint4 *>(ktile + kgo[i]);
             rk[i] = v;
         }
 #pragma unroll
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
             uint4 v = make_uint4(0, 0, 0, 0);
             const int64_t key = key0 + vkey[i];
             if (vok[i] && key < M) {   // ldvt >= M rounded up to 8: the 16-byte piece is inside the row
-                v = *reinterpret_cast<const uint4 *>(vptr[i]);
+                v = *reinterpret_cast<const uint4 *>(vtile + vgo[i]);
                 elem *e = reinterpret_cast<elem *>(&v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
@@ -202,16 +203,9 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
     float m_run = -INFINITY;   // running max in scaled (log2) units
     float l_run = 0.0f;        // only used when there is no spare O^T row
 
-    const int64_t ntiles = (M + KV - 1) / KV, nfull = M / KV;
-    if (nfull > 0) issue_full(); else issue_tail(0);
-    write_lds(0);
-    __syncthreads();
-
-    for (int64_t t = 0; t < ntiles; ++t) {
-        const int buf = (int)(t & 1);
-        if (t + 1 < nfull) issue_full();
-        else if (t + 1 < ntiles) issue_tail((t + 1) * KV);
-
+    // one tile: S^T = K Q^T -> online softmax -> O^T += V^T P^T.  TAIL = the ragged last tile (keys >= M masked).
+    auto tile = [&](auto tail_tag, int buf, int64_t key0) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         // ---- S^T = K Q^T : 2 blocks of 32 keys
         f32x16 s[2];
 #pragma unroll
@@ -223,13 +217,13 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
             for (int ks = 0; ks < DK; ++ks)
                 s[kb] = F::mfma(*reinterpret_cast<const vec *>(kp + ks * 16), qf[ks], s[kb]);
         }
-        if (t >= nfull) {   // ragged tile: keys >= M get -inf; lane (l31, hi) holds keys 32kb+(r&3)+8(r>>2)+4hi
-            const int64_t key0 = t * KV;
+        if constexpr (TAIL) {   // lane (l31, hi) holds keys key0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
+            const int lim = (int)(M - key0);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= M) s[kb][r] = -INFINITY;
+                    if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= lim) s[kb][r] = -INFINITY;
         }
 
         // ---- online softmax, base 2, deferred rescale
@@ -271,10 +265,33 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
                 o[dv] = F::mfma(*reinterpret_cast<vec *>(&vv), pf[st], o[dv]);
             }
         }
+    };
+    using std::false_type;
+    using std::true_type;
 
-        if (t + 1 < ntiles) write_lds(buf ^ 1);
+    const int64_t ntiles = (M + KV - 1) / KV, nfull = M / KV;
+    if (nfull > 0) issue_full(); else issue_tail(0);
+    write_lds(0);
+    __syncthreads();
+
+    // hot loop: full tiles whose successor is full too -- no bounds logic of any kind inside
+    int64_t t = 0;
+    for (; t + 1 < nfull; ++t) {
+        const int buf = (int)(t & 1);
+        issue_full();
+        tile(false_type{}, buf, t * KV);
+        write_lds(buf ^ 1);
         __syncthreads();
     }
+    if (nfull > 0) {            // last full tile; prefetches the ragged tile if there is one
+        const int buf = (int)(t & 1);
+        if (ntiles > nfull) issue_tail(nfull * KV);
+        tile(false_type{}, buf, t * KV);
+        if (ntiles > nfull) write_lds(buf ^ 1);
+        __syncthreads();
+        ++t;
+    }
+    if (ntiles > nfull) tile(true_type{}, (int)(t & 1), t * KV);
 
     // ---- epilogue: O / l, row q = q0 + l31, channels dv*32 + (r & 3) + 8 (r >> 2) + 4 hi
     float l_tot;
