@@ -5,8 +5,8 @@
 // including its injection branch (probabilities of the source sample reused for every batch group).
 //
 // Structure:
-//   * workgroup = 4 waves, each wave owns 32 query rows; K / V^T tiles of 64 keys are staged through
-//     LDS (register-staged, double-buffered) and shared by the 4 waves; all per-thread global pointers
+//   * workgroup = 8 waves, each wave owns 32 query rows; K / V^T tiles of 64 keys are staged through
+//     LDS (register-staged, double-buffered) and shared by the 8 waves; all per-thread global pointers
 //     and LDS offsets are hoisted, full tiles run without any bounds logic, the ragged last tile has its
 //     own masked path (sequence lengths are 34 816, 52 224, 8 704, 64 513 ...);
 //   * "swapped" QK^T: S^T = K Q^T with v_mfma_f32_32x32x16 puts one query per lane (j = lane & 31) and
@@ -32,7 +32,8 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int WAVES = 4;
+constexpr int WAVES = 8;
+constexpr int NT = WAVES * 64;   // threads per workgroup
 constexpr int QW = 32;           // queries per wave
 constexpr int QB = WAVES * QW;   // queries per workgroup
 constexpr int KV = 64;           // keys per tile
@@ -66,7 +67,7 @@ template <> struct Frag<vtm_bf16> {
 };
 
 template <typename T, int D>
-__global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void attention_kernel(
+__global__ __launch_bounds__(NT, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void attention_kernel(
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
     int64_t M, int64_t Mp, float scale_log2e, int64_t src_batch) {
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
     constexpr int DCH = D / 8;             // 16-byte chunks per K row
     constexpr int K_CHUNKS = KV * DCH;     // per tile
     constexpr int V_CHUNKS = D * (KV / 8);
-    constexpr int K_PER_T = (K_CHUNKS + 255) / 256;
-    constexpr int V_PER_T = (V_CHUNKS + 255) / 256;
+    constexpr int K_PER_T = (K_CHUNKS + NT - 1) / NT;
+    constexpr int V_PER_T = (V_CHUNKS + NT - 1) / NT;
     constexpr int SK_TILE = KV * K_STRIDE, SV_TILE = DV * 32 * VT_STRIDE;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,12 +98,12 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
 
     // one-time LDS init: K pad columns = 0 (they meet Q's zero padding; garbage could be NaN), V^T pad rows
     // = 0 except row D = 1 (denominator row) -- tile loads never touch these
-    for (int i = tid; i < 2 * KV * (K_STRIDE - D); i += 256) {
+    for (int i = tid; i < 2 * KV * (K_STRIDE - D); i += NT) {
         const int row = i / (K_STRIDE - D), c = D + i % (K_STRIDE - D);
         sK[row * K_STRIDE + c] = (elem)0.0f;
     }
     if constexpr (DV * 32 > D) {
-        for (int i = tid; i < 2 * (DV * 32 - D) * VT_STRIDE; i += 256) {
+        for (int i = tid; i < 2 * (DV * 32 - D) * VT_STRIDE; i += NT) {
             const int bufi = i / ((DV * 32 - D) * VT_STRIDE), rem = i % ((DV * 32 - D) * VT_STRIDE);
             const int row = D + rem / VT_STRIDE, c = rem % VT_STRIDE;
             sV[bufi * SV_TILE + row * VT_STRIDE + c] = (elem)((row == D) ? 1.0f : 0.0f);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
     bool kok[K_PER_T], vok[V_PER_T];
 #pragma unroll
     for (int i = 0; i < K_PER_T; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * NT;
         kok[i] = c < K_CHUNKS;
         krow[i] = c / DCH;
         kgo[i] = krow[i] * (int)ldk + (c % DCH) * 8;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(WAVES * 64, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void a
     }
 #pragma unroll
     for (int i = 0; i < V_PER_T; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * NT;
         vok[i] = c < V_CHUNKS;
         vkey[i] = (c % (KV / 8)) * 8;
         vgo[i] = (c / (KV / 8)) * (int)ldvt + vkey[i];
