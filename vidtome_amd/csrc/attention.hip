@@ -32,10 +32,10 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int WAVES = 8;
-constexpr int NT = WAVES * 64;   // threads per workgroup
+// waves per workgroup by head dim (each wave owns 32 queries; all waves share the K / V^T tiles): more waves
+// amortise the tile staging, bounded by the register budget of the wider heads
+constexpr int waves_for(int D) { return D <= 48 ? 8 : D <= 96 ? 16 : 4; }
 constexpr int QW = 32;           // queries per wave
-constexpr int QB = WAVES * QW;   // queries per workgroup
 constexpr int KV = 64;           // keys per tile
 constexpr int VT_STRIDE = KV + 4;  // 68 elements = 34 words: conflict-free ds_read_b64 over 32 rows
 constexpr float DEFER_THR = 8.0f;  // log2 units
@@ -67,13 +67,14 @@ template <> struct Frag<vtm_bf16> {
 };
 
 template <typename T, int D>
-__global__ __launch_bounds__(NT, (D <= 48 ? 4 : D <= 96 ? 3 : 1)) void attention_kernel(
+__global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1)) void attention_kernel(
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
     int64_t M, int64_t Mp, float scale_log2e, int64_t src_batch) {
     using F = Frag<T>;
     using vec = typename F::vec;
     using elem = typename F::elem;
+    constexpr int WAVES = waves_for(D), NT = WAVES * 64, QB = WAVES * QW;
     constexpr int DK = (D + 15) / 16;      // k-steps of the QK^T contraction
     constexpr int DV = (D + 31) / 32;      // 32-row blocks of O^T
     constexpr bool SPARE = (D % 32) != 0;  // O^T row D is free -> softmax denominator through the MFMA
@@ -335,6 +336,7 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
         if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_attention: LDS attribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
+    constexpr int WAVES = waves_for(D), QB = WAVES * QW;
     const dim3 grid((unsigned)vtm::cdiv(M, QB), (unsigned)h, (unsigned)B);
     const float scale_log2e = scale * 1.4426950408889634f;
     hipLaunchKernelGGL((attention_kernel<T, D>), grid, dim3(WAVES * 64), lds, s, (const T *)q, ldq, (const T *)k,
