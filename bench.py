@@ -95,6 +95,18 @@ class KernelTimer:
         return flops, ms, len(rec)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel's largest configuration (top-block attention, M = 52 224),
+    from the rocprofv3 PMC passes recorded in profiles/r01_pmc_traffic.json (FETCH_SIZE doubled per the gfx950
+    note + WRITE_SIZE); None if the profile file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            d = json.load(f)
+        return int(d["attention_kernel<half,40> B=2 h=8 M=52224"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(target_seconds: float):
     """Time the CPU oracle on a bounded sample of the cfg-2 step and extrapolate to the whole step.
     Sample: for one top site (N=4096, C=320) and one mid site (N=1024, C=640): the three matching levels on a
@@ -245,7 +257,7 @@ def main():
             "roofline": {"kernel": "attention_kernel<half,d> (flash attention over merged tokens, "
                                    "v_mfma_f32_32x32x16_f16)",
                          "bound": "mfma", "achieved": round(att_tf, 1), "peak": FP16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(att_tf / FP16_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(att_tf / FP16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                          "launches": an, "avg_launch_ms": round(ams / max(an, 1), 4),
                          "attention_ms_per_step": round(ams / args.steps, 3)},
             # the fused similarity + top-1 step (second largest): algorithmic fp32 FLOPs of the reference's
