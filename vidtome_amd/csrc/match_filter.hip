@@ -206,13 +206,18 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     load_b(0, rb[0]);
     __syncthreads();
 
+    // B-fragment pipeline: groups s = 0..3 of a step alternate between rb[0] / rb[1] (prefetch distance one
+    // group = 24 MFMAs); the FIRST group of the next step is fetched two groups early into rbn, so that the
+    // vmcnt(0) the end-of-step barrier implies never waits on a load that was just issued.
+    uint4 rbn[2][2];
     for (int st = 0; st < steps; ++st) {
         const int buf = st & 1;
         if (st + 1 < steps) load_a(st + 1, buf ^ 1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int gi = st * 4 + s;
-            if (gi + 1 < steps * 4) load_b(gi + 1, rb[(s + 1) & 1]);
+            if (s < 3) load_b(gi + 1, rb[(s + 1) & 1]);
+            if (s == 2 && st + 1 < steps) load_b(gi + 2, rbn);
             h16x8 fh[4], fl[4];
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) {
@@ -277,6 +282,10 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
             }
         }
         __syncthreads();
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) rb[0][sb][hl] = rbn[sb][hl];
     }
 
     // flush: the entries still inside the window of this lane's final maximum

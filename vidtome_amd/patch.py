@@ -235,9 +235,12 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
     wqk, bqk = _fused_weights(attn, x.dtype, x.device)
     qk = F.linear(x, wqk, bqk)                                           # (B, Mp, 2C): one GEMM for q and k
     wv = attn.to_v.weight.to(x.dtype)
-    vt = torch.empty((B, C, Mp), dtype=x.dtype, device=x.device)         # V^T straight from the GEMM:
-    for bi in range(B):                                                  # W_v @ x_b^T, transposed operand
-        torch.mm(wv, x[bi].t(), out=vt[bi])                              # handled by the BLAS (no copy)
+    if B <= 4:                                                           # merged sites: few long sequences
+        vt = torch.empty((B, C, Mp), dtype=x.dtype, device=x.device)     # V^T straight from the GEMM:
+        for bi in range(B):                                              # W_v @ x_b^T, transposed operand
+            torch.mm(wv, x[bi].t(), out=vt[bi])                          # handled by the BLAS (no copy)
+    else:                                                                # un-merged sites: many short ones
+        vt = torch.matmul(wv, x.transpose(1, 2))
     if getattr(attn.to_v, "bias", None) is not None:
         vt = vt + attn.to_v.bias.to(x.dtype)[None, :, None]
     o = _lib.attention(qk[:, :, :C], qk[:, :, C:], vt, heads, M, scale, share)
