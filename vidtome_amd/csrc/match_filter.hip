@@ -14,8 +14,8 @@
 // filter accumulates hi_a*hi_b + hi_a*lo_b + lo_a*hi_b with v_mfma_f32_32x32x16_f16 (exact products, fp32
 // accumulation).  Error budget per score (unit vectors, sum |a_k b_k| <= 1): representation 3 * 2^-22 ~
 // 7e-7, fp32 accumulation of 3C <= 3840 terms <= 2.3e-4 worst case (observed ~1e-6), canonical chain
-// <= 7.7e-5 worst case at C = 1280.  EPS = 2.5e-4 (W = 5e-4) covers the worst case; tests measure the
-// observed error.  The 1024 scale keeps lo out of the fp16 subnormal range for every component that
+// <= 7.7e-5 worst case at C = 1280; the shipped variant additionally drops the src operand's lo half (see
+// SRC_LO below for the full budget and the resulting window).  The 1024 scale keeps lo out of the fp16 subnormal range for every component that
 // matters (a flushed subnormal costs <= 1e-6, inside EPS).
 //
 // Escapes (all exact, no host round trip): a row whose candidate list overflows CAP (massively duplicated
@@ -33,7 +33,18 @@ constexpr int THREADS = 256;
 constexpr int CAP = 64;       // candidate slots per src row
 constexpr float SCALE = 1024.0f;
 constexpr float INV_S2 = 1.0f / (1024.0f * 1024.0f);
-constexpr float WINDOW = 5.0e-4f;   // 2 * EPS
+// SRC_LO = true : 3 products (hi*hi + hi*lo + lo*hi)
+// SRC_LO = false: 2 products ((hi_dst + lo_dst) * hi_src): the src operand's lo half is neither loaded nor
+//                 multiplied (a third less MFMA work and L2 traffic) at the price of a wider window.
+// Error budget per score for unit vectors (sum |a_k b_k| <= 1), C <= 1280, fp16 unit roundoff u = 2^-11:
+//   dropped src lo (SRC_LO = false only)   <= u * sum |a_k b_k|               = 4.9e-4
+//   hi/lo representation tails             <= 3 * 2^-22                       = 7e-7
+//   fp32 accumulation inside the MFMA      <= (2 or 3) * C * 2^-24            = 1.5e-4 / 2.3e-4
+//   the canonical fp32 chain itself        <= C * 2^-24                       = 7.6e-5
+// EPS = 7.5e-4 (2 products) / 3.25e-4 (3 products); observed errors are ~1e-5 / ~1e-6.
+constexpr bool SRC_LO = false;
+constexpr float WINDOW = SRC_LO ? 6.5e-4f : 1.5e-3f;   // 2 * EPS
+constexpr int MAX_C = 1280;                              // the budget above is derived for C <= 1280
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -154,8 +165,10 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         const int64_t off = ((int64_t)(kt * 8 + s * 2 + kh)) * Ns_pad + srow0 + l31;
         dst[0][0] = srch[off];
         dst[1][0] = srch[off + 32];
-        dst[0][1] = srcl[off];
-        dst[1][1] = srcl[off + 32];
+        if constexpr (SRC_LO) {
+            dst[0][1] = srcl[off];
+            dst[1][1] = srcl[off + 32];
+        }
     };
     // A tile of one step: 2 x 16 LDS-DMA wave-instructions of 1 KiB; wave w issues 8 of them
     auto load_a = [&](int st, int buf) {
@@ -233,7 +246,8 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
 #pragma unroll
                 for (int ib = 0; ib < 4; ++ib) {
                     acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], bhf, acc[ib][sb], 0, 0, 0);
-                    acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], blf, acc[ib][sb], 0, 0, 0);
+                    if constexpr (SRC_LO)
+                        acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], blf, acc[ib][sb], 0, 0, 0);
                     acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ib], bhf, acc[ib][sb], 0, 0, 0);
                 }
             }
@@ -330,7 +344,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
     const int64_t i = align ? row : row % Ns;
     // pass 1 (cheap, divergent): compact the candidates inside the window of the row's global approx max.
     // More than MAXS survivors: hand the row to the exact row pass instead.
-    constexpr int MAXS = 6;
+    constexpr int MAXS = 8;
     uint32_t sel[MAXS];
     int ns = 0;
     for (int c = 0; c < n; ++c) {
@@ -465,6 +479,8 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     VTM_REQUIRE(B > 0 && C > 0 && C % 8 == 0 && Ns > 0 && Nd > 0, "vtm_match_filtered: bad sizes");
     VTM_REQUIRE(P1 == 0 || x1, "vtm_match_filtered: x1 is null but P1 > 0");
     VTM_REQUIRE(B * Nd < (1ll << 32) - 1, "vtm_match_filtered: index space overflow");
+    VTM_REQUIRE(C <= MAX_C, "vtm_match_filtered: C=%lld > %d (error window derived for C <= %d; use vtm_match)",
+                (long long)C, MAX_C, MAX_C);
     const Layout L = make_layout(B, C, Ns, Nd, align);
     if (ws_bytes < L.total)
         return vtm::fail(VTM_EWORKSPACE, "vtm_match_filtered: workspace %zu < %zu bytes", ws_bytes, L.total);

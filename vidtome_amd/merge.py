@@ -63,7 +63,7 @@ def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float
     a_pos, b_pos, a_rows, b_rows = parts
     Ns, Nd = a_rows.shape[1], b_rows.shape[1]
     r = min(Ns, int(Ns * ratio))                       # merge.py:90 (Python float -> int truncation)
-    if MATCH_MODE == "exact":                          # plain fp32-MFMA kernel
+    if MATCH_MODE == "exact" or x0.shape[2] > 1280:    # plain fp32-MFMA kernel (filter window holds for C <= 1280)
         a_op, _ = _lib.normalize_gather(x0, x1, a_rows)
         b_op, _ = _lib.normalize_gather(x0, x1, b_rows)
         best = _lib.match(a_op, b_op, Ns, Nd, align_batch)
