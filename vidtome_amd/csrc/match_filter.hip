@@ -24,6 +24,8 @@
 // the ordinary fp32 kernel (match.hip) from a no-op into a full recomputation of the call.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int FBD = 128;      // dst rows per tile (MFMA A operand, LDS)
@@ -31,6 +33,7 @@ constexpr int FBS = 256;      // src rows per workgroup (B operand, registers), 
 constexpr int FBK = 64;       // channels per pipeline step = 4 MFMA k-steps = 8 panels
 constexpr int THREADS = 256;
 constexpr int CAP = 64;       // candidate slots per src row
+constexpr int MAX_SURVIVORS = 8;   // per row after the global-window filter; more -> exact row pass
 constexpr float SCALE = 1024.0f;
 constexpr float INV_S2 = 1.0f / (1024.0f * 1024.0f);
 // SRC_LO = true : 3 products (hi*hi + hi*lo + lo*hi)
@@ -321,55 +324,48 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     }
 }
 
-// ---- refine: exact canonical chain on the surviving candidates ----
+// ---- refine, step 1: per row, keep the candidates inside the window of the row's global approximate max ----
+__global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const unsigned int *__restrict__ amax,
+                                                        const int *__restrict__ cnt, const uint2 *__restrict__ cand,
+                                                        int *__restrict__ flags, int *__restrict__ ovf_rows,
+                                                        uint2 *__restrict__ pairs) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows_out) return;
+    const int n = cnt[row];
+    if (n > CAP) {   // candidate list overflowed: the row is recomputed exactly by exact_rows_kernel
+        ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
+        return;
+    }
+    const float thr = from_orderable(amax[row]) - WINDOW;
+    int ns = 0;
+    for (int c = 0; c < n; ++c) ns += __uint_as_float(cand[row * CAP + c].x) >= thr;
+    if (ns > MAX_SURVIVORS) {
+        ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
+        return;
+    }
+    int at = atomicAdd(&flags[3], ns);
+    for (int c = 0; c < n; ++c) {
+        const uint2 cd = cand[row * CAP + c];
+        if (__uint_as_float(cd.x) >= thr) pairs[at++] = make_uint2((uint32_t)row, cd.y);
+    }
+}
+
+// ---- refine, step 2: one thread per surviving (row, column) pair runs the canonical fp32 chain ----
 template <typename T>
 __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1,
                                                      int64_t P1, int64_t B, int64_t C,
                                                      const int32_t *__restrict__ a_rows, int64_t Ns,
                                                      const int32_t *__restrict__ b_rows, int64_t Nd,
                                                      const float *__restrict__ na, const float *__restrict__ nb,
-                                                     int align, const unsigned int *__restrict__ amax,
-                                                     const int *__restrict__ cnt, const uint2 *__restrict__ cand,
-                                                     unsigned long long *__restrict__ best, int *__restrict__ flags,
-                                                     int *__restrict__ ovf_rows) {
-    const int64_t rows_out = align ? Ns : B * Ns;
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows_out) return;
-    if (cnt[row] > CAP) {   // candidate list overflowed: the row is recomputed exactly by exact_rows_kernel
-        ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
-        return;
-    }
-    const int n = cnt[row];
-    const float thr = from_orderable(amax[row]) - WINDOW;
-    const int64_t i = align ? row : row % Ns;
-    // pass 1 (cheap, divergent): compact the candidates inside the window of the row's global approx max.
-    // More than MAXS survivors: hand the row to the exact row pass instead.
-    constexpr int MAXS = 8;
-    uint32_t sel[MAXS];
-    int ns = 0;
-    for (int c = 0; c < n; ++c) {
-        const uint2 cd = cand[row * CAP + c];
-        if (__uint_as_float(cd.x) >= thr) {
-            if (ns < MAXS) {
-#pragma unroll
-                for (int e = 0; e < MAXS; ++e)
-                    if (e == ns) sel[e] = cd.y;
-            }
-            ++ns;
-        }
-    }
-    if (ns > MAXS) {
-        ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
-        return;
-    }
-    // pass 2 (heavy, nearly uniform across the wave): the canonical chain of each survivor
-    unsigned long long bestkey = 0;
-#pragma unroll 1
-    for (int c = 0; c < ns; ++c) {
-        uint32_t col = sel[0];
-#pragma unroll
-        for (int e = 1; e < MAXS; ++e)
-            if (e == c) col = sel[e];
+                                                     int align, const int *__restrict__ flags,
+                                                     const uint2 *__restrict__ pairs,
+                                                     unsigned long long *__restrict__ best) {
+    const int npairs = flags[3];
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (int64_t)gridDim.x * blockDim.x) {
+        const uint2 pr = pairs[p];
+        const int64_t row = pr.x;
+        const uint32_t col = pr.y;
+        const int64_t i = align ? row : row % Ns;
         const int64_t bi = align ? (int64_t)(col / (uint32_t)Nd) : row / Ns;
         const int64_t j = align ? (int64_t)(col % (uint32_t)Nd) : (int64_t)col;
         const T *pa = pool_row(x0, P0, x1, P1, bi, a_rows[bi * Ns + i], C);
@@ -383,10 +379,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(fa[e] / nrm_a, fb[e] / nrm_b, acc);
         }
-        const unsigned long long key = ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col);
-        bestkey = key > bestkey ? key : bestkey;
+        atomicMax(&best[row], ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col));
     }
-    if (bestkey) atomicMax(&best[row], bestkey);
 }
 
 // ---- exact pass for the (rare) rows whose candidate list overflowed: all Nd canonical chains of the row ----
@@ -434,7 +428,7 @@ __global__ __launch_bounds__(256) void exact_rows_kernel(const T *__restrict__ x
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf, aop, bop, total;
+    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf, pairs, aop, bop, total;
     int64_t Ns_pad, Nd_pad, C64, C32;
 };
 
@@ -458,6 +452,7 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     L.flags = take(256);
     L.cand = take((size_t)rows_out * CAP * 8);
     L.ovf = take((size_t)rows_out * 4);
+    L.pairs = take((size_t)rows_out * MAX_SURVIVORS * 8);
     L.aop = take((size_t)B * L.C32 * L.Ns_pad * 4);
     L.bop = take((size_t)B * L.C32 * L.Nd_pad * 4);
     L.total = o;
@@ -492,6 +487,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     int *cnt = (int *)(w + L.cnt), *flags = (int *)(w + L.flags);
     uint2 *cand = (uint2 *)(w + L.cand);
     int *ovf_rows = (int *)(w + L.ovf);
+    uint2 *pairs = (uint2 *)(w + L.pairs);
     float *aop = (float *)(w + L.aop), *bop = (float *)(w + L.bop);
     const int64_t rows_out = align ? Ns : B * Ns;
 
@@ -542,21 +538,23 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
                            cnt, cand, flags);
     }
     {
-        const dim3 grid((unsigned)vtm::cdiv(rows_out, 256)), block(256);
+        hipLaunchKernelGGL(survivors_kernel, dim3((unsigned)vtm::cdiv(rows_out, 256)), dim3(256), 0, s, rows_out, amax, cnt,
+                           cand, flags, ovf_rows, pairs);
+        // one thread per surviving pair; the count lives on the device, so a fixed grid strides over the list
+        const dim3 grid((unsigned)std::min<int64_t>(vtm::cdiv(rows_out * 2, 256), 4096)), block(256);
         unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(refine_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, amax, cnt, cand, bp, flags, ovf_rows);
+                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(refine_kernel<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, amax, cnt, cand, bp, flags, ovf_rows);
+                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
                 break;
             default:
                 hipLaunchKernelGGL(refine_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, amax, cnt, cand,
-                                   bp, flags, ovf_rows);
+                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
         }
     }
     {   // persistent-style grid over the overflow list (usually empty: the blocks exit at once)
