@@ -25,6 +25,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -161,37 +162,33 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const uint4 *dsth = bh + (int64_t)bi * G * Nd_pad, *dstl = bl + (int64_t)bi * G * Nd_pad;
     const int64_t srow0 = (int64_t)st_ * FBS + wave * 64;
 
-    // B fragments of one MFMA k-step: [src block sb][hi|lo], double-buffered at k-step granularity
+    // B fragments of one MFMA k-step: [src block sb][hi|lo], double-buffered at k-step granularity.
+    // Addresses = wave-uniform panel base (scalar) + a per-lane 32-bit entry offset computed once.
+    const int lane_b = (int)(kh * Ns_pad + srow0 + l31);
     uint4 rb[2][2][2];
-    auto load_b = [&](int gi, uint4 (&dst)[2][2]) {
-        const int kt = (gi >> 2) % KT, s = gi & 3;
-        const int64_t off = ((int64_t)(kt * 8 + s * 2 + kh)) * Ns_pad + srow0 + l31;
-        dst[0][0] = srch[off];
-        dst[1][0] = srch[off + 32];
+    auto load_b = [&](int kt, int ks, uint4 (&dst)[2][2]) {
+        const int64_t pan = (int64_t)(kt * 8 + ks * 2) * Ns_pad;   // uniform
+        const uint4 *ph = srch + pan;
+        dst[0][0] = ph[lane_b];
+        dst[1][0] = ph[lane_b + 32];
         if constexpr (SRC_LO) {
-            dst[0][1] = srcl[off];
-            dst[1][1] = srcl[off + 32];
+            const uint4 *pl = srcl + pan;
+            dst[0][1] = pl[lane_b];
+            dst[1][1] = pl[lane_b + 32];
         }
     };
     // A tile of one step: 2 x 16 LDS-DMA wave-instructions of 1 KiB; wave w issues 8 of them
-    auto load_a = [&](int st, int buf) {
-        const int jt = jt0 + st / KT, kt = st % KT;
+    auto load_a = [&](int jt, int kt, int buf) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int q = wave * 8 + t, which = q >> 4, qq = q & 15, p = qq >> 1, half = qq & 1;
-            const uint4 *gp = (which ? dstl : dsth) + ((int64_t)kt * 8 + p) * Nd_pad + (int64_t)jt * FBD + half * 64 + lane;
+            const uint4 *gbase = (which ? dstl : dsth) + ((int64_t)kt * 8 + p) * Nd_pad + (int64_t)jt * FBD + half * 64;
             uint4 *lp = &sA[buf][which][p * FBD + half * 64];
-            __builtin_amdgcn_global_load_lds((glb_void *)gp, (lds_void *)lp, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(gbase + lane), (lds_void *)lp, 16, 0, 0);
         }
     };
 
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ib][sb][r] = 0.0f;
+    f32x16 acc[4][2];   // (re)started with a zero C operand at the first k-step of every dst tile
 
     const int64_t out_row0 = align ? 0 : (int64_t)bi * Ns;
     const uint32_t idx_base = align ? (uint32_t)((int64_t)bi * Nd) : 0u;
@@ -218,22 +215,24 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         }
     }
 
-    load_a(0, 0);
-    load_b(0, rb[0]);
+    load_a(jt0, 0, 0);
+    load_b(0, 0, rb[0]);
     __syncthreads();
 
     // B-fragment pipeline: groups s = 0..3 of a step alternate between rb[0] / rb[1] (prefetch distance one
-    // group = 24 MFMAs); the FIRST group of the next step is fetched two groups early into rbn, so that the
+    // group = 16 MFMAs); the FIRST group of the next step is fetched two groups early into rbn, so that the
     // vmcnt(0) the end-of-step barrier implies never waits on a load that was just issued.
     uint4 rbn[2][2];
+    int kt = 0, jt = jt0;
     for (int st = 0; st < steps; ++st) {
         const int buf = st & 1;
-        if (st + 1 < steps) load_a(st + 1, buf ^ 1);
+        const bool wrap = kt + 1 == KT;
+        const int ktn = wrap ? 0 : kt + 1, jtn = wrap ? jt + 1 : jt;
+        if (st + 1 < steps) load_a(jtn, ktn, buf ^ 1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int gi = st * 4 + s;
-            if (s < 3) load_b(gi + 1, rb[(s + 1) & 1]);
-            if (s == 2 && st + 1 < steps) load_b(gi + 2, rbn);
+            if (s < 3) load_b(kt, s + 1, rb[(s + 1) & 1]);
+            if (s == 2 && st + 1 < steps) load_b(ktn, 0, rbn);
             h16x8 fh[4], fl[4];
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) {
@@ -242,22 +241,30 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                 fh[ib] = __builtin_bit_cast(h16x8, vh);
                 fl[ib] = __builtin_bit_cast(h16x8, vl);
             }
+            auto mma = [&](auto first_tag) {
+                constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s & 1][sb][0]);
-                const h16x8 blf = __builtin_bit_cast(h16x8, rb[s & 1][sb][1]);
+                for (int sb = 0; sb < 2; ++sb) {
+                    const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s & 1][sb][0]);
+                    const h16x8 blf = __builtin_bit_cast(h16x8, rb[s & 1][sb][1]);
 #pragma unroll
-                for (int ib = 0; ib < 4; ++ib) {
-                    acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], bhf, acc[ib][sb], 0, 0, 0);
-                    if constexpr (SRC_LO)
-                        acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], blf, acc[ib][sb], 0, 0, 0);
-                    acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ib], bhf, acc[ib][sb], 0, 0, 0);
+                    for (int ib = 0; ib < 4; ++ib) {
+                        f32x16 c = acc[ib][sb];
+                        if constexpr (FIRST) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) c[r] = 0.0f;   // folds into the MFMA's zero C operand
+                        }
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], bhf, c, 0, 0, 0);
+                        if constexpr (SRC_LO) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], blf, c, 0, 0, 0);
+                        acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ib], bhf, c, 0, 0, 0);
+                    }
                 }
-            }
+            };
+            if (s == 0 && kt == 0) mma(std::true_type{});
+            else mma(std::false_type{});
         }
-        if ((st + 1) % KT == 0) {
+        if (wrap) {
             // dst tile finished: every score within the window of the lane's running max becomes a candidate
-            const int jt = jt0 + st / KT;
             const int dst0 = jt * FBD + 4 * kh;
             const bool full = (int64_t)(jt + 1) * FBD <= Nd;
 #pragma unroll
@@ -292,8 +299,6 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                         }
                     }
                     rm = fmaxf(rm, gm);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[ib][sb][r] = 0.0f;
                 }
                 runmax[sb] = rm;
             }
@@ -303,6 +308,8 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) rb[0][sb][hl] = rbn[sb][hl];
+        kt = ktn;
+        jt = jtn;
     }
 
     // flush: the entries still inside the window of this lane's final maximum
