@@ -201,6 +201,20 @@ int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const 
                   int64_t ldvt, void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t M,
                   int64_t Mp, int64_t d, float scale, int share_groups, vtm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * vtm_cfg_ddim -- the caller-side elementwise tail of a denoising step:
+ * classifier-free guidance `eps = uncond + guidance * (cond - uncond)` (generate.py:276-278) fused with the
+ * closed-form DDIM update of `pred_next_x` (generate.py:281-311):
+ *     pred_x0 = (x - b*eps) / a ;   x_out = c*pred_x0 + d*eps
+ * sampling: (a, b, c, d) = (mu, sigma, mu_prev, sigma_prev); inversion: (mu_prev, sigma_prev, mu, sigma).
+ * eps_cond may be NULL (no guidance: eps = eps_uncond); eps_out / x_out are optional outputs.  Every
+ * operation rounds to the tensor dtype in the reference's order, so fp16/bf16 results are bit-identical to
+ * the torch expression.
+ * ---------------------------------------------------------------------------------------------- */
+int vtm_cfg_ddim(const void *x, const void *eps_uncond, const void *eps_cond, int dtype, int64_t n,
+                 float guidance, float a, float b, float c, float d, void *eps_out, void *x_out,
+                 vtm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

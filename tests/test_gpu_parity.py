@@ -549,3 +549,18 @@ def test_full_size_properties(L):
         assert bool((ranked[:, 1:] <= ranked[:, :-1]).all())            # descending similarity order
         assert torch.equal(torch.sort(torch.cat([lv.src_idx, lv.unm_idx], 1), 1).values,
                            torch.arange(lv.Ns, device=DEV, dtype=torch.int32)[None].expand(B, -1))
+
+
+# ---------------------------------------------------------------------------------------------------
+# caller-side tail of a step: CFG combine + DDIM update vs the reference's pred_next_x
+# ---------------------------------------------------------------------------------------------------
+def test_cfg_ddim_golden_gpu(L):
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ddim.npz"))
+    for k in range(int(z["n"])):
+        _, _, inversion, guidance, mu, sigma, mu_p, sigma_p = z[f"{k}/meta"].tolist()   # generate.py:299-302
+        coef = (mu_p, sigma_p, mu, sigma) if inversion else (mu, sigma, mu_p, sigma_p)   # generate.py:304-309
+        x, eu, ec = (_t(z[f"{k}/{n}"]) for n in ("x", "eu", "ec"))
+        xn, eps = L.cfg_ddim(x, eu, ec, guidance, *coef, want_eps=True)
+        assert np.array_equal(eps.cpu().numpy(), z[f"{k}/eps"]), k
+        assert np.array_equal(xn.cpu().numpy(), z[f"{k}/xn"]), k

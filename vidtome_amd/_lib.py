@@ -49,6 +49,7 @@ _SIGNATURES = {
     "vtm_unmerge_add": ([_vp, _i64, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp], _int),
     "vtm_attention": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _f32,
                        _int, _vp], _int),
+    "vtm_cfg_ddim": ([_vp, _vp, _vp, _int, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp], _int),
 }
 
 
@@ -270,3 +271,21 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, M:
                                out.data_ptr(), C, dtype_code(q), B, heads, M, Mp, d, float(scale),
                                int(share_groups), _stream()), "vtm_attention")
     return out
+
+
+def cfg_ddim(x: Optional[torch.Tensor], eps_uncond: torch.Tensor, eps_cond: Optional[torch.Tensor], guidance: float,
+             a: float, b: float, c: float, d: float, want_eps: bool = False):
+    """generate.py:276-278 + 281-311 fused: returns x_next (and the guided eps when want_eps)."""
+    _req(eps_uncond, "eps_uncond")
+    n = eps_uncond.numel()
+    # the reference's coefficients are 0-dim fp32 tensors.  torch's CPU kernels (the parity oracle) cast the
+    # multipliers b, c, d to the tensor dtype before the op but divide by the ORIGINAL fp32 value of a
+    # (tests/golden/ddim.npz pins this for fp16); for fp32 tensors all four are used as they are.
+    b, c, d = (float(torch.tensor(v, dtype=torch.float32).to(eps_uncond.dtype)) for v in (b, c, d))
+    a = float(torch.tensor(a, dtype=torch.float32))
+    x_out = torch.empty_like(eps_uncond) if x is not None else None
+    eps_out = torch.empty_like(eps_uncond) if (want_eps or x is None) else None
+    _check(lib().vtm_cfg_ddim(_ptr(x), _ptr(eps_uncond), _ptr(eps_cond), dtype_code(eps_uncond), n, float(guidance),
+                              float(a), float(b), float(c), float(d), _ptr(eps_out), _ptr(x_out), _stream()),
+           "vtm_cfg_ddim")
+    return (x_out, eps_out) if want_eps else (x_out if x is not None else eps_out)
