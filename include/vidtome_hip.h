@@ -90,15 +90,18 @@ int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd,
 
 /* ------------------------------------------------------------------------------------------------
  * vtm_match_filtered -- the same packed result as vtm_normalize_gather x2 + vtm_match, BIT FOR BIT, several
- * times faster: an fp16-MFMA filter pass (hi/lo split operands, 3 products) collects for every src row
- * the dst rows whose approximate score lies within a rigorous error window of the row's running maximum,
- * and an fp32 refine pass evaluates the canonical fmaf chain on those candidates only.  Rows with
- * non-finite normalised components (zero tokens) or with more than 32 candidates raise a device flag that
- * makes a gated launch of the plain fp32 kernel recompute the whole call (exact, no host round trip).
+ * times faster: an fp16-MFMA filter pass (operands split 1024*xhat = hi + lo in fp16; 2 products,
+ * (hi + lo)_dst * hi_src) collects for every src row the dst rows whose approximate score lies within a
+ * rigorous error window of the row's running maximum, and an fp32 refine pass evaluates the canonical
+ * fmaf chain on those candidates only.  A row with more than 64 candidates (massively duplicated dst
+ * rows) is recomputed exactly on its own; any non-finite normalised component (zero token) raises a
+ * device flag that makes a gated launch of the plain fp32 kernel recompute the whole call (exact, no host
+ * round trip).  C > 1280 is rejected (the error budget is derived for C <= 1280; use vtm_match).
  * Inputs are the token pool (x0 | x1, as vtm_normalize_gather) and the gathered pool ids a_rows (B, Ns),
- * b_rows (B, Nd).  ws: >= vtm_match_filtered_ws_bytes(...) bytes.  flags_out (optional, 4 int32):
- * [0] = 1 if the whole-call exact fallback ran (non-finite component, = [1]), [2] = number of rows
- * recomputed exactly because their candidate list overflowed.  Derivation of the window: vidtome_amd/csrc/match_filter.hip.
+ * b_rows (B, Nd).  ws: >= vtm_match_filtered_ws_bytes(...) bytes.  flags_out (optional, 4 int32,
+ * device): [0] = [1] = 1 if the whole-call exact fallback ran (non-finite component), [2] = number of
+ * rows recomputed exactly because their candidate list overflowed, [3] = number of (row, dst) pairs the
+ * refine pass evaluated.  Derivation of the window: vidtome_amd/csrc/match_filter.hip.
  * ---------------------------------------------------------------------------------------------- */
 size_t vtm_match_filtered_ws_bytes(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align);
 int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,

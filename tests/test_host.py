@@ -63,10 +63,7 @@ def test_cpu_tensors_fail_loudly(built):
         merge.bipartite_soft_matching_randframe(x, 4, 0.5, 0, torch.Generator().manual_seed(1))
     with pytest.raises(RuntimeError, match="GPU only"):
         merge.bipartite_soft_matching_2s(x, 8, 0.5, False)
-    # the early-outs of the reference do not touch the data (merge.py:45-46, 364-365)
-    m, u, d = merge.bipartite_soft_matching_randframe(x.to("meta") if False else x, 4, 0.0, 0, None) \
-        if False else (merge.do_nothing, merge.do_nothing, {"unm_num": 4})
-    assert m(x) is x and d["unm_num"] == 4
+    assert merge.do_nothing(x) is x                                   # merge.py:5-6
 
 
 def test_missing_library_is_an_error(built, monkeypatch):
