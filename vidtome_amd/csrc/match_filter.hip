@@ -52,6 +52,7 @@ constexpr int MAX_C = 1280;                              // the budget above is 
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -162,29 +163,52 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const uint4 *dsth = bh + (int64_t)bi * G * Nd_pad, *dstl = bl + (int64_t)bi * G * Nd_pad;
     const int64_t srow0 = (int64_t)st_ * FBS + wave * 64;
 
-    // B fragments of one MFMA k-step: [src block sb][hi|lo], double-buffered at k-step granularity.
-    // Addresses = wave-uniform panel base (scalar) + a per-lane 32-bit entry offset computed once.
+    // ---- vector-memory pipeline, issued and awaited BY HAND (inline asm) --------------------------------------
+    // Why not builtins: while an LDS-DMA (global_load_lds) is pending, hipcc turns EVERY wait on a loaded register
+    // or LDS read into "s_waitcnt vmcnt(0) lgkmcnt(0)" (the instruction counts as a flat access to two address
+    // spaces), which drains the prefetches the moment they are issued -- measured: the MFMA pipe idles half the
+    // time.  vmcnt retires in order, so a counted wait only needs the number of operations issued AFTER the one
+    // awaited; the loop below issues a fixed sequence per step (no conditional loads), hence constant counts:
+    //     group 0: B(2) x NB, DMA x 4 | group 1: B(3) x NB, DMA x 4 | group 2: B(0') x NB | group 3: B(1') x NB
+    // B(s) = src fragments of group s (' = next step), DMA = LDS-DMA pieces of the next dst tile.  B fragments are
+    // fetched two groups (32 MFMAs) ahead, the DMA pieces ride behind the B loads of groups 0 / 1 so that no B wait
+    // drags a freshly issued piece along, and the end-of-step wait leaves the 2 NB youngest loads in flight.
+    // Any additional vector-memory operation the compiler issues (candidate pushes) is younger than ours and can
+    // only make these waits stricter, never laxer.
+    constexpr int NB = SRC_LO ? 4 : 2;
     const int lane_b = (int)(kh * Ns_pad + srow0 + l31);
-    uint4 rb[2][2][2];
-    auto load_b = [&](int kt, int ks, uint4 (&dst)[2][2]) {
+    u32x4 rb[4][2][2];
+    auto load_b = [&](int kt, int ks, u32x4 (&dst)[2][2]) {
         const int64_t pan = (int64_t)(kt * 8 + ks * 2) * Ns_pad;   // uniform
-        const uint4 *ph = srch + pan;
-        dst[0][0] = ph[lane_b];
-        dst[1][0] = ph[lane_b + 32];
+        const uint4 *ph = srch + pan + lane_b;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0][0]) : "v"(ph));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(dst[1][0]) : "v"(ph));
         if constexpr (SRC_LO) {
-            const uint4 *pl = srcl + pan;
-            dst[0][1] = pl[lane_b];
-            dst[1][1] = pl[lane_b + 32];
+            const uint4 *pl = srcl + pan + lane_b;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0][1]) : "v"(pl));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(dst[1][1]) : "v"(pl));
         }
     };
-    // A tile of one step: 2 x 16 LDS-DMA wave-instructions of 1 KiB; wave w issues 8 of them
-    auto load_a = [&](int jt, int kt, int buf) {
+    // the fragments become usable only through this statement (the "+v" ties order every use behind the wait)
+    auto await_b = [&](auto count_tag, u32x4 (&r)[2][2]) {
+        constexpr int N = decltype(count_tag)::value;
+        if constexpr (SRC_LO)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0][0]), "+v"(r[1][0]), "+v"(r[0][1]), "+v"(r[1][1]) : "n"(N));
+        else
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0][0]), "+v"(r[1][0]) : "n"(N));
+    };
+    // A tile of one step: 2 x 16 LDS-DMA wave-instructions of 1 KiB; wave w issues 8 of them, in two halves
+    auto load_a_half = [&](int jt, int kt, int buf, int half_id) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int q = wave * 8 + t, which = q >> 4, qq = q & 15, p = qq >> 1, half = qq & 1;
+        for (int t = 0; t < 4; ++t) {
+            const int q = wave * 8 + half_id * 4 + t, which = q >> 4, qq = q & 15, p = qq >> 1, half = qq & 1;
             const uint4 *gbase = (which ? dstl : dsth) + ((int64_t)kt * 8 + p) * Nd_pad + (int64_t)jt * FBD + half * 64;
             uint4 *lp = &sA[buf][which][p * FBD + half * 64];
-            __builtin_amdgcn_global_load_lds((glb_void *)(gbase + lane), (lds_void *)lp, 16, 0, 0);
+            const uint32_t lds_off = (uint32_t)reinterpret_cast<uintptr_t>((lds_void *)lp);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :
+                         : "s"(lds_off), "v"(gbase + lane)
+                         : "memory", "m0");
         }
     };
 
@@ -215,24 +239,30 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         }
     }
 
-    load_a(jt0, 0, 0);
+    load_a_half(jt0, 0, 0, 0);
+    load_a_half(jt0, 0, 0, 1);
     load_b(0, 0, rb[0]);
+    load_b(0, 1, rb[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // B-fragment pipeline: groups s = 0..3 of a step alternate between rb[0] / rb[1] (prefetch distance one
-    // group = 16 MFMAs); the FIRST group of the next step is fetched two groups early into rbn, so that the
-    // vmcnt(0) the end-of-step barrier implies never waits on a load that was just issued.
-    uint4 rbn[2][2];
     int kt = 0, jt = jt0;
     for (int st = 0; st < steps; ++st) {
         const int buf = st & 1;
         const bool wrap = kt + 1 == KT;
         const int ktn = wrap ? 0 : kt + 1, jtn = wrap ? jt + 1 : jt;
-        if (st + 1 < steps) load_a(jtn, ktn, buf ^ 1);
+        // the last step prefetches too (its own operands again, never used), so that the issue sequence -- and
+        // with it every wait count -- is the same in all steps
+        const bool more = st + 1 < steps;
+        const int ktp = more ? ktn : kt, jtp = more ? jtn : jt;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            if (s < 3) load_b(kt, s + 1, rb[(s + 1) & 1]);
-            if (s == 2 && st + 1 < steps) load_b(ktn, 0, rbn);
+            if (s < 2) load_b(kt, s + 2, rb[s + 2]);
+            else load_b(ktp, s - 2, rb[s - 2]);
+            if (s < 2) load_a_half(jtp, ktp, buf ^ 1, s);
+            // operations issued after B(s): see the table above
+            if (s == 0 || s == 3) await_b(std::integral_constant<int, 2 * NB + 4>{}, rb[s]);
+            else await_b(std::integral_constant<int, 2 * NB + 8>{}, rb[s]);
             h16x8 fh[4], fl[4];
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) {
@@ -245,8 +275,8 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                 constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb) {
-                    const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s & 1][sb][0]);
-                    const h16x8 blf = __builtin_bit_cast(h16x8, rb[s & 1][sb][1]);
+                    const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s][sb][0]);
+                    const h16x8 blf = __builtin_bit_cast(h16x8, rb[s][sb][1]);
 #pragma unroll
                     for (int ib = 0; ib < 4; ++ib) {
                         f32x16 c = acc[ib][sb];
@@ -303,14 +333,14 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                 runmax[sb] = rm;
             }
         }
+        // every wave's DMA pieces of the next tile must have landed before anybody reads them; they are older
+        // than the 2 NB loads of groups 2 and 3
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
         __syncthreads();
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl) rb[0][sb][hl] = rbn[sb][hl];
         kt = ktn;
         jt = jtn;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused prefetches of the last step
 
     // flush: the entries still inside the window of this lane's final maximum
 #pragma unroll
