@@ -183,10 +183,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # VIDTOME_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path run on a box with fewer GPUs than
+    # ranks (the ranks then share devices); the driver's runs use RCCL with one GPU per rank
+    backend = os.environ.get("VIDTOME_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)        # backend "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)    # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import vidtome_amd

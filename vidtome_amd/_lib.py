@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvidtome_hip.so")
+LIB_PATH = os.environ.get("VIDTOME_HIP_LIB") or os.path.join(_HERE, "lib", "libvidtome_hip.so")
 
 VTM_F32, VTM_F16, VTM_BF16 = 0, 1, 2
 ROW_PAD, K_PAD = 256, 32
