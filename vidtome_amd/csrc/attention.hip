@@ -23,7 +23,6 @@
 //     ones, so the MFMA itself accumulates the softmax denominator from the SAME fp16-rounded P.
 #include "common.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -90,6 +89,14 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     constexpr int DK = (D + 15) / 16;      // k-steps of the QK^T contraction
     constexpr int DV = (D + 31) / 32;      // 32-row blocks of O^T
     constexpr bool SPARE = (D % 32) != 0;  // O^T row D is free -> softmax denominator through the MFMA
+    // BIAS: the QK^T contraction has a spare k-slot (D % 16 != 0, e.g. d = 40 -> 48).  Channel D of every K row is
+    // set to 1 and channel D of the (pre-scaled) query to -m, so the MFMA itself delivers s * scale * log2(e) - m
+    // and the softmax needs no v_fma per score (with 40-wide heads the kernel is VALU-bound).  The shift m only
+    // has to be THE SAME for all keys of a query -- it cancels in the normalisation -- so an fp16-representable
+    // running max is as good as the exact one; the scale is folded into the query fragment (one extra fp16
+    // rounding of q, the same size as the rounding the projection GEMM already applied).
+    constexpr bool BIAS = (D % 16) != 0;
+    constexpr int BIAS_HI = (D % 16) / 8, BIAS_E = D % 8;   // lane half / fragment element holding channel D
     constexpr int K_STRIDE = DK * 16 + 8;  // elements; (DK*8+4) words = 4 x odd -> conflict-free b128
     constexpr int DCH = D / 8;             // 16-byte chunks per K row
     constexpr int K_CHUNKS = KV * DCH;     // per tile
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     // = 0 except row D = 1 (denominator row) -- tile loads never touch these
     for (int i = tid; i < 2 * KV * (K_STRIDE - D); i += NT) {
         const int row = i / (K_STRIDE - D), c = D + i % (K_STRIDE - D);
-        sK[row * K_STRIDE + c] = (elem)0.0f;
+        sK[row * K_STRIDE + c] = (elem)((BIAS && c == D) ? 1.0f : 0.0f);
     }
     if constexpr (DV * 32 > D) {
         for (int i = tid; i < 2 * (DV * 32 - D) * VT_STRIDE; i += NT) {
@@ -134,6 +141,10 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             uint4 v = make_uint4(0, 0, 0, 0);
             if (d0 < D && qi < M) v = *reinterpret_cast<const uint4 *>(qp + d0);
             qf[ks] = *reinterpret_cast<vec *>(&v);
+            if constexpr (BIAS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = (elem)((float)qf[ks][e] * scale_log2e);
+            }
         }
     }
 
@@ -212,6 +223,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dv][r] = 0.0f;
     float m_run = -INFINITY;   // running max in scaled (log2) units
+    float m_bias = 0.0f;       // BIAS: the fp16-representable shift currently held in channel D of the query
     float l_run = 0.0f;        // only used when there is no spare O^T row
 
     // one tile: S^T = K Q^T -> online softmax -> O^T += V^T P^T.  TAIL = the ragged last tile (keys >= M masked).
@@ -241,16 +253,39 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
         float mt = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[0][r]), s[1][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
-        if (!__all(mt <= m_run + DEFER_THR)) {
-            const float m_new = fmaxf(m_run, mt);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
-            m_run = m_new;
-            l_run *= alpha;
+        if constexpr (BIAS) {
+            // scores arrive as s c - m_bias: mt is the growth over the current shift (m_run = -inf only before
+            // the first tile, which therefore always takes the branch and installs its own maximum)
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            if (!__all(m_bias + mt <= m_run + DEFER_THR)) {
+                const float m_new = (float)(elem)(fmaxf(m_run, m_bias + mt));   // fp16-representable
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
+                const float delta = m_bias - m_new;                             // exact: both are fp16 values
+                m_run = m_new;
+                m_bias = m_new;
+                l_run *= alpha;
 #pragma unroll
-            for (int dv = 0; dv < DV; ++dv)
+                for (int dv = 0; dv < DV; ++dv)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] += delta;   // this tile was computed with the old shift
+                if (hi == BIAS_HI) qf[DK - 1][BIAS_E] = (elem)(-m_new);
+            }
+        } else {
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
+            if (!__all(mt <= m_run + DEFER_THR)) {
+                const float m_new = fmaxf(m_run, mt);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+            }
         }
         vec pf[4];
 #pragma unroll
@@ -258,7 +293,8 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             float p[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st >> 1][8 * (st & 1) + e], scale_log2e, -m_run));
+                const float sv = s[st >> 1][8 * (st & 1) + e];
+                p[e] = __builtin_amdgcn_exp2f(BIAS ? sv : __builtin_fmaf(sv, scale_log2e, -m_run));
                 if constexpr (!SPARE) l_run += p[e];
             }
             F::pack8(pf[st], p);
@@ -334,308 +370,6 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
 }
 
 
-// ---- software-pipelined variant -------------------------------------------------------------------------------
-// Same arithmetic, tile order and register layouts as attention_kernel; what changes is WHEN things are issued.
-// The wave works in stages of 32 keys and keeps the scores of the NEXT stage in flight:
-//     [MFMA]  S(next) = K(next) Q^T            beside   [VALU]  P(cur) = exp2(S(cur) c - m)  + fp16 pack
-//     [MFMA]  O^T += V^T(cur) P(cur)^T         beside   [VALU]  max of S(next), deferred-rescale decision
-// so each wave always carries matrix and vector work at the same time instead of alternating between an
-// MFMA-only and a VALU-only phase (with 40-wide heads the two are equally long).  The lookahead crosses tile
-// boundaries, hence a ring of three K / V^T tiles in LDS and one barrier per tile placed between its two stages.
-// A rescale (rare) happens after all of the current stage's P V products and before any P of the next stage is
-// exponentiated, so everything accumulated so far is at the old scale exactly once.
-template <int V> using tag = std::integral_constant<int, V>;
-
-template <typename T, int D, int WAVES, int MINW>
-__global__ __launch_bounds__(WAVES * 64, MINW) void attention_pipe_kernel(
-    const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
-    const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
-    int64_t M, int64_t Mp, float scale_log2e, int64_t src_batch) {
-    using F = Frag<T>;
-    using vec = typename F::vec;
-    using elem = typename F::elem;
-    constexpr int NT = WAVES * 64, QB = WAVES * QW, NBUF = 3;
-    constexpr int DK = (D + 15) / 16;
-    constexpr int DV = (D + 31) / 32;
-    constexpr bool SPARE = (D % 32) != 0;
-    constexpr int K_STRIDE = DK * 16 + 8;
-    constexpr int DCH = D / 8;
-    constexpr int K_CHUNKS = KV * DCH;
-    constexpr int V_CHUNKS = D * (KV / 8);
-    constexpr int K_PER_T = (K_CHUNKS + NT - 1) / NT;
-    constexpr int V_PER_T = (V_CHUNKS + NT - 1) / NT;
-    constexpr int SK_TILE = KV * K_STRIDE, SV_TILE = DV * 32 * VT_STRIDE;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    elem *sK = reinterpret_cast<elem *>(smem);   // [NBUF][KV][K_STRIDE]
-    elem *sV = sK + NBUF * SK_TILE;              // [NBUF][DV*32][VT_STRIDE]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int64_t b = blockIdx.z, h = blockIdx.y;
-    const int64_t bq = b % src_batch;
-    const int64_t q0 = (int64_t)blockIdx.x * QB + wave * QW;
-    const int64_t C = H * D;
-
-    for (int i = tid; i < NBUF * KV * (K_STRIDE - D); i += NT) {
-        const int row = i / (K_STRIDE - D), c = D + i % (K_STRIDE - D);
-        sK[row * K_STRIDE + c] = (elem)0.0f;
-    }
-    if constexpr (DV * 32 > D) {
-        for (int i = tid; i < NBUF * (DV * 32 - D) * VT_STRIDE; i += NT) {
-            const int bufi = i / ((DV * 32 - D) * VT_STRIDE), rem = i % ((DV * 32 - D) * VT_STRIDE);
-            const int row = D + rem / VT_STRIDE, c = rem % VT_STRIDE;
-            sV[bufi * SV_TILE + row * VT_STRIDE + c] = (elem)((row == D) ? 1.0f : 0.0f);
-        }
-    }
-
-    vec qf[DK];
-    {
-        const int64_t qi = q0 + l31;
-        const T *qp = q + (bq * Mp + (qi < M ? qi : 0)) * ldq + h * D;
-#pragma unroll
-        for (int ks = 0; ks < DK; ++ks) {
-            const int d0 = ks * 16 + hi * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (d0 < D && qi < M) v = *reinterpret_cast<const uint4 *>(qp + d0);
-            qf[ks] = *reinterpret_cast<vec *>(&v);
-        }
-    }
-
-    int kgo[K_PER_T], vgo[V_PER_T];
-    int koff[K_PER_T], voff[V_PER_T], krow[K_PER_T], vkey[V_PER_T];
-    bool kok[K_PER_T], vok[V_PER_T];
-#pragma unroll
-    for (int i = 0; i < K_PER_T; ++i) {
-        const int c = tid + i * NT;
-        kok[i] = c < K_CHUNKS;
-        krow[i] = c / DCH;
-        kgo[i] = kok[i] ? krow[i] * (int)ldk + (c % DCH) * 8 : 0;
-        koff[i] = krow[i] * K_STRIDE + (c % DCH) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < V_PER_T; ++i) {
-        const int c = tid + i * NT;
-        vok[i] = c < V_CHUNKS;
-        vkey[i] = (c % (KV / 8)) * 8;
-        vgo[i] = vok[i] ? (c / (KV / 8)) * (int)ldvt + vkey[i] : 0;
-        voff[i] = (c / (KV / 8)) * VT_STRIDE + vkey[i];
-    }
-    const T *ktile = k + bq * Mp * ldk + h * D;
-    const T *vtile = vt + (b * C + h * D) * ldvt;
-    const int64_t kstep = (int64_t)KV * ldk;
-
-    uint4 rk[K_PER_T], rv[V_PER_T];
-    auto issue_full = [&]() {
-        // unconditional: surplus threads re-read chunk 0 (their kgo / vgo is 0) and simply do not store it --
-        // a load inside a divergent branch makes the compiler wait for ALL outstanding loads right after it
-#pragma unroll
-        for (int i = 0; i < K_PER_T; ++i) rk[i] = *reinterpret_cast<const uint4 *>(ktile + kgo[i]);
-#pragma unroll
-        for (int i = 0; i < V_PER_T; ++i) rv[i] = *reinterpret_cast<const uint4 *>(vtile + vgo[i]);
-        ktile += kstep;
-        vtile += KV;
-    };
-    auto issue_tail = [&](int64_t key0) {
-#pragma unroll
-        for (int i = 0; i < K_PER_T; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (kok[i] && key0 + krow[i] < M) v = *reinterpret_cast<const uint4 *>(ktile + kgo[i]);
-            rk[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < V_PER_T; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int64_t key = key0 + vkey[i];
-            if (vok[i] && key < M) {
-                v = *reinterpret_cast<const uint4 *>(vtile + vgo[i]);
-                mask_keys(v, (int)(M - key));
-            }
-            rv[i] = v;
-        }
-    };
-    auto write_lds = [&](int buf) {
-        elem *dk = sK + buf * SK_TILE, *dv = sV + buf * SV_TILE;
-#pragma unroll
-        for (int i = 0; i < K_PER_T; ++i)
-            if (kok[i]) *reinterpret_cast<uint4 *>(dk + koff[i]) = rk[i];
-#pragma unroll
-        for (int i = 0; i < V_PER_T; ++i)
-            if (vok[i]) {
-                uint2 *dst = reinterpret_cast<uint2 *>(dv + voff[i]);
-                dst[0] = make_uint2(rv[i].x, rv[i].y);
-                dst[1] = make_uint2(rv[i].z, rv[i].w);
-            }
-    };
-
-    f32x16 o[DV];
-#pragma unroll
-    for (int dv = 0; dv < DV; ++dv)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dv][r] = 0.0f;
-    float m_run = -INFINITY;
-    float l_run = 0.0f;
-    f32x16 sc;   // scores of the current stage (32 keys): lane (l31, hi) holds keys (r & 3) + 8 (r >> 2) + 4 hi
-
-    // S^T block of stage (buf, kb); MASK: keys >= M read as -inf (ragged last tile)
-    auto qk = [&](auto mask_tag, int buf, int kb, int64_t key0, f32x16 &s) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-        const elem *kp = sK + buf * SK_TILE + (kb * 32 + l31) * K_STRIDE + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < DK; ++ks) s = F::mfma(*reinterpret_cast<const vec *>(kp + ks * 16), qf[ks], s);
-        if constexpr (decltype(mask_tag)::value) {
-            const int lim = (int)(M - key0) - kb * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((r & 3) + 8 * (r >> 2) + 4 * hi >= lim) s[r] = -INFINITY;
-        }
-    };
-    // raise the running max if the stage's scores outgrow it by more than the deferral threshold
-    auto decide = [&](const f32x16 &s) {
-        float mt = fmaxf(s[0], s[1]);
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[r]), s[r + 1]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
-        if (!__all(mt <= m_run + DEFER_THR)) {
-            const float m_new = fmaxf(m_run, mt);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first stage: exp2(-inf) = 0
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int dv = 0; dv < DV; ++dv)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
-        }
-    };
-    auto softmax = [&](const f32x16 &s, vec (&pf)[2]) {
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            float p[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[8 * st + e], scale_log2e, -m_run));
-                if constexpr (!SPARE) l_run += p[e];
-            }
-            F::pack8(pf[st], p);
-        }
-    };
-    // O^T += V^T P^T over the 32 keys of stage (buf, kb): k-slot (hi, e) <-> key 16 st + 8 (e >> 2) + 4 hi + (e & 3)
-    auto pv = [&](int buf, int kb, const vec (&pf)[2]) {
-#pragma unroll
-        for (int dv = 0; dv < DV; ++dv) {
-            const elem *vp = sV + buf * SV_TILE + (dv * 32 + l31) * VT_STRIDE + kb * 32 + 4 * hi;
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const uint2 lo = *reinterpret_cast<const uint2 *>(vp + st * 16);
-                const uint2 up = *reinterpret_cast<const uint2 *>(vp + st * 16 + 8);
-                uint4 vv = make_uint4(lo.x, lo.y, up.x, up.y);
-                o[dv] = F::mfma(*reinterpret_cast<vec *>(&vv), pf[st], o[dv]);
-            }
-        }
-    };
-    // one stage; NEXT: 0 = nothing follows, 1 = next stage is full, 2 = next stage needs the key mask
-    auto stage = [&](auto next_tag, int bufc, int kbc, int bufn, int kbn, int64_t key0n) {
-        constexpr int NEXT = decltype(next_tag)::value;
-        f32x16 sn;
-        if constexpr (NEXT != 0) qk(tag<(NEXT == 2)>{}, bufn, kbn, key0n, sn);
-        vec pf[2];
-        softmax(sc, pf);
-        pv(bufc, kbc, pf);
-        if constexpr (NEXT != 0) {
-            decide(sn);
-            sc = sn;
-        }
-    };
-
-    const int64_t ntiles = (M + KV - 1) / KV, nfull = M / KV;
-    auto issue = [&](int64_t tile_idx) {
-        if (tile_idx < nfull) issue_full();
-        else issue_tail(tile_idx * KV);
-    };
-    issue(0);
-    write_lds(0);
-    if (ntiles > 1) issue(1);
-    __syncthreads();
-    if (nfull > 0) qk(tag<0>{}, 0, 0, 0, sc); else qk(tag<1>{}, 0, 0, 0, sc);
-    decide(sc);
-
-    // tile t lives in ring slot t % 3; tile t + 1 is written at the top of iteration t (its slot was last read in
-    // iteration t - 2, and every wave has passed the barrier of iteration t - 1 since), becomes visible at the
-    // barrier between the two stages, and is first read by the lookahead of the second stage
-    int cur = 0;
-    int64_t t = 0;
-    for (; t + 2 < nfull; ++t) {   // hot loop: this tile, the next one and the one being fetched are all full
-        const int nxt = cur == 2 ? 0 : cur + 1;
-        write_lds(nxt);
-        issue_full();
-        stage(tag<1>{}, cur, 0, cur, 1, 0);
-        __syncthreads();
-        stage(tag<1>{}, cur, 1, nxt, 0, 0);
-        cur = nxt;
-    }
-    for (; t < ntiles; ++t) {      // the last (up to) three tiles: ragged tile and end-of-sequence handling
-        const int nxt = cur == 2 ? 0 : cur + 1;
-        const bool has_next = t + 1 < ntiles;
-        if (has_next) write_lds(nxt);
-        if (t + 2 < ntiles) issue(t + 2);
-        if (t < nfull) stage(tag<1>{}, cur, 0, cur, 1, 0);
-        else stage(tag<2>{}, cur, 0, cur, 1, t * KV);
-        __syncthreads();
-        if (!has_next) stage(tag<0>{}, cur, 1, 0, 0, 0);
-        else if (t + 1 < nfull) stage(tag<1>{}, cur, 1, nxt, 0, 0);
-        else stage(tag<2>{}, cur, 1, nxt, 0, (t + 1) * KV);
-        cur = nxt;
-    }
-
-    float l_tot;
-    if constexpr (SPARE) {
-        constexpr int LB = D / 32, LR = D % 32;
-        constexpr int LHI = (LR >> 2) & 1, LREG = (LR & 3) + 4 * (LR >> 3);
-        l_tot = __shfl(o[LB][LREG], l31 + 32 * LHI, 64);
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    }
-    const float inv_l = 1.0f / l_tot;
-    const int64_t qi = q0 + l31;
-    if (qi < M) {
-        T *op = out + (b * Mp + qi) * ldo + h * D;
-#pragma unroll
-        for (int dv = 0; dv < DV; ++dv)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = dv * 32 + 8 * g + 4 * hi;
-                if (d0 < D) {
-                    elem w[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = (elem)(o[dv][g * 4 + e] * inv_l);
-                    *reinterpret_cast<uint2 *>(op + d0) = *reinterpret_cast<uint2 *>(w);
-                }
-            }
-    }
-}
-
-template <typename T, int D, int WAVES, int MINW>
-int launch_pipe(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt, void *out,
-                int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, float scale, int share_groups, hipStream_t s) {
-    constexpr int DK = (D + 15) / 16, DV = (D + 31) / 32;
-    constexpr size_t lds = (size_t)3 * (KV * (DK * 16 + 8) + DV * 32 * VT_STRIDE) * 2;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_pipe_kernel<T, D, WAVES, MINW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_attention: LDS attribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    constexpr int QB = WAVES * QW;
-    const dim3 grid((unsigned)vtm::cdiv(M, QB), (unsigned)h, (unsigned)B);
-    const float scale_log2e = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL((attention_pipe_kernel<T, D, WAVES, MINW>), grid, dim3(WAVES * 64), lds, s, (const T *)q, ldq,
-                       (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, scale_log2e,
-                       B / share_groups);
-    return vtm::launch_status("vtm_attention");
-}
-
 template <typename T, int D>
 int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt, void *out,
            int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, float scale, int share_groups, hipStream_t s) {
@@ -659,10 +393,6 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
 template <typename T>
 int dispatch(int64_t d, const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
              void *out, int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, float scale, int sg, hipStream_t s) {
-    static const int variant = [] { const char *e = getenv("VTM_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-    if (d == 40 && variant == 1) return launch_pipe<T, 40, 8, 4>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
-    if (d == 40 && variant == 2) return launch_pipe<T, 40, 8, 2>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
-    if (d == 40 && variant == 3) return launch_pipe<T, 40, 4, 3>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
     switch (d) {
         case 40: return launch<T, 40>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
         case 64: return launch<T, 64>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);

@@ -179,7 +179,11 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const int lane_b = (int)(kh * Ns_pad + srow0 + l31);
     u32x4 rb[4][2][2];
     auto load_b = [&](int kt, int ks, u32x4 (&dst)[2][2]) {
+#ifdef VTM_EXP_HOTMEM
+        const int64_t pan = (int64_t)(ks * 2) * Ns_pad;
+#else
         const int64_t pan = (int64_t)(kt * 8 + ks * 2) * Ns_pad;   // uniform
+#endif
         const uint4 *ph = srch + pan + lane_b;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0][0]) : "v"(ph));
         asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(dst[1][0]) : "v"(ph));
@@ -202,13 +206,17 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int q = wave * 8 + half_id * 4 + t, which = q >> 4, qq = q & 15, p = qq >> 1, half = qq & 1;
+#ifdef VTM_EXP_HOTMEM
+            const uint4 *gbase = (which ? dstl : dsth) + (int64_t)p * Nd_pad + half * 64;
+#else
             const uint4 *gbase = (which ? dstl : dsth) + ((int64_t)kt * 8 + p) * Nd_pad + (int64_t)jt * FBD + half * 64;
+#endif
             uint4 *lp = &sA[buf][which][p * FBD + half * 64];
             const uint32_t lds_off = (uint32_t)reinterpret_cast<uintptr_t>((lds_void *)lp);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                          :
                          : "s"(lds_off), "v"(gbase + lane)
-                         : "memory", "m0");
+                         : "memory");
         }
     };
 
@@ -255,23 +263,33 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         // with it every wait count -- is the same in all steps
         const bool more = st + 1 < steps;
         const int ktp = more ? ktn : kt, jtp = more ? jtn : jt;
+        // A fragments (dst rows) come from LDS one half-group ahead: the hi halves of group s + 1 are read while
+        // the lo products of group s run, the lo halves of group s while its hi products run -- every read has
+        // 8 MFMAs (256 cycles) to land, in the registers the previous fragments just vacated
+        auto read_a = [&](int which, int s_, h16x8 (&f)[4]) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+                f[ib] = __builtin_bit_cast(h16x8, sA[buf][which][(s_ * 2 + kh) * FBD + ib * 32 + l31]);
+        };
+        h16x8 fh[4], fl[4];
+        read_a(0, 0, fh);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s < 2) load_b(kt, s + 2, rb[s + 2]);
             else load_b(ktp, s - 2, rb[s - 2]);
+#ifndef VTM_EXP_NODMA
             if (s < 2) load_a_half(jtp, ktp, buf ^ 1, s);
+#endif
             // operations issued after B(s): see the table above
+#ifdef VTM_EXP_NOAWAIT
+            await_b(std::integral_constant<int, 63>{}, rb[s]);
+#else
             if (s == 0 || s == 3) await_b(std::integral_constant<int, 2 * NB + 4>{}, rb[s]);
             else await_b(std::integral_constant<int, 2 * NB + 8>{}, rb[s]);
-            h16x8 fh[4], fl[4];
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib) {
-                const uint4 vh = sA[buf][0][(s * 2 + kh) * FBD + ib * 32 + l31];
-                const uint4 vl = sA[buf][1][(s * 2 + kh) * FBD + ib * 32 + l31];
-                fh[ib] = __builtin_bit_cast(h16x8, vh);
-                fl[ib] = __builtin_bit_cast(h16x8, vl);
-            }
-            auto mma = [&](auto first_tag) {
+#endif
+            read_a(1, s, fl);
+            __builtin_amdgcn_sched_barrier(0);
+            auto hi_products = [&](auto first_tag) {
                 constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb) {
@@ -286,14 +304,28 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                         }
                         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], bhf, c, 0, 0, 0);
                         if constexpr (SRC_LO) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], blf, c, 0, 0, 0);
-                        acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ib], bhf, c, 0, 0, 0);
+                        acc[ib][sb] = c;
                     }
                 }
             };
-            if (s == 0 && kt == 0) mma(std::true_type{});
-            else mma(std::false_type{});
+            if (s == 0 && kt == 0) hi_products(std::true_type{});
+            else hi_products(std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (s < 3) read_a(0, s + 1, fh);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s][sb][0]);
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+                    acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ib], bhf, acc[ib][sb], 0, 0, 0);
+            }
         }
+#ifdef VTM_EXP_NOWRAP
+        if (wrap && jt < 0) {
+#else
         if (wrap) {
+#endif
             // dst tile finished: every score within the window of the lane's running max becomes a candidate
             const int dst0 = jt * FBD + 4 * kh;
             const bool full = (int64_t)(jt + 1) * FBD <= Nd;
@@ -307,24 +339,62 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                         for (int r = 0; r < 16; ++r)
                             if (dst0 + ib * 32 + (r & 3) + 8 * (r >> 2) >= Nd) acc[ib][sb][r] = -INFINITY;
                     }
-                    // cheap common path: the block's maximum decides whether anything can qualify
-                    float gm = fmaxf(acc[ib][sb][0], acc[ib][sb][1]);
+                    // The block's 16 scores of this lane, as 4 quarters of 4 (quarter k = dst rows 8 k + 0..3).
+                    // Everything within the window of the running maximum AFTER this block becomes a candidate
+                    // (a running maximum is never above the final one, so this collects a superset of what the
+                    // final maximum requires).  Almost always that is nothing, or exactly the block's maximum:
+                    // that case is handled without a loop -- locate the maximum by compare/select, check that the
+                    // second largest score stays outside the window, insert.  Ties and near-ties inside one block
+                    // (rare) take the element-by-element path below.
+                    const f32x16 &v = acc[ib][sb];
+                    float q[4];
 #pragma unroll
-                    for (int r = 2; r < 16; r += 2) gm = fmaxf(fmaxf(gm, acc[ib][sb][r]), acc[ib][sb][r + 1]);
-                    if (__any(gm >= rm - WS && gm > -INFINITY)) {
+                    for (int k = 0; k < 4; ++k) q[k] = fmaxf(fmaxf(fmaxf(v[4 * k], v[4 * k + 1]), v[4 * k + 2]), v[4 * k + 3]);
+                    const float gm = fmaxf(fmaxf(fmaxf(q[0], q[1]), q[2]), q[3]);
+                    const float newmax = fmaxf(rm, gm);
+                    const float thr = newmax - WS;
+                    const bool trig = gm >= thr && gm > -INFINITY;   // NaN / masked blocks never pass
+                    if (__any(trig)) {
+                        // quarter and element of the (first) maximum
+                        const bool c0 = q[0] == gm, c1 = q[1] == gm, c2 = q[2] == gm;
+                        float w[4];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float v = acc[ib][sb][r];
-                            if (v >= rm - WS && v > -INFINITY) {   // NaN / masked rows never pass
-                                const float nrm_ = fmaxf(rm, v);
-                                if (cv[sb][3] >= nrm_ - WS)   // evicted entry still inside the window: spill it
+                        for (int j = 0; j < 4; ++j) w[j] = c0 ? v[j] : c1 ? v[4 + j] : c2 ? v[8 + j] : v[12 + j];
+                        const int kq = c0 ? 0 : c1 ? 1 : c2 ? 2 : 3;
+                        const bool d0 = w[0] == gm, d1 = w[1] == gm, d2 = w[2] == gm;
+                        const int eq = d0 ? 0 : d1 ? 1 : d2 ? 2 : 3;
+                        // largest score of the block apart from that element
+                        const float qo = fmaxf(fmaxf(fmaxf(c0 ? -INFINITY : q[0], (!c0 && c1) ? -INFINITY : q[1]),
+                                                     (!c0 && !c1 && c2) ? -INFINITY : q[2]),
+                                               (c0 || c1 || c2) ? q[3] : -INFINITY);
+                        const float wo = fmaxf(fmaxf(fmaxf(d0 ? -INFINITY : w[0], (!d0 && d1) ? -INFINITY : w[1]),
+                                                     (!d0 && !d1 && d2) ? -INFINITY : w[2]),
+                                               (d0 || d1 || d2) ? w[3] : -INFINITY);
+                        const float second = fmaxf(qo, wo);
+                        if (!__any(trig && second >= thr)) {
+                            if (trig) {
+                                if (cv[sb][3] >= thr)   // evicted entry still inside the window: spill it
                                     push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3]);
                                 cv[sb][3] = cv[sb][2]; ci[sb][3] = ci[sb][2];
                                 cv[sb][2] = cv[sb][1]; ci[sb][2] = ci[sb][1];
                                 cv[sb][1] = cv[sb][0]; ci[sb][1] = ci[sb][0];
-                                cv[sb][0] = v;
-                                ci[sb][0] = (uint32_t)(dst0 + ib * 32 + (r & 3) + 8 * (r >> 2));
-                                rm = nrm_;
+                                cv[sb][0] = gm;
+                                ci[sb][0] = (uint32_t)(dst0 + ib * 32 + eq + 8 * kq);
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float x = v[r];
+                                if (x >= rm - WS && x > -INFINITY) {
+                                    const float nrm_ = fmaxf(rm, x);
+                                    if (cv[sb][3] >= nrm_ - WS) push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3]);
+                                    cv[sb][3] = cv[sb][2]; ci[sb][3] = ci[sb][2];
+                                    cv[sb][2] = cv[sb][1]; ci[sb][2] = ci[sb][1];
+                                    cv[sb][1] = cv[sb][0]; ci[sb][1] = ci[sb][0];
+                                    cv[sb][0] = x;
+                                    ci[sb][0] = (uint32_t)(dst0 + ib * 32 + (r & 3) + 8 * (r >> 2));
+                                    rm = nrm_;
+                                }
                             }
                         }
                     }
@@ -335,8 +405,10 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         }
         // every wave's DMA pieces of the next tile must have landed before anybody reads them; they are older
         // than the 2 NB loads of groups 2 and 3
+#ifndef VTM_EXP_NOBARRIER
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
         __syncthreads();
+#endif
         kt = ktn;
         jt = jtn;
     }
