@@ -176,21 +176,22 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     // Any additional vector-memory operation the compiler issues (candidate pushes) is younger than ours and can
     // only make these waits stricter, never laxer.
     constexpr int NB = SRC_LO ? 4 : 2;
-    const int lane_b = (int)(kh * Ns_pad + srow0 + l31);
+    // addresses = wave-uniform 64-bit base (SGPR pair, advanced with scalar adds) + per-lane 32-bit byte offset
+    const uint32_t voff_b = (uint32_t)(kh * Ns_pad + srow0 + l31) * 16u;
+    const int64_t bgroup = 2 * Ns_pad;   // uint4 entries per k-step group (2 panels)
     u32x4 rb[4][2][2];
     auto load_b = [&](int kt, int ks, u32x4 (&dst)[2][2]) {
 #ifdef VTM_EXP_HOTMEM
-        const int64_t pan = (int64_t)(ks * 2) * Ns_pad;
+        const uint4 *ph = srch + ks * bgroup;
 #else
-        const int64_t pan = (int64_t)(kt * 8 + ks * 2) * Ns_pad;   // uniform
+        const uint4 *ph = srch + (int64_t)(kt * 4 + ks) * bgroup;   // uniform
 #endif
-        const uint4 *ph = srch + pan + lane_b;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0][0]) : "v"(ph));
-        asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(dst[1][0]) : "v"(ph));
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0][0]) : "v"(voff_b), "s"(ph));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(dst[1][0]) : "v"(voff_b), "s"(ph));
         if constexpr (SRC_LO) {
-            const uint4 *pl = srcl + pan + lane_b;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0][1]) : "v"(pl));
-            asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(dst[1][1]) : "v"(pl));
+            const uint4 *pl = srcl + (int64_t)(kt * 4 + ks) * bgroup;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0][1]) : "v"(voff_b), "s"(pl));
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(dst[1][1]) : "v"(voff_b), "s"(pl));
         }
     };
     // the fragments become usable only through this statement (the "+v" ties order every use behind the wait)
@@ -201,21 +202,30 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         else
             asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0][0]), "+v"(r[1][0]) : "n"(N));
     };
-    // A tile of one step: 2 x 16 LDS-DMA wave-instructions of 1 KiB; wave w issues 8 of them, in two halves
+    // A tile of one step: 2 x 16 LDS-DMA wave-instructions of 1 KiB; wave w issues 8 of them, in two halves.
+    // Per piece only the step offset (kt, jt) changes: the rest of the address and the LDS target are wave constants.
+    const uint4 *abase[8];
+    uint32_t alds[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int q = wave * 8 + t, which = q >> 4, qq = q & 15, p = qq >> 1, half = qq & 1;
+        abase[t] = (which ? dstl : dsth) + (int64_t)p * Nd_pad + half * 64;
+        alds[t] = (uint32_t)reinterpret_cast<uintptr_t>((lds_void *)&sA[0][which][p * FBD + half * 64]);
+    }
+    const uint32_t voff_a = (uint32_t)lane * 16u;
     auto load_a_half = [&](int jt, int kt, int buf, int half_id) {
+#ifdef VTM_EXP_HOTMEM
+        const int64_t step_off = 0;
+#else
+        const int64_t step_off = (int64_t)kt * 8 * Nd_pad + (int64_t)jt * FBD;
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int q = wave * 8 + half_id * 4 + t, which = q >> 4, qq = q & 15, p = qq >> 1, half = qq & 1;
-#ifdef VTM_EXP_HOTMEM
-            const uint4 *gbase = (which ? dstl : dsth) + (int64_t)p * Nd_pad + half * 64;
-#else
-            const uint4 *gbase = (which ? dstl : dsth) + ((int64_t)kt * 8 + p) * Nd_pad + (int64_t)jt * FBD + half * 64;
-#endif
-            uint4 *lp = &sA[buf][which][p * FBD + half * 64];
-            const uint32_t lds_off = (uint32_t)reinterpret_cast<uintptr_t>((lds_void *)lp);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+            const uint4 *g = abase[half_id * 4 + t] + step_off;
+            const uint32_t lds_off = alds[half_id * 4 + t] + (uint32_t)buf * (uint32_t)sizeof(sA[0]);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          :
-                         : "s"(lds_off), "v"(gbase + lane)
+                         : "s"(lds_off), "v"(voff_a), "s"(g)
                          : "memory");
         }
     };
