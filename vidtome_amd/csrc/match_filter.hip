@@ -37,17 +37,23 @@ constexpr int CAP = 64;       // candidate slots per src row
 constexpr int MAX_SURVIVORS = 8;   // per row after the global-window filter; more -> exact row pass
 constexpr float SCALE = 1024.0f;
 constexpr float INV_S2 = 1.0f / (1024.0f * 1024.0f);
-// SRC_LO = true : 3 products (hi*hi + hi*lo + lo*hi)
-// SRC_LO = false: 2 products ((hi_dst + lo_dst) * hi_src): the src operand's lo half is neither loaded nor
-//                 multiplied (a third less MFMA work and L2 traffic) at the price of a wider window.
-// Error budget per score for unit vectors (sum |a_k b_k| <= 1), C <= 1280, fp16 unit roundoff u = 2^-11:
-//   dropped src lo (SRC_LO = false only)   <= u * sum |a_k b_k|               = 4.9e-4
+// Which products the filter accumulates (the refine pass is exact whatever the filter does; fewer products = less
+// MFMA work and operand traffic, wider window = more candidates for the refine pass):
+//   SRC_LO && DST_LO : 3 products  hi*hi + hi*lo + lo*hi
+//   DST_LO only      : 2 products  (hi_dst + lo_dst) * hi_src
+//   neither          : 1 product   hi_dst * hi_src                                  <- shipped
+// Error budget per score for unit vectors (sum |a_k b_k| <= 1), C <= 1280, fp16 unit roundoff u = 2^-11
+// (|lo| <= u |1024 xhat| element-wise):
+//   each dropped lo operand                <= u * sum |a_k b_k|               = 4.9e-4   (both: 2u + u^2 = 9.8e-4)
 //   hi/lo representation tails             <= 3 * 2^-22                       = 7e-7
-//   fp32 accumulation inside the MFMA      <= (2 or 3) * C * 2^-24            = 1.5e-4 / 2.3e-4
+//   fp32 accumulation inside the MFMA      <= (#products) * C * 2^-24         = 7.6e-5 per product
 //   the canonical fp32 chain itself        <= C * 2^-24                       = 7.6e-5
-// EPS = 7.5e-4 (2 products) / 3.25e-4 (3 products); observed errors are ~1e-5 / ~1e-6.
+// EPS = 3.25e-4 (3 products) / 7.5e-4 (2) / 1.2e-3 (1); observed filter errors are ~1e-6 / ~1e-5 / ~2e-5.
+// Measured on the cfg-2 shapes: the wider window adds < 10 % surviving pairs (the refine pass is ~3 % of the call).
 constexpr bool SRC_LO = false;
-constexpr float WINDOW = SRC_LO ? 6.5e-4f : 1.5e-3f;   // 2 * EPS
+constexpr bool DST_LO = false;
+static_assert(DST_LO || !SRC_LO, "the src lo half is only used together with the dst lo half");
+constexpr float WINDOW = SRC_LO ? 6.5e-4f : DST_LO ? 1.5e-3f : 2.4e-3f;   // 2 * EPS
 constexpr int MAX_C = 1280;                              // the budget above is derived for C <= 1280
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void split_operand(const T *__restrict__ x0, i
         if (special) { flags[0] = 1; flags[1] = 1; }
     }
     out_hi[bg * n_pad + i] = vh;
-    out_lo[bg * n_pad + i] = vl;
+    if (out_lo) out_lo[bg * n_pad + i] = vl;
 }
 
 // ---- filter: approximate scores on the fp16 MFMA, candidate collection ----
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split, int total_src_tiles,
     unsigned int *__restrict__ amax, int *__restrict__ cnt, uint2 *__restrict__ cand, int *__restrict__ flags) {
     // dst tile of one step: 8 panels x 128 rows x 16 B, hi and lo, double-buffered: 2 x 2 x 16 KiB
-    __shared__ __attribute__((aligned(16))) uint4 sA[2][2][8 * FBD];
+    __shared__ __attribute__((aligned(16))) uint4 sA[2][DST_LO ? 2 : 1][8 * FBD];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     // spaces), which drains the prefetches the moment they are issued -- measured: the MFMA pipe idles half the
     // time.  vmcnt retires in order, so a counted wait only needs the number of operations issued AFTER the one
     // awaited; the loop below issues a fixed sequence per step (no conditional loads), hence constant counts:
-    //     group 0: B(2) x NB, DMA x 4 | group 1: B(3) x NB, DMA x 4 | group 2: B(0') x NB | group 3: B(1') x NB
+    //     group 0: B(2) x NB, DMA x PG | group 1: B(3) x NB, DMA x PG | group 2: B(0') x NB | group 3: B(1') x NB
     // B(s) = src fragments of group s (' = next step), DMA = LDS-DMA pieces of the next dst tile.  B fragments are
     // fetched two groups (32 MFMAs) ahead, the DMA pieces ride behind the B loads of groups 0 / 1 so that no B wait
     // drags a freshly issued piece along, and the end-of-step wait leaves the 2 NB youngest loads in flight.
@@ -204,11 +210,12 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     };
     // A tile of one step: 2 x 16 LDS-DMA wave-instructions of 1 KiB; wave w issues 8 of them, in two halves.
     // Per piece only the step offset (kt, jt) changes: the rest of the address and the LDS target are wave constants.
-    const uint4 *abase[8];
-    uint32_t alds[8];
+    constexpr int NPIECE = DST_LO ? 8 : 4, PG = NPIECE / 2;   // DMA pieces per wave and step / per group 0, 1
+    const uint4 *abase[NPIECE];
+    uint32_t alds[NPIECE];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int q = wave * 8 + t, which = q >> 4, qq = q & 15, p = qq >> 1, half = qq & 1;
+    for (int t = 0; t < NPIECE; ++t) {
+        const int q = wave * NPIECE + t, which = q >> 4, qq = q & 15, p = qq >> 1, half = qq & 1;
         abase[t] = (which ? dstl : dsth) + (int64_t)p * Nd_pad + half * 64;
         alds[t] = (uint32_t)reinterpret_cast<uintptr_t>((lds_void *)&sA[0][which][p * FBD + half * 64]);
     }
@@ -220,9 +227,9 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         const int64_t step_off = (int64_t)kt * 8 * Nd_pad + (int64_t)jt * FBD;
 #endif
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint4 *g = abase[half_id * 4 + t] + step_off;
-            const uint32_t lds_off = alds[half_id * 4 + t] + (uint32_t)buf * (uint32_t)sizeof(sA[0]);
+        for (int t = 0; t < PG; ++t) {
+            const uint4 *g = abase[half_id * PG + t] + step_off;
+            const uint32_t lds_off = alds[half_id * PG + t] + (uint32_t)buf * (uint32_t)sizeof(sA[0]);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          :
                          : "s"(lds_off), "v"(voff_a), "s"(g)
@@ -281,8 +288,8 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
             for (int ib = 0; ib < 4; ++ib)
                 f[ib] = __builtin_bit_cast(h16x8, sA[buf][which][(s_ * 2 + kh) * FBD + ib * 32 + l31]);
         };
-        h16x8 fh[4], fl[4];
-        read_a(0, 0, fh);
+        h16x8 fa[2][4], fl[4];
+        read_a(0, 0, fa[0]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s < 2) load_b(kt, s + 2, rb[s + 2]);
@@ -294,11 +301,13 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
 #ifdef VTM_EXP_NOAWAIT
             await_b(std::integral_constant<int, 63>{}, rb[s]);
 #else
-            if (s == 0 || s == 3) await_b(std::integral_constant<int, 2 * NB + 4>{}, rb[s]);
-            else await_b(std::integral_constant<int, 2 * NB + 8>{}, rb[s]);
+            if (s == 0 || s == 3) await_b(std::integral_constant<int, 2 * NB + PG>{}, rb[s]);
+            else await_b(std::integral_constant<int, 2 * NB + 2 * PG>{}, rb[s]);
 #endif
-            read_a(1, s, fl);
+            if constexpr (DST_LO) read_a(1, s, fl);
+            else if (s < 3) read_a(0, s + 1, fa[(s + 1) & 1]);   // one group ahead, alternating register sets
             __builtin_amdgcn_sched_barrier(0);
+            h16x8 (&fh)[4] = fa[DST_LO ? 0 : (s & 1)];
             auto hi_products = [&](auto first_tag) {
                 constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
@@ -320,15 +329,17 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
             };
             if (s == 0 && kt == 0) hi_products(std::true_type{});
             else hi_products(std::false_type{});
-            __builtin_amdgcn_sched_barrier(0);
-            if (s < 3) read_a(0, s + 1, fh);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DST_LO) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (s < 3) read_a(0, s + 1, fa[0]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s][sb][0]);
+                for (int sb = 0; sb < 2; ++sb) {
+                    const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s][sb][0]);
 #pragma unroll
-                for (int ib = 0; ib < 4; ++ib)
-                    acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ib], bhf, acc[ib][sb], 0, 0, 0);
+                    for (int ib = 0; ib < 4; ++ib)
+                        acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ib], bhf, acc[ib][sb], 0, 0, 0);
+                }
             }
         }
 #ifdef VTM_EXP_NOWRAP
@@ -635,8 +646,8 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         }
     };
     VTM_REQUIRE(dtype == VTM_F32 || dtype == VTM_F16 || dtype == VTM_BF16, "vtm_match_filtered: bad dtype");
-    split(a_rows, Ns, na, ah, al, L.Ns_pad);
-    split(b_rows, Nd, nb, bh, bl, L.Nd_pad);
+    split(a_rows, Ns, na, ah, SRC_LO ? al : nullptr, L.Ns_pad);
+    split(b_rows, Nd, nb, bh, DST_LO ? bl : nullptr, L.Nd_pad);
 
     {
         const int ns_tiles = (int)(L.Ns_pad / FBS), nd_tiles = (int)(L.Nd_pad / FBD);
