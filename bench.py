@@ -102,7 +102,8 @@ def pmc_traffic():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             d = json.load(f)
-        return int(d["attention_kernel<half,40> B=2 h=8 M=52224"]["hbm_bytes_per_launch"])
+        key = "attention_kernel<half,40> B=2 h=8 M=52224"
+        return int(d.get(key + " (r01_e)", d[key])["hbm_bytes_per_launch"])
     except Exception:
         return None
 

@@ -90,8 +90,8 @@ int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd,
 
 /* ------------------------------------------------------------------------------------------------
  * vtm_match_filtered -- the same packed result as vtm_normalize_gather x2 + vtm_match, BIT FOR BIT, several
- * times faster: an fp16-MFMA filter pass (operands split 1024*xhat = hi + lo in fp16; 2 products,
- * (hi + lo)_dst * hi_src) collects for every src row the dst rows whose approximate score lies within a
+ * times faster: an fp16-MFMA filter pass (operands hi = fp16(1024*xhat), one product hi_dst * hi_src;
+ * the residual lo terms are a build-time option) collects for every src row the dst rows whose approximate score lies within a
  * rigorous error window of the row's running maximum, and an fp32 refine pass evaluates the canonical
  * fmaf chain on those candidates only.  A row with more than 64 candidates (massively duplicated dst
  * rows) is recomputed exactly on its own; any non-finite normalised component (zero token) raises a

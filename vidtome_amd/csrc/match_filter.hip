@@ -1,5 +1,5 @@
 // vtm_match_filtered: the SAME result as vtm_match (canonical fp32 row max / first argmax, bit for bit),
-// obtained ~4x faster: an fp16-MFMA *filter* pass finds, for every src row, the few dst rows that can
+// obtained ~6x faster: an fp16-MFMA *filter* pass finds, for every src row, the few dst rows that can
 // possibly be the fp32 argmax, and an exact fp32 *refine* pass evaluates the canonical fmaf chain only on
 // those candidates.  Reference: vidtome/merge.py:87-113 / 392-417 (scores + max), as vtm_match.
 //
@@ -10,13 +10,12 @@
 // t_ij >= running_max - W" collects all true argmax columns; the refine pass computes their exact scores
 // and combines them with the same packed atomicMax as vtm_match (largest value, first index).
 //
-// Approximation.  xhat (fp32) is split as 1024*xhat = hi + lo (+ dropped 2^-22 tail), hi, lo fp16; the
-// filter accumulates hi_a*hi_b + hi_a*lo_b + lo_a*hi_b with v_mfma_f32_32x32x16_f16 (exact products, fp32
-// accumulation).  Error budget per score (unit vectors, sum |a_k b_k| <= 1): representation 3 * 2^-22 ~
-// 7e-7, fp32 accumulation of 3C <= 3840 terms <= 2.3e-4 worst case (observed ~1e-6), canonical chain
-// <= 7.7e-5 worst case at C = 1280; the shipped variant additionally drops the src operand's lo half (see
-// SRC_LO below for the full budget and the resulting window).  The 1024 scale keeps lo out of the fp16 subnormal range for every component that
-// matters (a flushed subnormal costs <= 1e-6, inside EPS).
+// Approximation.  xhat (fp32) is written as 1024*xhat = hi + lo (+ a dropped 2^-22 tail) with hi, lo fp16, and
+// the filter accumulates products of these halves with v_mfma_f32_32x32x16_f16 (exact products, fp32
+// accumulation).  The shipped variant keeps hi*hi only; the variants that add the lo cross terms are build-time
+// options (SRC_LO / DST_LO below, with the error budget and the window of each).  The 1024 scale keeps the
+// halves out of the fp16 subnormal range for every component that matters (a component below 6e-8 is
+// rounded with an absolute error <= 3e-11, far inside EPS even summed over 1280 channels).
 //
 // Escapes (all exact, no host round trip): a row whose candidate list overflows CAP (massively duplicated
 // dst rows) is recomputed exactly by exact_rows_kernel (all Nd chains of that row); any non-finite xhat
