@@ -414,6 +414,43 @@ def test_attention_core_vs_oracle(L, oracle, shape, dtype):
         assert np.abs(o - ref).max() < tol * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("d", [40, 64])
+@pytest.mark.parametrize("case", ["spike_late", "spike_every_tile", "all_very_negative", "wide_range"])
+def test_attention_rescale_paths(L, oracle, d, case):
+    """The online-softmax corner cases: the running maximum jumps late (deferred-rescale branch, and for d = 40 the
+    shift that rides in the spare k-slot has to be re-installed), grows in every tile, or sits far below zero."""
+    B, h, M = 1, 2, 700          # 11 key tiles of 64
+    C = h * d
+    g = torch.Generator().manual_seed(77 + d)
+    q = torch.randn(B, M, C, generator=g)
+    k = torch.randn(B, M, C, generator=g)
+    v = torch.randn(B, M, C, generator=g)
+    if case == "spike_late":
+        k[:, 600] = 6.0 * q[:, 17]                     # one key dominates query 17 from tile 9 on
+        k[:, 333, :d] = 5.0 * q[:, 400, :d]
+    elif case == "spike_every_tile":
+        for t in range(11):
+            k[:, min(64 * t + 5, M - 1)] = (0.5 + 0.45 * t) * q[:, 3]
+    elif case == "all_very_negative":
+        k = -3.0 * q[:, :1].expand(B, M, C).clone() + 0.05 * k   # every score of query 0 ~ -3 |q|^2 / sqrt(d)
+        q[:, 1:] = 3.0 * q[:, :1] + 0.05 * q[:, 1:]
+    else:
+        q, k = 3.0 * q, 3.0 * k
+    q, k, v = q.half(), k.half(), v.half()
+    Mp = (M + 7) // 8 * 8
+    pad = lambda t: torch.nn.functional.pad(t, (0, 0, 0, Mp - M))
+    o = L.attention(pad(q).to(DEV), pad(k).to(DEV), pad(v).to(DEV).transpose(1, 2).contiguous(), h, M, d ** -0.5, 1)
+    o = o[:, :M].float().cpu().numpy()
+    ref = oracle.attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), h, share_groups=1)
+    assert np.isfinite(o).all()
+    # 1e-3 as everywhere else, except the deliberately extreme "wide_range" logits (|s * scale| up to ~40, softmax
+    # decided by differences of a few 1e-3) on the heads whose query is pre-scaled in fp16 (d % 16 != 0, see
+    # attention.hip): the extra rounding of q costs |logit| * 2^-12 there.  An fp16 reference that rounds its scores
+    # to fp16 (the Diffusers attention the reference calls) is off by |logit| * 2^-11 on the same input.
+    tol = 2e-3 if (case == "wide_range" and d % 16) else 1e-3
+    assert np.abs(o - ref).max() < tol * max(1.0, np.abs(ref).max()), np.abs(o - ref).max()
+
+
 # ---------------------------------------------------------------------------------------------------
 # the other BASELINE.json configs at full size, through apply_patch on SD-shaped block sites
 # ---------------------------------------------------------------------------------------------------
