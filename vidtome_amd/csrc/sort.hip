@@ -4,30 +4,34 @@
 // The sort key is the high word of vtm_match's packed result (already an order-preserving integer
 // image of node_max), inverted so that an ASCENDING stable LSD radix sort yields the DESCENDING order.
 //
-// Design (v3): multi-workgroup LSD radix sort, 8 passes of 4-bit digits, every global access coalesced.
+// Design (v4): multi-workgroup LSD radix sort, 4 passes of 8-bit digits, every global access coalesced.
 // A row is cut into contiguous segments (one 256-thread workgroup each, a few 256-key tiles per segment),
 // so that ~64 CUs work on a row instead of one.  Per pass, three small kernels:
-//   hist     per-segment digit counts from 4 per-bit wave ballots per tile           -> hist[row][digit][seg]
-//   scan     exclusive scan of hist in (digit, segment) order                        -> offs[row][digit][seg]
+//   hist     per-segment digit counts (wave-aggregated: one LDS add per distinct digit and wave) -> hist[row][seg][digit]
+//   scan     exclusive scan of hist in (digit, segment) order                                    -> offs[row][seg][digit]
 //   scatter  stable scatter: offs + earlier tiles of the segment + lower waves of the tile + rank inside
-//            the wave (popcount of the same-digit ballot below the lane)
+//            the wave (popcount of the same-digit lane mask below the lane)
 // Thread order == index order inside a tile, tiles and segments are in index order, so equal digits keep
-// their order (stability).  Rows are <= ~110k keys (L2-resident); ~0.15 ms for 49k keys.
+// their order (stability).  The kernels are launch-latency sized (rows are <= ~110k keys, L2-resident), which
+// is why the digit is 8 bits wide: 12 launches per sort instead of the 24 a 4-bit digit needs.
 #include "common.h"
 
 namespace {
 
 constexpr int T = 256;       // threads per workgroup = keys per tile
 constexpr int WAVES = T / 64;
-constexpr int RADIX = 16;    // 4-bit digits
-constexpr int PASSES = 8;
+constexpr int RADIX = 256;   // 8-bit digits (== T: thread d owns digit d in the per-digit steps)
+constexpr int PASSES = 4;
+static_assert(RADIX == T, "thread d handles digit d");
 
-// mask of the lanes of this wave whose 4-bit digit equals dv, from the 4 per-bit ballots
-__device__ __forceinline__ unsigned long long same_digit(const unsigned long long (&mb)[4], unsigned long long valid,
-                                                         int dv) {
+// mask of the lanes of this wave that hold the same 8-bit digit as this lane (only lanes in `valid`)
+__device__ __forceinline__ unsigned long long same_digit_lanes(int d, unsigned long long valid) {
     unsigned long long m = valid;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) m &= ((dv >> b) & 1) ? mb[b] : ~mb[b];
+    for (int b = 0; b < 8; ++b) {
+        const unsigned long long bal = __ballot((d >> b) & 1);
+        m &= ((d >> b) & 1) ? bal : ~bal;
+    }
     return m;
 }
 
@@ -43,62 +47,50 @@ struct Geo {
 __global__ __launch_bounds__(T) void sort_hist_kernel(const uint64_t *__restrict__ best,
                                                       const uint32_t *__restrict__ ksrc_all, Geo g, int pass,
                                                       int *__restrict__ hist) {
-    __shared__ int wcnt[WAVES][RADIX];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int cnt[RADIX];
+    const int tid = threadIdx.x, lane = tid & 63;
     const int seg = blockIdx.x, row = blockIdx.y;
     const uint64_t *kin = best + (int64_t)row * g.n;
     const uint32_t *ksrc = ksrc_all + (int64_t)row * g.n;
-    const int sh = pass * 4;
-    int mycount = 0;
+    const int sh = pass * 8;
+    cnt[tid] = 0;
+    __syncthreads();
     for (int t = 0; t < g.tiles_per_seg; ++t) {
         const int64_t i = ((int64_t)seg * g.tiles_per_seg + t) * T + tid;
-        int d = 0;
-        if (i < g.n) d = (load_key(kin, ksrc, pass, i) >> sh) & 15u;
-        unsigned long long mb[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) mb[b] = __ballot((d >> b) & 1);
-        const unsigned long long valid = __ballot(i < g.n);
-        if (lane < RADIX) mycount += __popcll(same_digit(mb, valid, lane));
+        const bool ok = i < g.n;
+        const int d = ok ? (int)((load_key(kin, ksrc, pass, i) >> sh) & 255u) : 0;
+        const unsigned long long m = same_digit_lanes(d, __ballot(ok));
+        // the lowest lane of every digit group adds the group's size (no two lanes of a wave hit one address)
+        if (ok && (m & ((1ull << lane) - 1ull)) == 0) atomicAdd(&cnt[d], __popcll(m));
     }
-    if (lane < RADIX) wcnt[wave][lane] = mycount;
     __syncthreads();
-    if (tid < RADIX) {
-        int tot = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) tot += wcnt[w][tid];
-        hist[((int64_t)row * RADIX + tid) * g.nseg + seg] = tot;
-    }
+    hist[((int64_t)row * g.nseg + seg) * RADIX + tid] = cnt[tid];
 }
 
 // exclusive scan over the RADIX * nseg counts of a row in (digit, segment) order; one workgroup per row
 __global__ __launch_bounds__(T) void sort_scan_kernel(const int *__restrict__ hist, int nseg, int *__restrict__ offs) {
     __shared__ int part[T];
     const int tid = threadIdx.x, row = blockIdx.x;
-    const int total = RADIX * nseg;
-    const int per = (total + T - 1) / T;
-    const int *h = hist + (int64_t)row * total;
-    int *o = offs + (int64_t)row * total;
+    // thread d owns digit d: entries [seg][d], coalesced across the workgroup, independent loads kept in flight
+    const int *h = hist + (int64_t)row * nseg * RADIX + tid;
+    int *o = offs + (int64_t)row * nseg * RADIX + tid;
     int sum = 0;
-    for (int e = 0; e < per; ++e) {
-        const int idx = tid * per + e;
-        if (idx < total) sum += h[idx];
-    }
+#pragma unroll 8
+    for (int e = 0; e < nseg; ++e) sum += h[e * RADIX];
     part[tid] = sum;
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 256 partials
+    // Hillis-Steele inclusive scan over the 256 digit totals
     for (int off = 1; off < T; off <<= 1) {
         const int v = tid >= off ? part[tid - off] : 0;
         __syncthreads();
         part[tid] += v;
         __syncthreads();
     }
-    int run = part[tid] - sum;   // exclusive prefix of this thread's chunk
-    for (int e = 0; e < per; ++e) {
-        const int idx = tid * per + e;
-        if (idx < total) {
-            o[idx] = run;
-            run += h[idx];
-        }
+    int run = part[tid] - sum;   // keys with a smaller digit
+#pragma unroll 8
+    for (int e = 0; e < nseg; ++e) {
+        o[e * RADIX] = run;
+        run += h[e * RADIX];
     }
 }
 
@@ -107,7 +99,9 @@ __global__ __launch_bounds__(T) void sort_scatter_kernel(const uint64_t *__restr
                                                          const int32_t *__restrict__ psrc_all,
                                                          uint32_t *__restrict__ kdst_all, int32_t *__restrict__ pdst_all,
                                                          Geo g, int pass, int last, const int *__restrict__ offs) {
-    __shared__ int wcnt[WAVES][RADIX];
+    // wcnt[w][d] = (tile tag << 16) | keys of digit d in wave w of the tagged tile; an entry with another tag
+    // counts as zero, so the table never has to be cleared
+    __shared__ uint32_t wcnt[WAVES][RADIX];
     __shared__ int running[RADIX];   // offs[digit][seg] + keys of the digit in the tiles already scattered
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = blockIdx.x, row = blockIdx.y;
@@ -116,40 +110,45 @@ __global__ __launch_bounds__(T) void sort_scatter_kernel(const uint64_t *__restr
     const int32_t *psrc = psrc_all + (int64_t)row * g.n;
     uint32_t *kdst = kdst_all + (int64_t)row * g.n;
     int32_t *pdst = pdst_all + (int64_t)row * g.n;
-    const int sh = pass * 4;
+    const int sh = pass * 8;
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (tid < RADIX) running[tid] = offs[((int64_t)row * RADIX + tid) * g.nseg + seg];
+    running[tid] = offs[((int64_t)row * g.nseg + seg) * RADIX + tid];
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) wcnt[w][tid] = 0xffff0000u;   // tag no tile ever has
     __syncthreads();
     for (int t = 0; t < g.tiles_per_seg; ++t) {
         const int64_t i = ((int64_t)seg * g.tiles_per_seg + t) * T + tid;
+        const bool ok = i < g.n;
         uint32_t key = 0;
         int32_t id = 0;
         int d = 0;
-        if (i < g.n) {
+        if (ok) {
             key = load_key(kin, ksrc, pass, i);
             id = pass == 0 ? (int32_t)i : psrc[i];
-            d = (key >> sh) & 15u;
+            d = (int)((key >> sh) & 255u);
         }
-        unsigned long long mb[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) mb[b] = __ballot((d >> b) & 1);
-        const unsigned long long valid = __ballot(i < g.n);
-        const int rank = __popcll(same_digit(mb, valid, d) & below);
-        if (lane < RADIX) wcnt[wave][lane] = __popcll(same_digit(mb, valid, lane));
+        const unsigned long long m = same_digit_lanes(d, __ballot(ok));
+        const uint32_t tag = (uint32_t)t << 16;
+        if (ok && (m & below) == 0) wcnt[wave][d] = tag | (uint32_t)__popcll(m);
         __syncthreads();
-        if (i < g.n) {
-            int pos = running[d] + rank;
+        if (ok) {
+            int pos = running[d] + __popcll(m & below);
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w)
-                if (w < wave) pos += wcnt[w][d];
+            for (int w = 0; w < WAVES - 1; ++w) {
+                const uint32_t e = wcnt[w][d];
+                if (w < wave && (e & 0xffff0000u) == tag) pos += (int)(e & 0xffffu);
+            }
             if (!last) kdst[pos] = key;
             pdst[pos] = id;
         }
         __syncthreads();   // everyone has read running[] / wcnt[] of this tile
-        if (tid < RADIX) {
+        {
             int tot = 0;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) tot += wcnt[w][tid];
+            for (int w = 0; w < WAVES; ++w) {
+                const uint32_t e = wcnt[w][tid];
+                tot += (e & 0xffff0000u) == tag ? (int)(e & 0xffffu) : 0;
+            }
             running[tid] += tot;
         }
         __syncthreads();
@@ -188,6 +187,7 @@ VTM_EXPORT int vtm_sort_desc(const uint64_t *best, int64_t rows, int64_t n, int3
     if (n == 0) return VTM_OK;
     hipStream_t s = vtm::as_stream(stream);
     const Geo g = make_geo(n);
+    VTM_REQUIRE(g.tiles_per_seg < 0xffff, "vtm_sort_desc: row too long for the tile tag");
     char *w = static_cast<char *>(ws);
     uint32_t *k0 = reinterpret_cast<uint32_t *>(w), *k1 = k0 + rows * n;
     int32_t *p0 = reinterpret_cast<int32_t *>(k1 + rows * n), *p1 = p0 + rows * n;
