@@ -218,6 +218,17 @@ int vtm_cfg_ddim(const void *x, const void *eps_uncond, const void *eps_cond, in
                  float guidance, float a, float b, float c, float d, void *eps_out, void *x_out,
                  vtm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * vtm_layernorm -- the block's norm1 (vidtome/patch.py:139-146, the plain torch.nn.LayerNorm branch
+ * `norm_hidden_states = self.norm1(hidden_states)`), the first operation of the patched segment and the
+ * producer of the matching metric; also usable for norm2 / norm3 (patch.py:173-176, 187).
+ * x, out: (rows, C) contiguous in `dtype`; gamma, beta: (C) in the same dtype or NULL (no affine part).
+ * fp32 statistics (mean, then centred sum of squares; biased variance like torch), y = (x - mean) *
+ * rsqrt(var + eps) * gamma + beta evaluated in fp32, rounded once.  C % 8 == 0, C <= 2048.
+ * ---------------------------------------------------------------------------------------------- */
+int vtm_layernorm(const void *x, const void *gamma, const void *beta, int dtype, int64_t rows, int64_t C,
+                  float eps, void *out, vtm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -414,6 +414,22 @@ def test_attention_core_vs_oracle(L, oracle, shape, dtype):
         assert np.abs(o - ref).max() < tol * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,C,affine", [(37, 320, True), (1000, 640, True), (5, 1280, True), (3, 8, False), (64, 2048, True)])
+def test_layernorm_vs_torch_fp32(L, rows, C, affine, dtype):
+    """norm1 (patch.py:146): vtm_layernorm against a plain PyTorch fp32 LayerNorm of the same (rounded) input."""
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 3.0 + 0.7).to(dtype)
+    w = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dtype) if affine else None
+    b = (0.1 * torch.randn(C, generator=g)).to(dtype) if affine else None
+    ref = torch.nn.functional.layer_norm(x.float(), (C,), w.float() if affine else None, b.float() if affine else None, 1e-5)
+    y = L.layernorm(x.to(DEV), w.to(DEV) if affine else None, b.to(DEV) if affine else None, 1e-5).float().cpu()
+    tol = {torch.float32: 2e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    assert (y - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    if dtype != torch.float32:   # at most one rounding step away from the correctly rounded fp32 result
+        assert ((y - ref.to(dtype).float()).abs() <= (ref.abs() * 2.0 ** (-10 if dtype == torch.float16 else -7) + 1e-6)).all()
+
+
 @pytest.mark.parametrize("d", [40, 64])
 @pytest.mark.parametrize("case", ["spike_late", "spike_every_tile", "all_very_negative", "wide_range"])
 def test_attention_rescale_paths(L, oracle, d, case):

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "vtm_attention": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _f32,
                        _int, _vp], _int),
     "vtm_cfg_ddim": ([_vp, _vp, _vp, _int, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp], _int),
+    "vtm_layernorm": ([_vp, _vp, _vp, _int, _i64, _i64, _f32, _vp, _vp], _int),
 }
 
 
@@ -289,3 +290,18 @@ def cfg_ddim(x: Optional[torch.Tensor], eps_uncond: torch.Tensor, eps_cond: Opti
                               float(a), float(b), float(c), float(d), _ptr(eps_out), _ptr(x_out), _stream()),
            "vtm_cfg_ddim")
     return (x_out, eps_out) if want_eps else (x_out if x is not None else eps_out)
+
+
+def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float) -> torch.Tensor:
+    """torch.nn.LayerNorm over the last axis (patch.py:139-146 `self.norm1(hidden_states)`)."""
+    _req(x, "x")
+    C = x.shape[-1]
+    xc = x.contiguous()
+    for name, p in (("weight", weight), ("bias", bias)):
+        if p is not None and (p.dtype != x.dtype or p.numel() != C or p.device != x.device):
+            raise RuntimeError(f"vidtome_amd: layernorm {name} must be a ({C},) {x.dtype} tensor on {x.device}")
+    out = torch.empty_like(xc)
+    _check(lib().vtm_layernorm(_ptr(xc), _ptr(weight.contiguous() if weight is not None else None),
+                               _ptr(bias.contiguous() if bias is not None else None), dtype_code(xc),
+                               xc.numel() // C, C, float(eps), _ptr(out), _stream()), "vtm_layernorm")
+    return out

@@ -277,6 +277,19 @@ def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.
     return u_a(attn_output, resid=hidden_states)                          # patch.py:168-169 fused
 
 
+def layer_norm(norm: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """`self.norm1(hidden_states)` (patch.py:146; also norm2 / norm3, patch.py:173-176, 187): a plain
+    torch.nn.LayerNorm over the channel axis runs as vtm_layernorm; anything else (AdaLayerNorm variants,
+    unusual shapes) is the module's own business."""
+    if (type(norm) is torch.nn.LayerNorm and x.is_cuda and len(norm.normalized_shape) == 1
+            and x.shape[-1] == norm.normalized_shape[0] and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048
+            and x.dtype in (torch.float16, torch.bfloat16, torch.float32)
+            and (norm.weight is None or norm.weight.dtype == x.dtype)
+            and (norm.bias is None or norm.bias.dtype == x.dtype)):
+        return _lib.layernorm(x, norm.weight, norm.bias, norm.eps)
+    return norm(x)
+
+
 def make_diffusers_tome_block(block_class: Type[torch.nn.Module]) -> Type[torch.nn.Module]:
     """vidtome/patch.py:119-203: patched class made on the fly, named ToMeBlock, keeps ``_parent``."""
 
@@ -293,7 +306,7 @@ def make_diffusers_tome_block(block_class: Type[torch.nn.Module]) -> Type[torch.
                 norm_hidden_states, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(
                     hidden_states, timestep, class_labels, hidden_dtype=hidden_states.dtype)
             else:
-                norm_hidden_states = self.norm1(hidden_states)
+                norm_hidden_states = layer_norm(self.norm1, hidden_states)
 
             # 1. self-attention on merged tokens (the hot path)                    # patch.py:148-169
             hidden_states = patched_self_attention_segment(
@@ -303,12 +316,12 @@ def make_diffusers_tome_block(block_class: Type[torch.nn.Module]) -> Type[torch.
             cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
             if self.attn2 is not None:                                             # patch.py:171-185
                 norm_hidden_states = (self.norm2(hidden_states, timestep) if self.use_ada_layer_norm
-                                      else self.norm2(hidden_states))
+                                      else layer_norm(self.norm2, hidden_states))
                 attn_output = self.attn2(norm_hidden_states, encoder_hidden_states=encoder_hidden_states,
                                          attention_mask=encoder_attention_mask, **cross_attention_kwargs)
                 hidden_states = attn_output + hidden_states
 
-            norm_hidden_states = self.norm3(hidden_states)                         # patch.py:187-199
+            norm_hidden_states = layer_norm(self.norm3, hidden_states)             # patch.py:187-199
             if self.use_ada_layer_norm_zero:
                 norm_hidden_states = norm_hidden_states * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
             ff_output = self.ff(norm_hidden_states)
