@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void split_operand(const T *__restrict__ x0, i
 __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const uint4 *__restrict__ ah, const uint4 *__restrict__ al, const uint4 *__restrict__ bh,
     const uint4 *__restrict__ bl, int64_t Ns, int64_t Nd, int64_t Ns_pad, int64_t Nd_pad, int64_t C_pad, int align,
-    int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split, int total_src_tiles,
+    int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split, int total_src_tiles, int patch_tiles,
     unsigned int *__restrict__ amax, int *__restrict__ cnt, uint2 *__restrict__ cand, int *__restrict__ flags) {
     // dst tile of one step: 8 panels x 128 rows x 16 B, hi and lo, double-buffered: 2 x 2 x 16 KiB
     __shared__ __attribute__((aligned(16))) uint4 sA[2][DST_LO ? 2 : 1][8 * FBD];
@@ -144,16 +144,18 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
 
-    // XCD-aware work mapping (blocks are dispatched round-robin over the 8 XCDs): the ~64 workgroups resident
-    // on one XCD form a patch of 8 consecutive src tiles x all dst splits, so their src operands (the part
-    // that is re-read for every dst tile) stay inside that XCD's 4 MiB L2 and each dst stream is shared by
-    // 8 workgroups.  Purely a speed choice; any placement gives the same result.
+    // XCD-aware work mapping (blocks are dispatched round-robin over the 8 XCDs, in index order): an XCD works
+    // through patches of `patch_tiles` consecutive src tiles x all dst splits, so the src operands (the part that
+    // is re-read for every dst tile) of its ~64 resident workgroups stay inside that XCD's 4 MiB L2 and each dst
+    // stream is shared by a whole patch.  Inside a patch the order is split-major: the later splits of a row
+    // start when the earlier ones have published their maximum, so their running maximum starts high and
+    // their candidate logic stays on the cheap path.  Purely a speed choice; any placement gives the same result.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per_group = 8 * nsplit;
+    const int per_group = patch_tiles * nsplit;
     const int grp = (slot / per_group) * 8 + xcd;
     const int q = slot % per_group;
-    const int stg = grp * 8 + q / nsplit;          // flattened (sample, src tile)
-    const int split = q % nsplit;
+    const int stg = grp * patch_tiles + q % patch_tiles;   // flattened (sample, src tile)
+    const int split = q / patch_tiles;
     if (stg >= total_src_tiles) return;
     const int st_ = stg % ns_tiles;
     const int bi = stg / ns_tiles;
@@ -660,10 +662,12 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         const int tiles_per_split = (int)vtm::cdiv(nd_tiles, nsplit);
         nsplit = (int)vtm::cdiv(nd_tiles, tiles_per_split);
         const int total_src_tiles = (int)(B * ns_tiles);
-        const int ngroups = (int)vtm::cdiv(total_src_tiles, 8);
-        const int64_t grid = (int64_t)8 * vtm::cdiv(ngroups, 8) * 8 * nsplit;
+        // patch = 16 src tiles while their (hi) operands fit comfortably in one L2 (16 x 256 rows x C x 2 B <= 3 MiB)
+        const int patch_tiles = (int64_t)16 * FBS * L.C64 * 2 <= (3 << 20) ? 16 : 8;
+        const int ngroups = (int)vtm::cdiv(total_src_tiles, patch_tiles);
+        const int64_t grid = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit;
         hipLaunchKernelGGL(filter_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
-                           L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, amax,
+                           L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles, amax,
                            cnt, cand, flags);
     }
     {
