@@ -204,6 +204,13 @@ int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const 
                   int64_t ldvt, void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t M,
                   int64_t Mp, int64_t d, float scale, int share_groups, vtm_stream_t stream);
 
+/* The same kernel with separate query / key lengths: the block's cross-attention `self.attn2(...)`
+ * (vidtome/patch.py:178-183; SD: Mk = 77 text tokens per frame).  q (B, Mqp, .) / out as above; k (B, Mkp, .),
+ * vt (B, h*d, ldvt >= Mk).  vtm_attention is this entry with Mk = Mq, Mkp = Mqp. */
+int vtm_attention_kv(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+                     void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
+                     int64_t Mk, int64_t Mkp, int64_t d, float scale, int share_groups, vtm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * vtm_cfg_ddim -- the caller-side elementwise tail of a denoising step:
  * classifier-free guidance `eps = uncond + guidance * (cond - uncond)` (generate.py:276-278) fused with the
@@ -228,6 +235,13 @@ int vtm_cfg_ddim(const void *x, const void *eps_uncond, const void *eps_cond, in
  * ---------------------------------------------------------------------------------------------- */
 int vtm_layernorm(const void *x, const void *gamma, const void *beta, int dtype, int64_t rows, int64_t C,
                   float eps, void *out, vtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * vtm_geglu -- the gated activation inside the block's feed-forward `self.ff(...)` (vidtome/patch.py:187-199;
+ * SD blocks use the Diffusers GEGLU feed-forward): x (rows, 2 D) = [value | gate] -> out (rows, D) =
+ * value * gelu(gate), exact (erf) gelu, the gate rounded to `dtype` before the product like torch's two ops.
+ * ---------------------------------------------------------------------------------------------- */
+int vtm_geglu(const void *x, int dtype, int64_t rows, int64_t D, void *out, vtm_stream_t stream);
 
 #ifdef __cplusplus
 }

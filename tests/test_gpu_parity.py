@@ -430,6 +430,69 @@ def test_layernorm_vs_torch_fp32(L, rows, C, affine, dtype):
         assert ((y - ref.to(dtype).float()).abs() <= (ref.abs() * 2.0 ** (-10 if dtype == torch.float16 else -7) + 1e-6)).all()
 
 
+# ---------------------------------------------------------------------------------------------------
+# the rest of the patched block (patch.py:171-199): cross-attention and the GEGLU feed-forward
+# ---------------------------------------------------------------------------------------------------
+class GEGLU(torch.nn.Module):                       # named like the Diffusers class the host code recognises
+    def __init__(self, C, inner):
+        super().__init__()
+        self.proj = torch.nn.Linear(C, 2 * inner)
+
+    def forward(self, x):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * torch.nn.functional.gelu(gate)
+
+
+class _FeedForward(torch.nn.Module):
+    def __init__(self, C):
+        super().__init__()
+        self.net = torch.nn.ModuleList([GEGLU(C, 4 * C), torch.nn.Dropout(0.0), torch.nn.Linear(4 * C, C)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_geglu_vs_torch_fp32(L, dtype):
+    g = torch.Generator().manual_seed(5)
+    x = (2.0 * torch.randn(53, 2 * 320, generator=g)).to(dtype)
+    h, gate = x.float().chunk(2, dim=-1)
+    ref = h * torch.nn.functional.gelu(gate)
+    y = L.geglu(x.to(DEV)).float().cpu()
+    tol = {torch.float32: 2e-6, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    assert (y - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,N,Mk,C,heads", [(4, 256, 77, 320, 8), (2, 100, 77, 640, 8), (3, 64, 10, 160, 2)])
+def test_cross_attention_and_ff_vs_torch_fp32(L, B, N, Mk, C, heads):
+    """attn2 / ff of the patched block (patch.py:171-199) against plain PyTorch fp32 on the same rounded inputs."""
+    from standin import Attention
+    from vidtome_amd import patch as vpatch
+    torch.manual_seed(N + C)
+    attn = Attention(C, heads).eval()
+    ff = _FeedForward(C).eval()
+    x = torch.randn(B, N, C).half()
+    enc = torch.randn(B, Mk, C).half()
+    with torch.no_grad():
+        # fp32 reference with the weights rounded to fp16 like the device copy
+        attn_h, ff_h = attn.half(), ff.half()
+        w = lambda m: m.weight.float()
+        q, k, v = x.float() @ w(attn_h.to_q).t(), enc.float() @ w(attn_h.to_k).t(), enc.float() @ w(attn_h.to_v).t()
+        q, k, v = (t.half().float().reshape(B, -1, heads, C // heads).transpose(1, 2) for t in (q, k, v))
+        p = torch.softmax(q @ k.transpose(-1, -2) * attn_h.scale, dim=-1)
+        o = (p @ v).transpose(1, 2).reshape(B, N, C)
+        ref_attn = o @ w(attn_h.to_out[0]).t() + attn_h.to_out[0].bias.float()
+        y = vpatch.cross_attention(attn_h.to(DEV), x.to(DEV), enc.to(DEV)).float().cpu()
+        assert (y - ref_attn).abs().max() < 2e-3 * max(1.0, float(ref_attn.abs().max()))
+        ref_ff = _FeedForward(C).eval()
+        ref_ff.load_state_dict({k_: v_.float() for k_, v_ in ff_h.state_dict().items()})
+        r = ref_ff(x.float())
+        z = vpatch.feed_forward(ff_h.to(DEV), x.to(DEV)).float().cpu()
+        assert (z - r).abs().max() < 4e-3 * max(1.0, float(r.abs().max()))
+
+
 @pytest.mark.parametrize("d", [40, 64])
 @pytest.mark.parametrize("case", ["spike_late", "spike_every_tile", "all_very_negative", "wide_range"])
 def test_attention_rescale_paths(L, oracle, d, case):

@@ -49,8 +49,11 @@ _SIGNATURES = {
     "vtm_unmerge_add": ([_vp, _i64, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp], _int),
     "vtm_attention": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _f32,
                        _int, _vp], _int),
+    "vtm_attention_kv": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                          _f32, _int, _vp], _int),
     "vtm_cfg_ddim": ([_vp, _vp, _vp, _int, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp], _int),
     "vtm_layernorm": ([_vp, _vp, _vp, _int, _i64, _i64, _f32, _vp, _vp], _int),
+    "vtm_geglu": ([_vp, _int, _i64, _i64, _vp, _vp], _int),
 }
 
 
@@ -304,4 +307,33 @@ def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[to
     _check(lib().vtm_layernorm(_ptr(xc), _ptr(weight.contiguous() if weight is not None else None),
                                _ptr(bias.contiguous() if bias is not None else None), dtype_code(xc),
                                xc.numel() // C, C, float(eps), _ptr(out), _stream()), "vtm_layernorm")
+    return out
+
+
+def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, Mq: int, Mk: int, scale: float
+                 ) -> torch.Tensor:
+    """Cross-attention core (patch.py:178-183): q (B, Mqp, C), k (B, Mkp, C) views contiguous along the last axis,
+    vt (B, C, ldvt >= Mk) = v transposed.  Returns (B, Mqp, C)."""
+    B, Mqp, C = q.shape
+    Mkp = k.shape[1]
+    d = C // heads
+    if q.stride(2) != 1 or k.stride(2) != 1 or vt.stride(2) != 1:
+        raise RuntimeError("attention operands must be contiguous along their last axis")
+    if q.stride(0) != Mqp * q.stride(1) or k.stride(0) != Mkp * k.stride(1) or vt.stride(0) != C * vt.stride(1):
+        raise RuntimeError("attention operands must have dense batch strides")
+    out = torch.zeros((B, Mqp, C), dtype=q.dtype, device=q.device) if Mqp != Mq else \
+        torch.empty((B, Mqp, C), dtype=q.dtype, device=q.device)
+    _check(lib().vtm_attention_kv(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(), vt.stride(1),
+                                  out.data_ptr(), C, dtype_code(q), B, heads, Mq, Mqp, Mk, Mkp, d, float(scale), 1,
+                                  _stream()), "vtm_attention_kv")
+    return out
+
+
+def geglu(x: torch.Tensor) -> torch.Tensor:
+    """value * gelu(gate) over the two halves of the last axis (the GEGLU feed-forward, patch.py:187-199)."""
+    _req(x, "x")
+    D = x.shape[-1] // 2
+    xc = x.contiguous()
+    out = torch.empty(xc.shape[:-1] + (D,), dtype=x.dtype, device=x.device)
+    _check(lib().vtm_geglu(_ptr(xc), dtype_code(xc), xc.numel() // (2 * D), D, _ptr(out), _stream()), "vtm_geglu")
     return out

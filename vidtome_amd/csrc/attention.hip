@@ -81,7 +81,9 @@ template <typename T, int D>
 __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1)) void attention_kernel(
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
-    int64_t M, int64_t Mp, float scale_log2e, int64_t src_batch) {
+    int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch) {
+    // M / Mp: queries per sample and their row stride; Mk / Mkp: keys per sample and the row stride of k
+    // (self-attention passes the same values; cross-attention, patch.py:178-183, has Mk = 77)
     using F = Frag<T>;
     using vec = typename F::vec;
     using elem = typename F::elem;
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
         vgo[i] = vok[i] ? (c / (KV / 8)) * (int)ldvt + vkey[i] : 0;
         voff[i] = (c / (KV / 8)) * VT_STRIDE + vkey[i];
     }
-    const T *ktile = k + bq * Mp * ldk + h * D;          // uniform
+    const T *ktile = k + bq * Mkp * ldk + h * D;          // uniform
     const T *vtile = vt + (b * C + h * D) * ldvt;        // uniform
     const int64_t kstep = (int64_t)KV * ldk;
 
@@ -189,16 +191,16 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
 #pragma unroll
         for (int i = 0; i < K_PER_T; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (kok[i] && key0 + krow[i] < M) v = *reinterpret_cast<const uint4 *>(ktile + kgo[i]);
+            if (kok[i] && key0 + krow[i] < Mk) v = *reinterpret_cast<const uint4 *>(ktile + kgo[i]);
             rk[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < V_PER_T; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
             const int64_t key = key0 + vkey[i];
-            if (vok[i] && key < M) {   // ldvt >= M rounded up to 8: the 16-byte piece is inside the row
+            if (vok[i] && key < Mk) {   // ldvt >= Mk rounded up to 8: the 16-byte piece is inside the row
                 v = *reinterpret_cast<const uint4 *>(vtile + vgo[i]);
-                mask_keys(v, (int)(M - key));   // p is 0 there, but 0 * garbage may be NaN
+                mask_keys(v, (int)(Mk - key));   // p is 0 there, but 0 * garbage may be NaN
             }
             rv[i] = v;
         }
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
                 s[kb] = F::mfma(*reinterpret_cast<const vec *>(kp + ks * 16), qf[ks], s[kb]);
         }
         if constexpr (TAIL) {   // lane (l31, hi) holds keys key0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
-            const int lim = (int)(M - key0);
+            const int lim = (int)(Mk - key0);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     using std::false_type;
     using std::true_type;
 
-    const int64_t ntiles = (M + KV - 1) / KV, nfull = M / KV;
+    const int64_t ntiles = (Mk + KV - 1) / KV, nfull = Mk / KV;
     if (nfull > 0) issue_full(); else issue_tail(0);
     write_lds(0);
     __syncthreads();
@@ -372,7 +374,8 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
 
 template <typename T, int D>
 int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt, void *out,
-           int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, float scale, int share_groups, hipStream_t s) {
+           int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale, int share_groups,
+           hipStream_t s) {
     constexpr int DK = (D + 15) / 16, DV = (D + 31) / 32;
     constexpr size_t lds = (size_t)2 * (KV * (DK * 16 + 8) + DV * 32 * VT_STRIDE) * 2;
     static bool attr_set = false;
@@ -386,23 +389,24 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
     const dim3 grid((unsigned)vtm::cdiv(M, QB), (unsigned)h, (unsigned)B);
     const float scale_log2e = scale * 1.4426950408889634f;
     hipLaunchKernelGGL((attention_kernel<T, D>), grid, dim3(WAVES * 64), lds, s, (const T *)q, ldq, (const T *)k,
-                       ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, scale_log2e, B / share_groups);
+                       ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp, scale_log2e, B / share_groups);
     return vtm::launch_status("vtm_attention");
 }
 
 template <typename T>
 int dispatch(int64_t d, const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
-             void *out, int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, float scale, int sg, hipStream_t s) {
+             void *out, int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale, int sg,
+             hipStream_t s) {
     switch (d) {
-        case 40: return launch<T, 40>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
-        case 64: return launch<T, 64>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
-        case 80: return launch<T, 80>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
-        case 160: return launch<T, 160>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
-        case 8: return launch<T, 8>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
-        case 16: return launch<T, 16>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
-        case 32: return launch<T, 32>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
-        case 96: return launch<T, 96>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
-        case 128: return launch<T, 128>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, sg, s);
+        case 40: return launch<T, 40>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
+        case 64: return launch<T, 64>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
+        case 80: return launch<T, 80>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
+        case 160: return launch<T, 160>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
+        case 8: return launch<T, 8>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
+        case 16: return launch<T, 16>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
+        case 32: return launch<T, 32>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
+        case 96: return launch<T, 96>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
+        case 128: return launch<T, 128>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
     }
     return vtm::fail(VTM_EINVAL, "vtm_attention: unsupported head dim %lld (have 8,16,32,40,64,80,96,128,160)",
                      (long long)d);
@@ -410,19 +414,25 @@ int dispatch(int64_t d, const void *q, int64_t ldq, const void *k, int64_t ldk, 
 
 }  // namespace
 
-VTM_EXPORT int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt,
-                             int64_t ldvt, void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t M,
-                             int64_t Mp, int64_t d, float scale, int share_groups, vtm_stream_t stream) {
+VTM_EXPORT int vtm_attention_kv(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+                                void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp, int64_t Mk,
+                                int64_t Mkp, int64_t d, float scale, int share_groups, vtm_stream_t stream) {
     VTM_REQUIRE(q && k && vt && out, "vtm_attention: null pointer");
-    VTM_REQUIRE(B > 0 && h > 0 && M > 0 && d > 0 && Mp >= M, "vtm_attention: bad sizes");
+    VTM_REQUIRE(B > 0 && h > 0 && Mq > 0 && Mk > 0 && d > 0 && Mqp >= Mq && Mkp >= Mk, "vtm_attention: bad sizes");
     VTM_REQUIRE(share_groups >= 1 && B % share_groups == 0, "vtm_attention: B %% share_groups != 0");
-    VTM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= M,
-                "vtm_attention: leading dimensions must keep 16-byte alignment (ldvt >= M, %% 8)");
+    VTM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Mk,
+                "vtm_attention: leading dimensions must keep 16-byte alignment (ldvt >= Mk, %% 8)");
     VTM_REQUIRE(h <= 65535 && B <= 65535, "vtm_attention: grid too large");
     hipStream_t s = vtm::as_stream(stream);
     if (dtype == VTM_F16)
-        return dispatch<__half>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, share_groups, s);
+        return dispatch<__half>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, s);
     if (dtype == VTM_BF16)
-        return dispatch<vtm_bf16>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, scale, share_groups, s);
+        return dispatch<vtm_bf16>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, s);
     return vtm::fail(VTM_EINVAL, "vtm_attention: dtype must be VTM_F16 or VTM_BF16");
+}
+
+VTM_EXPORT int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt,
+                             int64_t ldvt, void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t M,
+                             int64_t Mp, int64_t d, float scale, int share_groups, vtm_stream_t stream) {
+    return vtm_attention_kv(q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, M, Mp, M, Mp, d, scale, share_groups, stream);
 }

@@ -249,6 +249,50 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
     return F.linear(o, to_out.weight.to(o.dtype), None if to_out.bias is None else to_out.bias.to(o.dtype)).to(out_dtype)
 
 
+def cross_attention(attn: torch.nn.Module, x: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor],
+                    attention_mask=None, **kwargs) -> torch.Tensor:
+    """`self.attn2(norm_hidden_states, encoder_hidden_states=..., attention_mask=...)` (patch.py:178-183) -- the
+    un-merged tokens attending to the conditioning (77 text tokens in SD).  The plain case (projection Linears, no
+    mask, no processor kwargs) runs on vtm_attention_kv; everything else is the module's own forward."""
+    plain = (encoder_hidden_states is not None and attention_mask is None and not kwargs and x.is_cuda
+             and all(hasattr(attn, a) for a in ("to_q", "to_k", "to_v", "to_out", "heads"))
+             and x.dim() == 3 and encoder_hidden_states.dim() == 3 and x.shape[-1] % (8 * attn.heads) == 0
+             and x.dtype in (torch.float16, torch.bfloat16)
+             and getattr(attn, "norm_cross", None) is None and getattr(attn, "group_norm", None) is None)
+    if not plain:
+        return attn(x, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, **kwargs)
+    B, N, C = x.shape
+    enc = encoder_hidden_states.to(x.dtype)
+    Mk = enc.shape[1]
+    heads = attn.heads
+    scale = getattr(attn, "scale", None) or (C // heads) ** -0.5
+    Np, Mkp = (N + 7) // 8 * 8, (Mk + 7) // 8 * 8
+    if Np != N:
+        x = F.pad(x, (0, 0, 0, Np - N))
+    if Mkp != Mk:
+        enc = F.pad(enc, (0, 0, 0, Mkp - Mk))
+    lin = lambda m, t: F.linear(t, m.weight.to(t.dtype), None if m.bias is None else m.bias.to(t.dtype))
+    q = lin(attn.to_q, x)
+    k = lin(attn.to_k, enc)
+    vt = lin(attn.to_v, enc).transpose(1, 2).contiguous()               # (B, C, Mkp): 77 keys, negligible
+    o = _lib.attention_kv(q, k, vt, heads, N, Mk, scale)
+    to_out = attn.to_out[0] if isinstance(attn.to_out, (torch.nn.ModuleList, torch.nn.Sequential, list, tuple)) \
+        else attn.to_out
+    return lin(to_out, o)[:, :N]
+
+
+def feed_forward(ff: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """`self.ff(norm_hidden_states)` (patch.py:192).  The Diffusers feed-forward of SD blocks is
+    [GEGLU(proj: Linear C -> 8C), Dropout, Linear 4C -> C]; when that shape is recognised the gated activation
+    runs as vtm_geglu (the two Linears stay library GEMMs), otherwise the module runs unchanged."""
+    net = getattr(ff, "net", None)
+    if (net is not None and len(net) == 3 and net[0].__class__.__name__ == "GEGLU" and hasattr(net[0], "proj")
+            and isinstance(net[2], torch.nn.Linear) and x.is_cuda and not ff.training
+            and x.dtype in (torch.float16, torch.bfloat16, torch.float32) and net[0].proj.out_features % 16 == 0):
+        return net[2](_lib.geglu(net[0].proj(x)))
+    return ff(x)
+
+
 # ----------------------------------------------------------------------------------------------------
 # patched block
 # ----------------------------------------------------------------------------------------------------
@@ -317,14 +361,14 @@ def make_diffusers_tome_block(block_class: Type[torch.nn.Module]) -> Type[torch.
             if self.attn2 is not None:                                             # patch.py:171-185
                 norm_hidden_states = (self.norm2(hidden_states, timestep) if self.use_ada_layer_norm
                                       else layer_norm(self.norm2, hidden_states))
-                attn_output = self.attn2(norm_hidden_states, encoder_hidden_states=encoder_hidden_states,
-                                         attention_mask=encoder_attention_mask, **cross_attention_kwargs)
+                attn_output = cross_attention(self.attn2, norm_hidden_states, encoder_hidden_states,
+                                              encoder_attention_mask, **cross_attention_kwargs)
                 hidden_states = attn_output + hidden_states
 
             norm_hidden_states = layer_norm(self.norm3, hidden_states)             # patch.py:187-199
             if self.use_ada_layer_norm_zero:
                 norm_hidden_states = norm_hidden_states * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
-            ff_output = self.ff(norm_hidden_states)
+            ff_output = feed_forward(self.ff, norm_hidden_states)
             if self.use_ada_layer_norm_zero:
                 ff_output = gate_mlp.unsqueeze(1) * ff_output
             return ff_output + hidden_states
