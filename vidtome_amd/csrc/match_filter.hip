@@ -28,6 +28,11 @@
 
 namespace {
 
+// Ablation switches (never defined in the shipped build; used for the measurements quoted in DESIGN.md section 9):
+//   VTM_EXP_NOWRAP     skip the candidate collection at the end of every dst tile
+//   VTM_EXP_NOBARRIER  drop the end-of-step wait + barrier      VTM_EXP_NOAWAIT  never wait for fragment loads
+//   VTM_EXP_NODMA      do not fetch dst tiles                   VTM_EXP_HOTMEM   fetch everything from one hot tile
+// (all of them produce wrong results; they only tell where the time goes)
 constexpr int FBD = 128;      // dst rows per tile (MFMA A operand, LDS)
 constexpr int FBS = 256;      // src rows per workgroup (B operand, registers), 64 per wave
 constexpr int FBK = 64;       // channels per pipeline step = 4 MFMA k-steps = 8 panels
