@@ -78,6 +78,8 @@ class KernelTimer:
     def __enter__(self):
         # attention(q, k, vt, heads, M, scale, share): 4 * B * M^2 * C flops (QK^T + PV, all heads)
         self._wrap("attention", "attention", lambda q, k, vt, heads, M, scale, share=1: 4.0 * q.shape[0] * M * M * q.shape[2])
+        # attention_kv(q, k, vt, heads, Mq, Mk, scale): 4 * B * Mq * Mk * C executed flops
+        self._wrap("attention_kv", "attention", lambda q, k, vt, heads, Mq, Mk, scale: 4.0 * q.shape[0] * Mq * Mk * q.shape[2])
         # match_filtered(x0, x1, a_rows, b_rows, align): 2 * B * Ns * Nd * C algorithmic flops
         self._wrap("match_filtered", "matching",
                    lambda x0, x1, ar, br, align, want_flag=False: 2.0 * x0.shape[0] * ar.shape[1] * br.shape[1] * x0.shape[2])
@@ -96,14 +98,18 @@ class KernelTimer:
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel's largest configuration (top-block attention, M = 52 224),
+    """HBM bytes per launch of the dominant kernel's largest configuration (top-block attention: 34 816 live queries
+    x 52 224 keys),
     from the rocprofv3 PMC passes recorded in profiles/r01_pmc_traffic.json (FETCH_SIZE doubled per the gfx950
     note + WRITE_SIZE); None if the profile file is absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             d = json.load(f)
-        key = "attention_kernel<half,40> B=2 h=8 M=52224"
-        return int(d.get(key + " (r01_e)", d[key])["hbm_bytes_per_launch"])
+        for key in ("attention_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224 (r01_f)",
+                    "attention_kernel<half,40> B=2 h=8 M=52224 (r01_e)", "attention_kernel<half,40> B=2 h=8 M=52224"):
+            if key in d:
+                return int(d[key]["hbm_bytes_per_launch"])
+        return None
     except Exception:
         return None
 
@@ -263,8 +269,10 @@ def main():
                        "parallelism": f"chunk-parallel x{world}" + (", RCCL all-gather of the anchor tokens per merging "
                                                                      "block" if world > 1 else "")},
             # dominant single kernel of the step: the merged-token self-attention (MFMA-bound)
+            # `achieved` counts EXECUTED flops (4 B Mq Mk C per launch): with a global level the block only computes the
+            # attention rows unmerge() reads, so the reference-algorithmic 4 B M^2 C would overstate the kernel
             "roofline": {"kernel": "attention_kernel<half,d> (flash attention over merged tokens, "
-                                   "v_mfma_f32_32x32x16_f16)",
+                                   "v_mfma_f32_32x32x16_f16; executed flops)",
                          "bound": "mfma", "achieved": round(att_tf, 1), "peak": FP16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(att_tf / FP16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                          "launches": an, "avg_launch_ms": round(ams / max(an, 1), 4),

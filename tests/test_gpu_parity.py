@@ -561,6 +561,42 @@ def _site_pass_checks(unet, sites_list, hiddens, B, F, expected_M):
     return outs, plans
 
 
+@pytest.mark.parametrize("F,global_rand", [(4, 0.0), (4, 1.0), (1, 0.5), (8, 0.5)])
+def test_live_queries_equal_full_attention(L, F, global_rand):
+    """With a global level the block computes attention only for the merged rows whose output unmerge() reads
+    (MergePlan.q_rows).  The block output must equal the one obtained by attending from every merged row, as the
+    reference does (patch.py:157-169) -- for both coin outcomes (local chunk = src / dst) and single-frame chunks."""
+    import vidtome_amd
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import sites as S
+    B, latent = 2, (16, 16)
+    sl = [s for s in S.sd15_sites() if s.name in ("up3.0", "up2.0")]
+    outs = {}
+    for live in (True, False):
+        unet = S.SiteUNet(sl, seed=3).to(device=DEV, dtype=torch.float16)
+        vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B,
+                                global_rand=global_rand)
+        unet.set_size(latent)
+        torch.manual_seed(123)
+        old = vpatch.LIVE_QUERIES
+        vpatch.LIVE_QUERIES = live
+        try:
+            res = []
+            for chunk in range(3):       # chunk 0 stores anchors, chunks 1 and 2 merge against them
+                hiddens = [S.synthetic_hidden(s, B, F, latent, torch.float16, DEV, seed=90 + 7 * chunk + i)
+                           for i, s in enumerate(sl)]
+                with torch.no_grad():
+                    res.append([o.float().cpu() for o in S.run_segment_pass(unet, hiddens)])
+            outs[live] = res
+        finally:
+            vpatch.LIVE_QUERIES = old
+            vidtome_amd.remove_patch(unet)
+    for a_chunk, b_chunk in zip(outs[True], outs[False]):
+        for a, b in zip(a_chunk, b_chunk):
+            assert a.shape == b.shape and torch.isfinite(a).all()
+            assert (a - b).abs().max() <= 2e-3 * max(1.0, float(b.abs().max()))
+
+
 def test_cfg5_sd21_768_full_size(L):
     """cfg-5: SD-2.1-768, 16 frames 768x768 (latent 96x96), ratio 0.6, fp16: N = 9216 / 2304 tokens per frame,
     head dim 64, ragged merged lengths (64 513 / 16 129 local, 90 319 / 22 581 with global merging)."""

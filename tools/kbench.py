@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--shape", default="top_l1")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--M", type=int, default=52224)
+    ap.add_argument("--Mq", type=int, default=0, help="attn: number of query rows (0 = M, square self-attention)")
     ap.add_argument("--d", type=int, default=40)
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--B", type=int, default=2)
@@ -69,9 +70,15 @@ def main():
         Mp = (M + 7) // 8 * 8
         qk = torch.randn(B, Mp, 2 * C, generator=g, device=dev, dtype=torch.float16)
         vt = torch.randn(B, C, Mp, generator=g, device=dev, dtype=torch.float16)
-        med, best = timeit(lambda: _lib.attention(qk[:, :, :C], qk[:, :, C:], vt, h, M, d ** -0.5, 1), a.iters)
-        fl = 4.0 * B * M * M * C
-        print(f"attention B={B} M={M} h={h} d={d}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), "
+        if a.Mq:
+            Mq = a.Mq
+            q = torch.randn(B, (Mq + 7) // 8 * 8, C, generator=g, device=dev, dtype=torch.float16)
+            med, best = timeit(lambda: _lib.attention_kv(q, qk[:, :, C:], vt, h, Mq, M, d ** -0.5), a.iters)
+        else:
+            Mq = M
+            med, best = timeit(lambda: _lib.attention(qk[:, :, :C], qk[:, :, C:], vt, h, M, d ** -0.5, 1), a.iters)
+        fl = 4.0 * B * Mq * M * C
+        print(f"attention B={B} Mq={Mq} Mk={M} h={h} d={d}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), "
               f"best {best:.3f} ms ({fl / best / 1e9:.1f} TFLOP/s)")
     elif a.what == "sort":
         keys = torch.randint(0, 2 ** 62, (a.B, a.n), generator=g, device=dev, dtype=torch.int64)

@@ -29,6 +29,11 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, merge
+
+# Attention over the merged sequence computes outputs only for the rows unmerge() reads (see MergePlan.q_rows);
+# VIDTOME_LIVE_QUERIES=0 computes every row like the reference does (same block output, more work).
+import os as _os
+LIVE_QUERIES = _os.environ.get("VIDTOME_LIVE_QUERIES", "1") != "0"
 from .utils import init_generator, isinstance_str, join_frame, split_frame
 
 
@@ -39,7 +44,7 @@ class MergePlan:
     """What ``compute_merge`` produces for one block call: composed maps + the merged tokens."""
 
     __slots__ = ("fsize", "L", "M", "gather_map", "inv", "merged", "levels", "global_level", "local_chunk",
-                 "x_joined", "anchors_in")
+                 "x_joined", "anchors_in", "q_rows", "inv_q")
 
     def __init__(self):
         self.levels = []
@@ -48,6 +53,13 @@ class MergePlan:
         self.gather_map = None
         self.inv = None
         self.anchors_in = None
+        # Global level only: the rows of the merged sequence whose attention output unmerge() ever reads
+        # (q_rows[b, t] = merged row of local token t) and the local-levels-only inverse map.  The merged
+        # sequence also contains the other chunk's tokens; they are keys / values, but nobody reads their
+        # attention OUTPUT (merge.py:459 returns the local part only), so the block computes attention for
+        # the q_rows queries only -- a third fewer at global_merge_ratio 0.5, same block output.
+        self.q_rows = None
+        self.inv_q = None
 
 
 def _draw_coin(generator: torch.Generator) -> float:
@@ -125,6 +137,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 # patch.py:80: new anchors = u(merged) = the local tokens with every merged local src row
                 # replaced by its matched global row -> one gather from [chunk | old anchors]
                 anchors_out = _lib.gather_rows(xj, gt, _lib.compose(loc, gl.new_cur, Ml))
+                plan.q_rows, plan.inv_q = loc, inv
                 inv = _lib.compose(inv, loc, L) if inv is not None else loc
                 cur = gl.new_cur
                 n_cur = cur.shape[1]
@@ -188,6 +201,20 @@ def _pnp_num_inputs(attn: torch.nn.Module) -> Optional[int]:
     return None
 
 
+def _pnp_share_groups(attn: torch.nn.Module) -> int:
+    """1, or the number of batch groups that share the source group's attention probabilities at this timestep
+    (pnp_utils.py:57-67)."""
+    sched = getattr(attn, "injection_schedule", None)
+    if sched is not None:
+        t = getattr(attn, "t", None)
+        if t is not None and (t in sched or t == 1000):                 # pnp_utils.py:57-58
+            n = _pnp_num_inputs(attn)
+            if n is None:
+                raise RuntimeError("PnP injection is registered on attn1 but num_inputs is unknown")
+            return n
+    return 1
+
+
 def _fused_weights(attn: torch.nn.Module, dtype, device):
     """[Wq; Wk] stacked once per module (one projection GEMM for q and k), cached on the module."""
     cache = attn.__dict__.get("_vtm_wcache")
@@ -205,23 +232,19 @@ def _fused_weights(attn: torch.nn.Module, dtype, device):
     return cache[1], cache[2]
 
 
-def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = None) -> torch.Tensor:
+def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = None,
+                   q_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``attn1(x)`` for self-attention without mask (patch.py:157-162), arithmetic of pnp_utils.py:47-95:
     q,k,v projections -> softmax(q k^T * scale) v per head -> to_out[0] (+ dropout(0)).
-    x is (B, Mp, C) whose first M rows per sample are the sequence."""
+    x is (B, Mp, C) whose first M rows per sample are the sequence.  With ``q_rows`` (B, Mq) only those rows act
+    as queries (every row stays a key / value) and the result is (B, Mq rounded up to 8, C) in q_rows order."""
     B, Mp, C = x.shape
     M = Mp if M is None else M
     heads = attn.heads
     scale = getattr(attn, "scale", None) or (C // heads) ** -0.5
-    share = 1
-    sched = getattr(attn, "injection_schedule", None)
-    if sched is not None:
-        t = getattr(attn, "t", None)
-        if t is not None and (t in sched or t == 1000):                 # pnp_utils.py:57-58
-            n = _pnp_num_inputs(attn)
-            if n is None:
-                raise RuntimeError("PnP injection is registered on attn1 but num_inputs is unknown")
-            share = n
+    share = _pnp_share_groups(attn)
+    if q_rows is not None and share != 1:
+        raise RuntimeError("q_rows cannot be combined with the PnP shared-probability mode")
     if x.shape[1] % 8:
         # keep the transposed V (B, C, Mp) 16-byte aligned per row
         pad = 8 - x.shape[1] % 8
@@ -233,7 +256,13 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
         # their projections and attention in fp16 -- the matching path above stays exact fp32
         x = x.to(torch.float16)
     wqk, bqk = _fused_weights(attn, x.dtype, x.device)
-    qk = F.linear(x, wqk, bqk)                                           # (B, Mp, 2C): one GEMM for q and k
+    if q_rows is None:
+        qk = F.linear(x, wqk, bqk)                                       # (B, Mp, 2C): one GEMM for q and k
+        q_op, k_op = qk[:, :, :C], qk[:, :, C:]
+    else:
+        xq = _lib.gather_rows(x, None, q_rows, pad_to=8)                 # (B, Mqp, C) query tokens
+        q_op = F.linear(xq, wqk[:C], None if bqk is None else bqk[:C])
+        k_op = F.linear(x, wqk[C:], None if bqk is None else bqk[C:])
     wv = attn.to_v.weight.to(x.dtype)
     if B <= 4:                                                           # merged sites: few long sequences
         vt = torch.empty((B, C, Mp), dtype=x.dtype, device=x.device)     # V^T straight from the GEMM:
@@ -243,7 +272,10 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
         vt = torch.matmul(wv, x.transpose(1, 2))
     if getattr(attn.to_v, "bias", None) is not None:
         vt = vt + attn.to_v.bias.to(x.dtype)[None, :, None]
-    o = _lib.attention(qk[:, :, :C], qk[:, :, C:], vt, heads, M, scale, share)
+    if q_rows is None:
+        o = _lib.attention(q_op, k_op, vt, heads, M, scale, share)
+    else:
+        o = _lib.attention_kv(q_op, k_op, vt, heads, q_rows.shape[1], M, scale)
     to_out = attn.to_out[0] if isinstance(attn.to_out, (torch.nn.ModuleList, torch.nn.Sequential, list, tuple)) \
         else attn.to_out                                                 # pnp_utils.py:41-45
     return F.linear(o, to_out.weight.to(o.dtype), None if to_out.bias is None else to_out.bias.to(o.dtype)).to(out_dtype)
@@ -313,7 +345,19 @@ def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.
                                   encoder_hidden_states=encoder_hidden_states if block.only_cross_attention else None,
                                   attention_mask=attention_mask, **cross_attention_kwargs)
     else:
-        attn_output = self_attention(block.attn1, merged, plan.M if plan is not None else None)
+        # (PnP injection reads the source sample's q for every group: it keeps the full, aligned layout)
+        live = (plan is not None and plan.q_rows is not None and gate_msa is None and LIVE_QUERIES
+                and _pnp_share_groups(block.attn1) == 1)
+        attn_output = self_attention(block.attn1, merged, plan.M if plan is not None else None,
+                                     plan.q_rows if live else None)
+        if live:
+            # rows are the chunk's local merged tokens: unmerge with the local levels' map alone
+            # (= the global level's unmerge, merge.py:439-460, folded into the choice of queries)
+            fs = plan.fsize
+            r = join_frame(hidden_states.contiguous(), fs)
+            if plan.inv_q is None:                                        # single-frame chunk: no local level
+                return split_frame(attn_output[:, :plan.L] + r, fs)
+            return split_frame(_lib.unmerge_add(attn_output.contiguous(), plan.inv_q, r), fs)
     if gate_msa is not None:
         attn_output = gate_msa.unsqueeze(1) * attn_output
     if plan is None:
