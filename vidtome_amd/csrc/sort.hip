@@ -6,14 +6,15 @@
 //
 // Design (v4): multi-workgroup LSD radix sort, 4 passes of 8-bit digits, every global access coalesced.
 // A row is cut into contiguous segments (one 256-thread workgroup each, a few 256-key tiles per segment),
-// so that ~64 CUs work on a row instead of one.  Per pass, three small kernels:
+// so that ~64 CUs work on a row instead of one.  Per pass, two small kernels:
 //   hist     per-segment digit counts (wave-aggregated: one LDS add per distinct digit and wave) -> hist[row][seg][digit]
-//   scan     exclusive scan of hist in (digit, segment) order                                    -> offs[row][seg][digit]
-//   scatter  stable scatter: offs + earlier tiles of the segment + lower waves of the tile + rank inside
-//            the wave (popcount of the same-digit lane mask below the lane)
+//   scatter  every workgroup derives its 256 scatter offsets from the table (exclusive scan in (digit, segment)
+//            order), then scatters stably: offset + earlier tiles of the segment + lower waves of the tile + rank
+//            inside the wave (popcount of the same-digit lane mask below the lane)
 // Thread order == index order inside a tile, tiles and segments are in index order, so equal digits keep
 // their order (stability).  The kernels are launch-latency sized (rows are <= ~110k keys, L2-resident), which
-// is why the digit is 8 bits wide: 12 launches per sort instead of the 24 a 4-bit digit needs.
+// is why the digit is 8 bits wide and the scan lives inside the scatter kernel: 8 launches per sort (a 4-bit digit
+// with a separate scan kernel needs 24).
 #include "common.h"
 
 namespace {
@@ -67,42 +68,16 @@ __global__ __launch_bounds__(T) void sort_hist_kernel(const uint64_t *__restrict
     hist[((int64_t)row * g.nseg + seg) * RADIX + tid] = cnt[tid];
 }
 
-// exclusive scan over the RADIX * nseg counts of a row in (digit, segment) order; one workgroup per row
-__global__ __launch_bounds__(T) void sort_scan_kernel(const int *__restrict__ hist, int nseg, int *__restrict__ offs) {
-    __shared__ int part[T];
-    const int tid = threadIdx.x, row = blockIdx.x;
-    // thread d owns digit d: entries [seg][d], coalesced across the workgroup, independent loads kept in flight
-    const int *h = hist + (int64_t)row * nseg * RADIX + tid;
-    int *o = offs + (int64_t)row * nseg * RADIX + tid;
-    int sum = 0;
-#pragma unroll 8
-    for (int e = 0; e < nseg; ++e) sum += h[e * RADIX];
-    part[tid] = sum;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 256 digit totals
-    for (int off = 1; off < T; off <<= 1) {
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int run = part[tid] - sum;   // keys with a smaller digit
-#pragma unroll 8
-    for (int e = 0; e < nseg; ++e) {
-        o[e * RADIX] = run;
-        run += h[e * RADIX];
-    }
-}
-
 __global__ __launch_bounds__(T) void sort_scatter_kernel(const uint64_t *__restrict__ best,
                                                          const uint32_t *__restrict__ ksrc_all,
                                                          const int32_t *__restrict__ psrc_all,
                                                          uint32_t *__restrict__ kdst_all, int32_t *__restrict__ pdst_all,
-                                                         Geo g, int pass, int last, const int *__restrict__ offs) {
+                                                         Geo g, int pass, int last, const int *__restrict__ hist) {
     // wcnt[w][d] = (tile tag << 16) | keys of digit d in wave w of the tagged tile; an entry with another tag
     // counts as zero, so the table never has to be cleared
     __shared__ uint32_t wcnt[WAVES][RADIX];
-    __shared__ int running[RADIX];   // offs[digit][seg] + keys of the digit in the tiles already scattered
+    __shared__ int running[RADIX];   // scatter offset of (digit, this segment) + keys of the digit already scattered
+    __shared__ int part[RADIX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = blockIdx.x, row = blockIdx.y;
     const uint64_t *kin = best + (int64_t)row * g.n;
@@ -112,7 +87,28 @@ __global__ __launch_bounds__(T) void sort_scatter_kernel(const uint64_t *__restr
     int32_t *pdst = pdst_all + (int64_t)row * g.n;
     const int sh = pass * 8;
     const unsigned long long below = (1ull << lane) - 1ull;
-    running[tid] = offs[((int64_t)row * g.nseg + seg) * RADIX + tid];
+    // scatter offsets of this segment, straight from the histogram table (exclusive scan in (digit, segment)
+    // order): thread d owns digit d -- keys of smaller digits in all segments + keys of digit d in earlier
+    // segments.  The table is [seg][digit], so the loads are coalesced and independent.
+    {
+        const int *h = hist + (int64_t)row * g.nseg * RADIX + tid;
+        int tot = 0, bef = 0;
+#pragma unroll 8
+        for (int e = 0; e < g.nseg; ++e) {
+            const int c = h[e * RADIX];
+            tot += c;
+            bef += e < seg ? c : 0;
+        }
+        part[tid] = tot;
+        __syncthreads();
+        for (int off = 1; off < T; off <<= 1) {   // Hillis-Steele inclusive scan over the 256 digit totals
+            const int v = tid >= off ? part[tid - off] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        running[tid] = part[tid] - tot + bef;
+    }
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) wcnt[w][tid] = 0xffff0000u;   // tag no tile ever has
     __syncthreads();
@@ -173,8 +169,8 @@ inline size_t aligned(size_t v) { return (v + 255) & ~(size_t)255; }
 VTM_EXPORT size_t vtm_sort_ws_bytes(int64_t rows, int64_t n) {
     if (rows <= 0 || n <= 0) return 0;
     const Geo g = make_geo(n);
-    // key / index ping-pong buffers + hist + offs
-    return aligned((size_t)rows * n * 16u) + 2 * aligned((size_t)rows * RADIX * g.nseg * sizeof(int));
+    // key / index ping-pong buffers + the histogram table
+    return aligned((size_t)rows * n * 16u) + aligned((size_t)rows * RADIX * g.nseg * sizeof(int));
 }
 
 VTM_EXPORT int vtm_sort_desc(const uint64_t *best, int64_t rows, int64_t n, int32_t *perm, void *ws,
@@ -192,8 +188,6 @@ VTM_EXPORT int vtm_sort_desc(const uint64_t *best, int64_t rows, int64_t n, int3
     uint32_t *k0 = reinterpret_cast<uint32_t *>(w), *k1 = k0 + rows * n;
     int32_t *p0 = reinterpret_cast<int32_t *>(k1 + rows * n), *p1 = p0 + rows * n;
     int *hist = reinterpret_cast<int *>(w + aligned((size_t)rows * n * 16u));
-    int *offs = reinterpret_cast<int *>(reinterpret_cast<char *>(hist) +
-                                        aligned((size_t)rows * RADIX * g.nseg * sizeof(int)));
     const dim3 grid((unsigned)g.nseg, (unsigned)rows), block(T);
     for (int pass = 0; pass < PASSES; ++pass) {
         const uint32_t *ksrc = (pass & 1) ? k1 : k0;
@@ -203,8 +197,7 @@ VTM_EXPORT int vtm_sort_desc(const uint64_t *best, int64_t rows, int64_t n, int3
         const int last = pass == PASSES - 1;
         if (last) pdst = perm;
         hipLaunchKernelGGL(sort_hist_kernel, grid, block, 0, s, best, ksrc, g, pass, hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)rows), block, 0, s, hist, g.nseg, offs);
-        hipLaunchKernelGGL(sort_scatter_kernel, grid, block, 0, s, best, ksrc, psrc, kdst, pdst, g, pass, last, offs);
+        hipLaunchKernelGGL(sort_scatter_kernel, grid, block, 0, s, best, ksrc, psrc, kdst, pdst, g, pass, last, hist);
     }
     return vtm::launch_status("vtm_sort_desc");
 }
