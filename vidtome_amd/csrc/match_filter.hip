@@ -667,8 +667,14 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         const int tiles_per_split = (int)vtm::cdiv(nd_tiles, nsplit);
         nsplit = (int)vtm::cdiv(nd_tiles, tiles_per_split);
         const int total_src_tiles = (int)(B * ns_tiles);
-        // patch = 16 src tiles while their (hi) operands fit comfortably in one L2 (16 x 256 rows x C x 2 B <= 3 MiB)
-        const int patch_tiles = (int64_t)16 * FBS * L.C64 * 2 <= (3 << 20) ? 16 : 8;
+        // patch size: at most 16 src tiles while their (hi) operands fit comfortably in one L2 (16 x 256 rows x C x
+        // 2 B <= 3 MiB), else 8 -- and balanced: patch g runs on XCD g % 8, so the tiles are cut into equal patches
+        // whose number per XCD is the same for all XCDs (17 patches of 16 tiles would keep one XCD busy for three
+        // patches while the other seven idle after two)
+        const int max_patch = (int64_t)16 * FBS * L.C64 * 2 <= (3 << 20) ? 16 : 8;
+        const int tiles_per_xcd = (int)vtm::cdiv(total_src_tiles, 8);
+        const int patches_per_xcd = (int)vtm::cdiv(tiles_per_xcd, max_patch);
+        const int patch_tiles = (int)vtm::cdiv(tiles_per_xcd, patches_per_xcd);
         const int ngroups = (int)vtm::cdiv(total_src_tiles, patch_tiles);
         const int64_t grid = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit;
         hipLaunchKernelGGL(filter_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
