@@ -202,14 +202,22 @@ int vtm_unmerge_add(const void *y, int64_t M, const int32_t *inv, const void *re
  * ---------------------------------------------------------------------------------------------- */
 int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt,
                   int64_t ldvt, void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t M,
-                  int64_t Mp, int64_t d, float scale, int share_groups, vtm_stream_t stream);
+                  int64_t Mp, int64_t d, float scale, int share_groups, void *ws, size_t ws_bytes,
+                  vtm_stream_t stream);
+
+/* Optional workspace of vtm_attention / vtm_attention_kv (0 = none needed).  All workgroups of an attention launch
+ * take the same time; when the last round of workgroups would leave most of the chip idle, those query blocks are
+ * split along the key axis into a second launch whose partial results (fp32 accumulators, running max, denominator)
+ * live in this workspace and are merged by a third kernel.  ws may be NULL (single launch, slower for such shapes). */
+size_t vtm_attention_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64_t Mk, int64_t d);
 
 /* The same kernel with separate query / key lengths: the block's cross-attention `self.attn2(...)`
  * (vidtome/patch.py:178-183; SD: Mk = 77 text tokens per frame).  q (B, Mqp, .) / out as above; k (B, Mkp, .),
  * vt (B, h*d, ldvt >= Mk).  vtm_attention is this entry with Mk = Mq, Mkp = Mqp. */
 int vtm_attention_kv(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
                      void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
-                     int64_t Mk, int64_t Mkp, int64_t d, float scale, int share_groups, vtm_stream_t stream);
+                     int64_t Mk, int64_t Mkp, int64_t d, float scale, int share_groups, void *ws, size_t ws_bytes,
+                     vtm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * vtm_cfg_ddim -- the caller-side elementwise tail of a denoising step:

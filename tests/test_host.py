@@ -52,7 +52,7 @@ def test_error_convention(built):
     # null pointers are rejected before any launch
     assert L.vtm_match(None, None, 1, 1, 1, 128, 128, 32, 0, None, None) == -1
     assert L.vtm_sort_desc(None, 1, 1, None, None, 0, None) == -1
-    assert L.vtm_attention(None, 8, None, 8, None, 8, None, 8, 1, 1, 1, 8, 8, 40, 1.0, 1, None) == -1
+    assert L.vtm_attention(None, 8, None, 8, None, 8, None, 8, 1, 1, 1, 8, 8, 40, 1.0, 1, None, 0, None) == -1
 
 
 def test_cpu_tensors_fail_loudly(built):

@@ -48,9 +48,10 @@ _SIGNATURES = {
     "vtm_gather_rows": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _vp], _int),
     "vtm_unmerge_add": ([_vp, _i64, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp], _int),
     "vtm_attention": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _f32,
-                       _int, _vp], _int),
+                       _int, _vp, ctypes.c_size_t, _vp], _int),
+    "vtm_attention_ws_bytes": ([_i64, _i64, _i64, _i64, _i64], ctypes.c_size_t),
     "vtm_attention_kv": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
-                          _f32, _int, _vp], _int),
+                          _f32, _int, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_cfg_ddim": ([_vp, _vp, _vp, _int, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp], _int),
     "vtm_layernorm": ([_vp, _vp, _vp, _int, _i64, _i64, _f32, _vp, _vp], _int),
     "vtm_geglu": ([_vp, _int, _i64, _i64, _vp, _vp], _int),
@@ -259,6 +260,14 @@ def unmerge_add(y: torch.Tensor, inv: torch.Tensor, resid: Optional[torch.Tensor
     return out
 
 
+def _attention_ws(B: int, heads: int, Mq: int, Mk: int, d: int, device):
+    """Workspace for the split last round of an attention launch (None when the shape needs none)."""
+    nb = int(lib().vtm_attention_ws_bytes(B, heads, Mq, Mk, d))
+    if nb == 0:
+        return None, 0
+    return torch.empty(nb, dtype=torch.uint8, device=device), nb
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, M: int, scale: float,
               share_groups: int = 1) -> torch.Tensor:
     """q, k: (B, Mp, C) views with arbitrary last-dim-contiguous row stride; vt: (B, C, ldvt) = v transposed.
@@ -271,9 +280,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, M:
         raise RuntimeError("attention operands must have dense batch strides")
     out = torch.zeros((B, Mp, C), dtype=q.dtype, device=q.device) if Mp != M else \
         torch.empty((B, Mp, C), dtype=q.dtype, device=q.device)
+    ws, nb = _attention_ws(B, heads, M, M, d, q.device)
     _check(lib().vtm_attention(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(), vt.stride(1),
                                out.data_ptr(), C, dtype_code(q), B, heads, M, Mp, d, float(scale),
-                               int(share_groups), _stream()), "vtm_attention")
+                               int(share_groups), _ptr(ws), nb, _stream()), "vtm_attention")
     return out
 
 
@@ -323,9 +333,10 @@ def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
         raise RuntimeError("attention operands must have dense batch strides")
     out = torch.zeros((B, Mqp, C), dtype=q.dtype, device=q.device) if Mqp != Mq else \
         torch.empty((B, Mqp, C), dtype=q.dtype, device=q.device)
+    ws, nb = _attention_ws(B, heads, Mq, Mk, d, q.device)
     _check(lib().vtm_attention_kv(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(), vt.stride(1),
                                   out.data_ptr(), C, dtype_code(q), B, heads, Mq, Mqp, Mk, Mkp, d, float(scale), 1,
-                                  _stream()), "vtm_attention_kv")
+                                  _ptr(ws), nb, _stream()), "vtm_attention_kv")
     return out
 
 

@@ -77,13 +77,86 @@ __device__ __forceinline__ void mask_keys(uint4 &v, int valid) {
     }
 }
 
+// normalise and store one wave's O^T accumulators: row q = q0 + l31, channels dv*32 + (r & 3) + 8 (r >> 2) + 4 hi
+template <typename T, int D>
+__device__ __forceinline__ void write_output(const f32x16 (&o)[(D + 31) / 32], float l_run, T *__restrict__ out,
+                                             int64_t ldo, int64_t b, int64_t h, int64_t q0, int64_t M, int64_t Mp,
+                                             int l31, int hi) {
+    using elem = typename Frag<T>::elem;
+    constexpr int DV = (D + 31) / 32;
+    constexpr bool SPARE = (D % 32) != 0;
+    float l_tot;
+    if constexpr (SPARE) {
+        // denominator row D of O^T: block D/32, in-block row D%32 = (r&3) + 8(r>>2) + 4hi
+        constexpr int LB = D / 32, LR = D % 32;
+        constexpr int LHI = (LR >> 2) & 1, LREG = (LR & 3) + 4 * (LR >> 3);
+        l_tot = __shfl(o[LB][LREG], l31 + 32 * LHI, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
+    const float inv_l = 1.0f / l_tot;
+    const int64_t qi = q0 + l31;
+    if (qi < M) {
+        T *op = out + (b * Mp + qi) * ldo + h * D;
+#pragma unroll
+        for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dv * 32 + 8 * g + 4 * hi;
+                if (d0 < D) {  // D % 8 == 0 and d0 % 4 == 0 -> the 4 channels are all valid
+                    elem w[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (elem)(o[dv][g * 4 + e] * inv_l);
+                    *reinterpret_cast<uint2 *>(op + d0) = *reinterpret_cast<uint2 *>(w);
+                }
+            }
+    }
+}
+
+// merges the `nsplit` partial states of a query block (same thread <-> register mapping as attention_kernel)
+template <typename T, int D>
+__global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
+    const float *__restrict__ partial, T *__restrict__ out, int64_t ldo, int64_t H, int64_t M, int64_t Mp, int64_t nqb,
+    int64_t id0, int nsplit) {
+    constexpr int WAVES = waves_for(D), NT = WAVES * 64, QB = WAVES * QW, DV = (D + 31) / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int64_t lin = id0 + blockIdx.x;
+    const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
+    const int64_t q0 = (lin % nqb) * QB + wave * QW;
+    f32x16 o[DV];
+#pragma unroll
+    for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dv][r] = 0.0f;
+    float m = -INFINITY, l = 0.0f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float *pp = partial + ((int64_t)blockIdx.x * nsplit + sp) * (DV * 16 + 2) * NT + tid;
+        const float ms = pp[(DV * 16) * NT], ls = pp[(DV * 16 + 1) * NT];
+        const float mn = fmaxf(m, ms);
+        const float fa = __builtin_amdgcn_exp2f(m - mn), fb = __builtin_amdgcn_exp2f(ms - mn);   // exp2(-inf) = 0
+        m = mn;
+        l = l * fa + ls * fb;
+#pragma unroll
+        for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dv][r] = o[dv][r] * fa + pp[(dv * 16 + r) * NT] * fb;
+    }
+    write_output<T, D>(o, l, out, ldo, b, h, q0, M, Mp, l31, hi);
+}
+
 template <typename T, int D>
 __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1)) void attention_kernel(
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
-    int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch) {
+    int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t id0,
+    int nsplit, float *__restrict__ partial) {
     // M / Mp: queries per sample and their row stride; Mk / Mkp: keys per sample and the row stride of k
-    // (self-attention passes the same values; cross-attention, patch.py:178-183, has Mk = 77)
+    // (self-attention passes the same values; cross-attention, patch.py:178-183, has Mk = 77).
+    // Work decomposition: workgroup = (query block, head, sample) numbered id0 + blockIdx.x / nsplit, query blocks
+    // fastest; with nsplit > 1 a workgroup covers only the key tiles of split blockIdx.x % nsplit and leaves its
+    // unnormalised accumulators, running max and denominator in `partial` for attention_combine_kernel (used for
+    // the query blocks that do not fill a whole round of the chip, see launch()).
     using F = Frag<T>;
     using vec = typename F::vec;
     using elem = typename F::elem;
@@ -113,9 +186,11 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int64_t b = blockIdx.z, h = blockIdx.y;
+    const int64_t lin = id0 + blockIdx.x / nsplit;
+    const int split = (int)(blockIdx.x % nsplit);
+    const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t bq = b % src_batch;  // PnP injection: q/k of the source sample (pnp_utils.py:57-67)
-    const int64_t q0 = (int64_t)blockIdx.x * QB + wave * QW;
+    const int64_t q0 = (lin % nqb) * QB + wave * QW;
     const int64_t C = H * D;
 
     // one-time LDS init: K pad columns = 0 (they meet Q's zero padding; garbage could be NaN), V^T pad rows
@@ -319,63 +394,103 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     using std::true_type;
 
     const int64_t ntiles = (Mk + KV - 1) / KV, nfull = Mk / KV;
-    if (nfull > 0) issue_full(); else issue_tail(0);
+    const int64_t tps = (ntiles + nsplit - 1) / nsplit;                     // key tiles per split
+    const int64_t tb = split * tps, te = tb + tps < ntiles ? tb + tps : ntiles;
+    const int64_t fe = te < nfull ? te : nfull;                             // end of the full tiles of this range
+    ktile += tb * kstep;
+    vtile += tb * KV;
+    if (tb < fe) issue_full(); else issue_tail(tb * KV);
     write_lds(0);
     __syncthreads();
 
     // hot loop: full tiles whose successor is full too -- no bounds logic of any kind inside
-    int64_t t = 0;
-    for (; t + 1 < nfull; ++t) {
-        const int buf = (int)(t & 1);
+    int64_t t = tb;
+    int buf = 0;
+    for (; t + 1 < fe; ++t) {
         issue_full();
         tile(false_type{}, buf, t * KV);
         write_lds(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
-    if (nfull > 0) {            // last full tile; prefetches the ragged tile if there is one
-        const int buf = (int)(t & 1);
-        if (ntiles > nfull) issue_tail(nfull * KV);
+    if (t < fe) {               // last full tile; prefetches the ragged tile if it belongs to this range
+        const bool ragged_next = te > fe;
+        if (ragged_next) issue_tail(fe * KV);
         tile(false_type{}, buf, t * KV);
-        if (ntiles > nfull) write_lds(buf ^ 1);
+        if (ragged_next) write_lds(buf ^ 1);
         __syncthreads();
         ++t;
+        buf ^= 1;
     }
-    if (ntiles > nfull) tile(true_type{}, (int)(t & 1), t * KV);
+    if (t < te) tile(true_type{}, buf, t * KV);
 
-    // ---- epilogue: O / l, row q = q0 + l31, channels dv*32 + (r & 3) + 8 (r >> 2) + 4 hi
-    float l_tot;
-    if constexpr (SPARE) {
-        // denominator row D of O^T: block D/32, in-block row D%32 = (r&3) + 8(r>>2) + 4hi
-        constexpr int LB = D / 32, LR = D % 32;
-        constexpr int LHI = (LR >> 2) & 1, LREG = (LR & 3) + 4 * (LR >> 3);
-        l_tot = __shfl(o[LB][LREG], l31 + 32 * LHI, 64);
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    }
-    const float inv_l = 1.0f / l_tot;
-    const int64_t qi = q0 + l31;
-    if (qi < M) {
-        T *op = out + (b * Mp + qi) * ldo + h * D;
+    if (partial) {   // split workgroup: hand the raw state to attention_combine_kernel
+        float *pp = partial + (int64_t)blockIdx.x * (DV * 16 + 2) * NT + tid;
 #pragma unroll
         for (int dv = 0; dv < DV; ++dv)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = dv * 32 + 8 * g + 4 * hi;
-                if (d0 < D) {  // D % 8 == 0 and d0 % 4 == 0 -> the 4 channels are all valid
-                    elem w[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = (elem)(o[dv][g * 4 + e] * inv_l);
-                    *reinterpret_cast<uint2 *>(op + d0) = *reinterpret_cast<uint2 *>(w);
-                }
-            }
+            for (int r = 0; r < 16; ++r) pp[(dv * 16 + r) * NT] = o[dv][r];
+        pp[(DV * 16) * NT] = m_run;
+        pp[(DV * 16 + 1) * NT] = l_run;
+        return;
     }
+    write_output<T, D>(o, l_run, out, ldo, b, h, q0, M, Mp, l31, hi);
 }
 
+// Tail plan.  All workgroups of a launch take the same time, so the launch runs in "rounds" of as many workgroups
+// as the chip holds (slots); the last, partly filled round leaves most CUs idle for a whole workgroup time (cfg-2
+// mid blocks: 272 workgroups on 256 slots -> the launch takes two rounds for 6 % more work than one).  The
+// workgroups of that last round are therefore split along the key axis into `nsplit` shorter ones that fill the
+// chip, and merged by attention_combine_kernel.
+struct TailPlan {
+    int64_t nqb, total, full;   // query blocks per (sample, head), all workgroups, workgroups in whole rounds
+    int nsplit;                 // splits of each remaining workgroup (1 = no tail launch)
+    size_t ws_bytes;
+};
+
+inline int device_cus() {
+    static int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    return cus;
+}
+
+template <int D>
+TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk) {
+    constexpr int WAVES = waves_for(D), QB = WAVES * QW, DV = (D + 31) / 32;
+    constexpr int wg_per_cu = D <= 48 ? 2 : 1;   // resident workgroups per CU (launch bounds / LDS)
+    TailPlan p;
+    p.nqb = vtm::cdiv(Mq, QB);
+    p.total = p.nqb * h * B;
+    const int64_t slots = (int64_t)device_cus() * wg_per_cu;
+    p.full = p.total / slots * slots;
+    const int64_t rem = p.total - p.full, ntiles = vtm::cdiv(Mk, KV);
+    p.nsplit = 1;
+    p.ws_bytes = 0;
+    // worth it only behind at least one whole round, for long key axes, and when the last round is nearly empty:
+    // a workgroup that has its CU to itself already runs about twice as fast as in a full round, so a last round
+    // of a quarter of the slots costs ~half a round either way (measured: 128 of 512 -> no gain, 16 of 256 -> -18 %)
+    if (p.full > 0 && rem > 0 && rem * 8 <= slots && ntiles >= 32) {
+        int64_t ns = slots / rem;
+        if (ns > 16) ns = 16;
+        if (ns > ntiles / 8) ns = ntiles / 8;
+        if (ns >= 2) {
+            p.nsplit = (int)ns;
+            p.ws_bytes = (size_t)rem * ns * (DV * 16 + 2) * (WAVES * 64) * sizeof(float);
+        }
+    }
+    if (p.nsplit == 1) p.full = p.total;
+    return p;
+}
 
 template <typename T, int D>
 int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt, void *out,
            int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale, int share_groups,
-           hipStream_t s) {
+           void *ws, size_t ws_bytes, hipStream_t s) {
     constexpr int DK = (D + 15) / 16, DV = (D + 31) / 32;
     constexpr size_t lds = (size_t)2 * (KV * (DK * 16 + 8) + DV * 32 * VT_STRIDE) * 2;
     static bool attr_set = false;
@@ -385,28 +500,43 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
         if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_attention: LDS attribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    constexpr int WAVES = waves_for(D), QB = WAVES * QW;
-    const dim3 grid((unsigned)vtm::cdiv(M, QB), (unsigned)h, (unsigned)B);
+    constexpr int WAVES = waves_for(D);
+    TailPlan p = plan_tail<D>(B, h, M, Mk);
+    if (p.nsplit > 1 && (!ws || ws_bytes < p.ws_bytes)) {   // no workspace: plain single launch
+        p.nsplit = 1;
+        p.full = p.total;
+    }
     const float scale_log2e = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL((attention_kernel<T, D>), grid, dim3(WAVES * 64), lds, s, (const T *)q, ldq, (const T *)k,
-                       ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp, scale_log2e, B / share_groups);
+    const int64_t src_batch = B / share_groups;
+    VTM_REQUIRE(p.total < (1ll << 31) / 16, "vtm_attention: grid too large");
+    hipLaunchKernelGGL((attention_kernel<T, D>), dim3((unsigned)p.full), dim3(WAVES * 64), lds, s, (const T *)q, ldq,
+                       (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp, scale_log2e, src_batch,
+                       p.nqb, (int64_t)0, 1, (float *)nullptr);
+    if (p.nsplit > 1) {
+        const int64_t rem = p.total - p.full;
+        hipLaunchKernelGGL((attention_kernel<T, D>), dim3((unsigned)(rem * p.nsplit)), dim3(WAVES * 64), lds, s,
+                           (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
+                           scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws);
+        hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem), dim3(WAVES * 64), 0, s,
+                           (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit);
+    }
     return vtm::launch_status("vtm_attention");
 }
 
 template <typename T>
 int dispatch(int64_t d, const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
              void *out, int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale, int sg,
-             hipStream_t s) {
+             void *ws, size_t ws_bytes, hipStream_t s) {
     switch (d) {
-        case 40: return launch<T, 40>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
-        case 64: return launch<T, 64>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
-        case 80: return launch<T, 80>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
-        case 160: return launch<T, 160>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
-        case 8: return launch<T, 8>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
-        case 16: return launch<T, 16>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
-        case 32: return launch<T, 32>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
-        case 96: return launch<T, 96>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
-        case 128: return launch<T, 128>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, s);
+        case 40: return launch<T, 40>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
+        case 64: return launch<T, 64>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
+        case 80: return launch<T, 80>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
+        case 160: return launch<T, 160>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
+        case 8: return launch<T, 8>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
+        case 16: return launch<T, 16>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
+        case 32: return launch<T, 32>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
+        case 96: return launch<T, 96>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
+        case 128: return launch<T, 128>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
     }
     return vtm::fail(VTM_EINVAL, "vtm_attention: unsupported head dim %lld (have 8,16,32,40,64,80,96,128,160)",
                      (long long)d);
@@ -414,25 +544,45 @@ int dispatch(int64_t d, const void *q, int64_t ldq, const void *k, int64_t ldk, 
 
 }  // namespace
 
+VTM_EXPORT size_t vtm_attention_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64_t Mk, int64_t d) {
+    if (B <= 0 || h <= 0 || Mq <= 0 || Mk <= 0) return 0;
+    switch (d) {
+        case 40: return plan_tail<40>(B, h, Mq, Mk).ws_bytes;
+        case 64: return plan_tail<64>(B, h, Mq, Mk).ws_bytes;
+        case 80: return plan_tail<80>(B, h, Mq, Mk).ws_bytes;
+        case 160: return plan_tail<160>(B, h, Mq, Mk).ws_bytes;
+        case 8: return plan_tail<8>(B, h, Mq, Mk).ws_bytes;
+        case 16: return plan_tail<16>(B, h, Mq, Mk).ws_bytes;
+        case 32: return plan_tail<32>(B, h, Mq, Mk).ws_bytes;
+        case 96: return plan_tail<96>(B, h, Mq, Mk).ws_bytes;
+        case 128: return plan_tail<128>(B, h, Mq, Mk).ws_bytes;
+    }
+    return 0;
+}
+
 VTM_EXPORT int vtm_attention_kv(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
                                 void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp, int64_t Mk,
-                                int64_t Mkp, int64_t d, float scale, int share_groups, vtm_stream_t stream) {
+                                int64_t Mkp, int64_t d, float scale, int share_groups, void *ws, size_t ws_bytes,
+                                vtm_stream_t stream) {
     VTM_REQUIRE(q && k && vt && out, "vtm_attention: null pointer");
     VTM_REQUIRE(B > 0 && h > 0 && Mq > 0 && Mk > 0 && d > 0 && Mqp >= Mq && Mkp >= Mk, "vtm_attention: bad sizes");
     VTM_REQUIRE(share_groups >= 1 && B % share_groups == 0, "vtm_attention: B %% share_groups != 0");
     VTM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Mk,
                 "vtm_attention: leading dimensions must keep 16-byte alignment (ldvt >= Mk, %% 8)");
-    VTM_REQUIRE(h <= 65535 && B <= 65535, "vtm_attention: grid too large");
     hipStream_t s = vtm::as_stream(stream);
     if (dtype == VTM_F16)
-        return dispatch<__half>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, s);
+        return dispatch<__half>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws,
+                                ws_bytes, s);
     if (dtype == VTM_BF16)
-        return dispatch<vtm_bf16>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, s);
+        return dispatch<vtm_bf16>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws,
+                                  ws_bytes, s);
     return vtm::fail(VTM_EINVAL, "vtm_attention: dtype must be VTM_F16 or VTM_BF16");
 }
 
 VTM_EXPORT int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt,
                              int64_t ldvt, void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t M,
-                             int64_t Mp, int64_t d, float scale, int share_groups, vtm_stream_t stream) {
-    return vtm_attention_kv(q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, M, Mp, M, Mp, d, scale, share_groups, stream);
+                             int64_t Mp, int64_t d, float scale, int share_groups, void *ws, size_t ws_bytes,
+                             vtm_stream_t stream) {
+    return vtm_attention_kv(q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, M, Mp, M, Mp, d, scale, share_groups, ws,
+                            ws_bytes, stream);
 }
