@@ -100,15 +100,29 @@ __device__ __forceinline__ float from_orderable(uint32_t o) {   // 0 (never writ
 }
 
 // ---- operand writer: hi / lo fp16 panels [b][g = k/8][row][8], one thread per (g, row), rows fastest ----
+struct SplitArgs {   // one operand: gathered rows, their norms, the panel outputs
+    const int32_t *rows;
+    int64_t n;
+    const float *norms;
+    uint4 *out_hi, *out_lo;
+    int64_t n_pad;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void split_operand(const T *__restrict__ x0, int64_t P0,
                                                      const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
-                                                     const int32_t *__restrict__ rows, int64_t n,
-                                                     const float *__restrict__ norms, uint4 *__restrict__ out_hi,
-                                                     uint4 *__restrict__ out_lo, int64_t n_pad, int64_t C_pad,
+                                                     SplitArgs A0, SplitArgs A1, int64_t C_pad,
                                                      int *__restrict__ flags) {
+    // one launch writes both operands of a match: threads beyond the first operand's range take the second
     const int64_t G = C_pad / 8;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool second = idx >= B * A0.n_pad * G;
+    if (second) idx -= B * A0.n_pad * G;
+    const SplitArgs &A = second ? A1 : A0;
+    const int32_t *__restrict__ rows = A.rows;
+    const float *__restrict__ norms = A.norms;
+    uint4 *__restrict__ out_hi = A.out_hi, *__restrict__ out_lo = A.out_lo;
+    const int64_t n = A.n, n_pad = A.n_pad;
     if (idx >= B * n_pad * G) return;
     const int64_t i = idx % n_pad;
     const int64_t bg = idx / n_pad;
@@ -631,29 +645,28 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     if (e == hipSuccess) e = hipMemsetAsync(best, 0, (size_t)rows_out * 8, s);
     if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: memset: %s", hipGetErrorString(e));
 
-    if (int rc = vtm::launch_row_norms(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, s)) return rc;
-    if (int rc = vtm::launch_row_norms(x0, P0, x1, P1, dtype, B, C, b_rows, Nd, nb, s)) return rc;
+    if (int rc = vtm::launch_row_norms(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, s, b_rows, Nd, nb)) return rc;
 
-    auto split = [&](const int32_t *rows, int64_t n, const float *norms, uint4 *oh, uint4 *ol, int64_t n_pad) {
-        const int64_t total = B * n_pad * (L.C64 / 8);
+    VTM_REQUIRE(dtype == VTM_F32 || dtype == VTM_F16 || dtype == VTM_BF16, "vtm_match_filtered: bad dtype");
+    {
+        const SplitArgs A0{a_rows, Ns, na, ah, SRC_LO ? al : nullptr, L.Ns_pad};
+        const SplitArgs A1{b_rows, Nd, nb, bh, DST_LO ? bl : nullptr, L.Nd_pad};
+        const int64_t total = B * (L.Ns_pad + L.Nd_pad) * (L.C64 / 8);
         const dim3 grid((unsigned)vtm::cdiv(total, 256)), block(256);
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(split_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, rows, n, norms, oh, ol, n_pad, L.C64, flags);
+                                   B, C, A0, A1, L.C64, flags);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(split_operand<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, rows, n, norms, oh, ol, n_pad, L.C64, flags);
+                                   P1, B, C, A0, A1, L.C64, flags);
                 break;
             default:
                 hipLaunchKernelGGL(split_operand<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, rows, n, norms, oh, ol, n_pad, L.C64, flags);
+                                   (const vtm_bf16 *)x1, P1, B, C, A0, A1, L.C64, flags);
         }
-    };
-    VTM_REQUIRE(dtype == VTM_F32 || dtype == VTM_F16 || dtype == VTM_BF16, "vtm_match_filtered: bad dtype");
-    split(a_rows, Ns, na, ah, SRC_LO ? al : nullptr, L.Ns_pad);
-    split(b_rows, Nd, nb, bh, DST_LO ? bl : nullptr, L.Nd_pad);
+    }
 
     {
         const int ns_tiles = (int)(L.Ns_pad / FBS), nd_tiles = (int)(L.Nd_pad / FBD);

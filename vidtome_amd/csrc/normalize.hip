@@ -27,9 +27,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void row_norms(const T *__restrict__ x0, int64_t P0,
                                                  const T *__restrict__ x1, int64_t P1, int64_t B,
                                                  int64_t C, const int32_t *__restrict__ rows,
-                                                 int64_t n, float *__restrict__ norms) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * n) return;
+                                                 int64_t n, float *__restrict__ norms,
+                                                 const int32_t *__restrict__ rows2, int64_t n2,
+                                                 float *__restrict__ norms2) {
+    // one launch may serve two row lists (the src and the dst rows of a match): threads >= B*n take the second
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n) {
+        idx -= B * n;
+        rows = rows2;
+        n = n2;
+        norms = norms2;
+        if (idx >= B * n) return;
+    }
     const int64_t b = idx / n;
     const T *src = pool_row(x0, P0, x1, P1, b, rows[idx], C);
     constexpr int N = Vec16<T>::N;
@@ -96,7 +105,7 @@ int run(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, int64
     if (B * n > 0) {
         const int64_t blocks = vtm::cdiv(B * n, 256);
         hipLaunchKernelGGL(row_norms<T>, dim3((unsigned)blocks), dim3(256), 0, s, (const T *)x0, P0,
-                           (const T *)x1, P1, B, C, rows, n, norms);
+                           (const T *)x1, P1, B, C, rows, n, norms, (const int32_t *)nullptr, (int64_t)0, (float *)nullptr);
     }
     const int64_t total = B * n_pad * (C_pad / 8);
     if (total > 0) {
@@ -112,21 +121,22 @@ int run(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, int64
 namespace vtm {
 // shared with match_filter.hip: the canonical row norms of gathered pool rows (same kernel, same bits)
 int launch_row_norms(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B, int64_t C,
-                     const int32_t *rows, int64_t n, float *norms, hipStream_t s) {
-    if (B * n <= 0) return VTM_OK;
-    const dim3 grid((unsigned)cdiv(B * n, 256)), block(256);
+                     const int32_t *rows, int64_t n, float *norms, hipStream_t s, const int32_t *rows2, int64_t n2,
+                     float *norms2) {
+    if (B * (n + n2) <= 0) return VTM_OK;
+    const dim3 grid((unsigned)cdiv(B * (n + n2), 256)), block(256);
     switch (dtype) {
         case VTM_F32:
             hipLaunchKernelGGL(row_norms<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1, B,
-                               C, rows, n, norms);
+                               C, rows, n, norms, rows2, n2, norms2);
             break;
         case VTM_F16:
             hipLaunchKernelGGL(row_norms<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1, P1,
-                               B, C, rows, n, norms);
+                               B, C, rows, n, norms, rows2, n2, norms2);
             break;
         case VTM_BF16:
             hipLaunchKernelGGL(row_norms<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0, (const vtm_bf16 *)x1,
-                               P1, B, C, rows, n, norms);
+                               P1, B, C, rows, n, norms, rows2, n2, norms2);
             break;
         default: return fail(VTM_EINVAL, "unsupported dtype %d", dtype);
     }
