@@ -286,7 +286,7 @@ def main():
                          "frac_of_fp32_peak": round(mat_tf / FP32_PEAK_TFLOPS, 3), "calls": mn,
                          "matching_ms_per_step": round(mms / args.steps, 3)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
