@@ -37,7 +37,7 @@ typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 constexpr int waves_for(int D) { return D <= 48 ? 8 : D <= 96 ? 16 : 4; }
 constexpr int QW = 32;           // queries per wave
 constexpr int KV = 64;           // keys per tile
-constexpr int VT_STRIDE = KV + 4;  // 68 elements = 34 words: conflict-free ds_read_b64 over 32 rows
+constexpr int VT_STRIDE = KV + 8;  // 72 elements = 144 B: 16-byte aligned rows, conflict-free ds_read_b128 over 32 rows
 constexpr float DEFER_THR = 8.0f;  // log2 units
 
 template <typename T> struct Frag;
@@ -245,7 +245,9 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
         vok[i] = c < V_CHUNKS;
         vkey[i] = (c % (KV / 8)) * 8;
         vgo[i] = vok[i] ? (c / (KV / 8)) * (int)ldvt + vkey[i] : 0;
-        voff[i] = (c / (KV / 8)) * VT_STRIDE + vkey[i];
+        // inside every 16-key group the tile is stored as [k0-3 | k8-11 | k4-7 | k12-15]: the 8 keys one lane
+        // feeds to a PV k-step (4 hi + {0..3} and 8 + 4 hi + {0..3}) are then one contiguous 16-byte read
+        voff[i] = (c / (KV / 8)) * VT_STRIDE + (vkey[i] & ~15) + ((vkey[i] >> 3) & 1) * 4;
     }
     const T *ktile = k + bq * Mkp * ldk + h * D;          // uniform
     const T *vtile = vt + (b * C + h * D) * ldvt;        // uniform
@@ -287,10 +289,10 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             if (kok[i]) *reinterpret_cast<uint4 *>(dk + koff[i]) = rk[i];
 #pragma unroll
         for (int i = 0; i < V_PER_T; ++i)
-            if (vok[i]) {   // rows are only 8-byte aligned (stride 136 B): two 8-byte stores
+            if (vok[i]) {   // keys 0-3 and 4-7 of the chunk go to the two halves of the 16-key group
                 uint2 *dst = reinterpret_cast<uint2 *>(dv + voff[i]);
                 dst[0] = make_uint2(rv[i].x, rv[i].y);
-                dst[1] = make_uint2(rv[i].z, rv[i].w);
+                dst[2] = make_uint2(rv[i].z, rv[i].w);
             }
     };
 
@@ -380,14 +382,10 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
         // ---- O^T += V^T P^T : 4 steps of 16 keys; k-slot (hi, e) <-> key 16 st + 8 (e >> 2) + 4 hi + (e & 3)
 #pragma unroll
         for (int dv = 0; dv < DV; ++dv) {
-            const elem *vp = sV + buf * SV_TILE + (dv * 32 + l31) * VT_STRIDE + 4 * hi;
+            const elem *vp = sV + buf * SV_TILE + (dv * 32 + l31) * VT_STRIDE + 8 * hi;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const uint2 lo = *reinterpret_cast<const uint2 *>(vp + st * 16);
-                const uint2 up = *reinterpret_cast<const uint2 *>(vp + st * 16 + 8);
-                uint4 vv = make_uint4(lo.x, lo.y, up.x, up.y);
-                o[dv] = F::mfma(*reinterpret_cast<vec *>(&vv), pf[st], o[dv]);
-            }
+            for (int st = 0; st < 4; ++st)
+                o[dv] = F::mfma(*reinterpret_cast<const vec *>(vp + st * 16), pf[st], o[dv]);
         }
     };
     using std::false_type;
