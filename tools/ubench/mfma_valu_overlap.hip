@@ -43,6 +43,52 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// same stream with v_mfma_f32_16x16x32_f16 (4 passes, 16 cycles): TWO of them per slot = the flops of one 32x32x16
+template <int FILL>
+__global__ __launch_bounds__(256) void k16(float *out, int iters, float seed) {
+    f32x4 c[8];
+    for (int j = 0; j < 8; ++j) for (int i = 0; i < 4; ++i) c[j][i] = seed;
+    h16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(seed + i); b[i] = (_Float16)(seed - i); }
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = seed + threadIdx.x * 1e-3f + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c[(2 * u) & 7]) : "v"(a), "v"(b));
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c[(2 * u + 1) & 7]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int f = 0; f < FILL; ++f) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[f & 7]) : "v"(v[(f + 1) & 7]));
+        }
+    }
+    float s = 0;
+    for (int j = 0; j < 8; ++j) for (int i = 0; i < 4; ++i) s += c[j][i];
+    for (int i = 0; i < 8; ++i) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int FILL>
+void run16(int waves_per_simd) {
+    const int cus = 256, iters = 1000;
+    float *out;
+    hipMalloc(&out, sizeof(float) * cus * 8 * 256);
+    dim3 grid(cus * waves_per_simd), block(256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k16<FILL>), grid, block, 0, 0, out, 10, 1.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k16<FILL>), grid, block, 0, 0, out, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("2 x mfma 16x16x32 + fma        fill %2d  waves/SIMD %d: %.3f ms -> %.2f ns per slot per SIMD\n", FILL, waves_per_simd, ms,
+           ms * 1e6 / ((double)iters * 16 * waves_per_simd));
+    hipFree(out);
+}
+
 template <int FILL, int KIND, bool ACC = false>
 void run(const char *name, int waves_per_simd) {
     const int cus = 256, iters = 1000;
@@ -84,6 +130,7 @@ int main() {
         run<12, 0, true>("AGPR mfma + fma", w);
         run<16, 0, true>("AGPR mfma + fma", w);
         run<4, 1, true>("AGPR mfma + exp", w);
+        run16<0>(w); run16<4>(w); run16<6>(w); run16<8>(w); run16<12>(w);
     }
     return 0;
 }
