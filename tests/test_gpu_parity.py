@@ -493,6 +493,31 @@ def test_cross_attention_and_ff_vs_torch_fp32(L, B, N, Mk, C, heads):
         assert (z - r).abs().max() < 4e-3 * max(1.0, float(r.abs().max()))
 
 
+def test_attention_split_last_round_equals_single_launch(L):
+    """A launch whose last round of workgroups is nearly empty runs those query blocks as key-split workgroups plus
+    a combine kernel (attention.hip, plan_tail).  Shape of the cfg-2 mid blocks: 272 workgroups on a 256-CU chip."""
+    B, h, d, Mq, Mk = 2, 8, 80, 8704, 4160          # 65 key tiles, the last one full; 17 x 16 = 272 workgroups
+    C = h * d
+    assert L.lib().vtm_attention_ws_bytes(B, h, Mq, Mk, d) > 0, "this shape is expected to take the split path"
+    g = torch.Generator(device=DEV).manual_seed(3)
+    q = torch.randn(B, Mq, C, generator=g, device=DEV, dtype=torch.float16)
+    k = torch.randn(B, Mk, C, generator=g, device=DEV, dtype=torch.float16)
+    vt = torch.randn(B, C, Mk, generator=g, device=DEV, dtype=torch.float16)
+    a = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5)
+    b = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5, use_workspace=False)
+    assert torch.isfinite(a).all()
+    assert (a.float() - b.float()).abs().max() <= 1e-3
+    # ragged key count (last tile partly masked) through the split path
+    Mk2, Mkp2 = Mk - 37, (Mk - 37 + 7) // 8 * 8
+    k2 = torch.zeros(B, Mkp2, C, device=DEV, dtype=torch.float16)
+    k2[:, :Mk2] = k[:, :Mk2]
+    vt2 = torch.zeros(B, C, Mkp2, device=DEV, dtype=torch.float16)
+    vt2[:, :, :Mk2] = vt[:, :, :Mk2]
+    a2 = L.attention_kv(q, k2, vt2, h, Mq, Mk2, d ** -0.5)
+    b2 = L.attention_kv(q, k2, vt2, h, Mq, Mk2, d ** -0.5, use_workspace=False)
+    assert (a2.float() - b2.float()).abs().max() <= 1e-3
+
+
 @pytest.mark.parametrize("d", [40, 64])
 @pytest.mark.parametrize("case", ["spike_late", "spike_every_tile", "all_very_negative", "wide_range"])
 def test_attention_rescale_paths(L, oracle, d, case):

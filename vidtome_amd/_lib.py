@@ -320,8 +320,8 @@ def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[to
     return out
 
 
-def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, Mq: int, Mk: int, scale: float
-                 ) -> torch.Tensor:
+def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, Mq: int, Mk: int, scale: float,
+                 use_workspace: bool = True) -> torch.Tensor:
     """Cross-attention core (patch.py:178-183): q (B, Mqp, C), k (B, Mkp, C) views contiguous along the last axis,
     vt (B, C, ldvt >= Mk) = v transposed.  Returns (B, Mqp, C)."""
     B, Mqp, C = q.shape
@@ -333,7 +333,7 @@ def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
         raise RuntimeError("attention operands must have dense batch strides")
     out = torch.zeros((B, Mqp, C), dtype=q.dtype, device=q.device) if Mqp != Mq else \
         torch.empty((B, Mqp, C), dtype=q.dtype, device=q.device)
-    ws, nb = _attention_ws(B, heads, Mq, Mk, d, q.device)
+    ws, nb = _attention_ws(B, heads, Mq, Mk, d, q.device) if use_workspace else (None, 0)
     _check(lib().vtm_attention_kv(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(), vt.stride(1),
                                   out.data_ptr(), C, dtype_code(q), B, heads, Mq, Mqp, Mk, Mkp, d, float(scale), 1,
                                   _ptr(ws), nb, _stream()), "vtm_attention_kv")
