@@ -96,6 +96,16 @@ class KernelTimer:
         ms = sum(r[1].elapsed_time(r[2]) for r in rec)
         return flops, ms, len(rec)
 
+    def largest(self, kind):
+        """(flops, average ms, count) of the launches with the most work -- the top-block launches, whose average
+        duration is what the rocprofv3 summary under profiles/ lists for the same kernel instantiation."""
+        rec = self.records[kind]
+        if not rec:
+            return 0.0, 0.0, 0
+        top = max(r[0] for r in rec)
+        sel = [r for r in rec if r[0] == top]
+        return top, sum(r[1].elapsed_time(r[2]) for r in sel) / len(sel), len(sel)
+
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel's largest configuration (top-block attention: 34 816 live queries
@@ -247,6 +257,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     aflops, ams, an = mt.summary("attention")
+    top_flops, top_ms, top_n = mt.largest("attention")
     mflops, mms, mn = mt.summary("matching")
 
     if rank == 0:
@@ -276,6 +287,9 @@ def main():
                          "bound": "mfma", "achieved": round(att_tf, 1), "peak": FP16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(att_tf / FP16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                          "launches": an, "avg_launch_ms": round(ams / max(an, 1), 4),
+                         # the top-block launches alone (compare with attention_kernel<half,40> in profiles/*_kernel_stats.txt)
+                         "top_block": {"launches": top_n, "avg_ms": round(top_ms, 4),
+                                       "tflops": round(top_flops / (top_ms * 1e-3) / 1e12, 1) if top_ms > 0 else 0.0},
                          "attention_ms_per_step": round(ams / args.steps, 3)},
             # the fused similarity + top-1 step (second largest): algorithmic fp32 FLOPs of the reference's
             # `a @ b.T` + max over HIP-event time; the filtered matcher produces the fp32-exact result with
