@@ -18,7 +18,7 @@
 // rounded with an absolute error <= 3e-11, far inside EPS even summed over 1280 channels).
 //
 // Escapes (all exact, no host round trip): a row whose candidate list overflows CAP (massively duplicated
-// dst rows) is recomputed exactly by exact_rows_kernel (all Nd chains of that row); any non-finite xhat
+// dst rows) is recomputed exactly by the exact-row pass at the end of refine_kernel (all Nd chains of that row); any non-finite xhat
 // component (zero token -> 0/0, merge.py:84 has no eps) raises a device flag that turns a *gated* launch of
 // the ordinary fp32 kernel (match.hip) from a no-op into a full recomputation of the call.
 #include "common.h"
@@ -112,10 +112,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void split_operand(const T *__restrict__ x0, int64_t P0,
                                                      const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
                                                      SplitArgs A0, SplitArgs A1, int64_t C_pad,
-                                                     int *__restrict__ flags) {
+                                                     int *__restrict__ flags,
+                                                     unsigned long long *__restrict__ best, int64_t nbest) {
     // one launch writes both operands of a match: threads beyond the first operand's range take the second
     const int64_t G = C_pad / 8;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nbest) best[idx] = 0ull;   // the packed results start from "nothing found" (saves a memset launch)
     const bool second = idx >= B * A0.n_pad * G;
     if (second) idx -= B * A0.n_pad * G;
     const SplitArgs &A = second ? A1 : A0;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const 
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows_out) return;
     const int n = cnt[row];
-    if (n > CAP) {   // candidate list overflowed: the row is recomputed exactly by exact_rows_kernel
+    if (n > CAP) {   // candidate list overflowed: the row is recomputed exactly by refine_kernel's row pass
         ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
         return;
     }
@@ -508,8 +510,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
                                                      const int32_t *__restrict__ b_rows, int64_t Nd,
                                                      const float *__restrict__ na, const float *__restrict__ nb,
                                                      int align, const int *__restrict__ flags,
-                                                     const uint2 *__restrict__ pairs,
+                                                     const uint2 *__restrict__ pairs, const int *__restrict__ ovf_rows,
                                                      unsigned long long *__restrict__ best) {
+    extern __shared__ float sa[];   // exact-row pass: the normalised src row (C floats)
     const int npairs = flags[3];
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (int64_t)gridDim.x * blockDim.x) {
         const uint2 pr = pairs[p];
@@ -531,19 +534,10 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
         }
         atomicMax(&best[row], ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col));
     }
-}
 
-// ---- exact pass for the (rare) rows whose candidate list overflowed: all Nd canonical chains of the row ----
-template <typename T>
-__global__ __launch_bounds__(256) void exact_rows_kernel(const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1,
-                                                         int64_t P1, int64_t B, int64_t C,
-                                                         const int32_t *__restrict__ a_rows, int64_t Ns,
-                                                         const int32_t *__restrict__ b_rows, int64_t Nd,
-                                                         const float *__restrict__ na, const float *__restrict__ nb,
-                                                         int align, const int *__restrict__ flags,
-                                                         const int *__restrict__ ovf_rows,
-                                                         unsigned long long *__restrict__ best) {
-    extern __shared__ float sa[];   // the normalised src row (C floats)
+    // ---- exact pass for the (rare) rows whose candidate list overflowed: all Nd canonical chains of the row,
+    // one workgroup per row (same launch: the list is almost always empty and a launch of its own costs more
+    // than the check)
     const int nrows = flags[2];
     for (int it = blockIdx.x; it < nrows; it += gridDim.x) {
         const int64_t row = ovf_rows[it];
@@ -641,8 +635,8 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     float *aop = (float *)(w + L.aop), *bop = (float *)(w + L.bop);
     const int64_t rows_out = align ? Ns : B * Ns;
 
-    hipError_t e = hipMemsetAsync(w + L.amax, 0, (L.cand - L.amax), s);   // amax, cnt, flags
-    if (e == hipSuccess) e = hipMemsetAsync(best, 0, (size_t)rows_out * 8, s);
+    // amax, cnt and flags start from zero; `best` is zeroed by split_operand
+    hipError_t e = hipMemsetAsync(w + L.amax, 0, (L.cand - L.amax), s);
     if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: memset: %s", hipGetErrorString(e));
 
     if (int rc = vtm::launch_row_norms(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, s, b_rows, Nd, nb)) return rc;
@@ -651,20 +645,21 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     {
         const SplitArgs A0{a_rows, Ns, na, ah, SRC_LO ? al : nullptr, L.Ns_pad};
         const SplitArgs A1{b_rows, Nd, nb, bh, DST_LO ? bl : nullptr, L.Nd_pad};
-        const int64_t total = B * (L.Ns_pad + L.Nd_pad) * (L.C64 / 8);
+        const int64_t total = B * (L.Ns_pad + L.Nd_pad) * (L.C64 / 8);   // >= rows_out by construction
+        unsigned long long *bp0 = reinterpret_cast<unsigned long long *>(best);
         const dim3 grid((unsigned)vtm::cdiv(total, 256)), block(256);
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(split_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, A0, A1, L.C64, flags);
+                                   B, C, A0, A1, L.C64, flags, bp0, rows_out);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(split_operand<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, A0, A1, L.C64, flags);
+                                   P1, B, C, A0, A1, L.C64, flags, bp0, rows_out);
                 break;
             default:
                 hipLaunchKernelGGL(split_operand<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, A0, A1, L.C64, flags);
+                                   (const vtm_bf16 *)x1, P1, B, C, A0, A1, L.C64, flags, bp0, rows_out);
         }
     }
 
@@ -700,45 +695,26 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         // one thread per surviving pair; the count lives on the device, so a fixed grid strides over the list
         const dim3 grid((unsigned)std::min<int64_t>(vtm::cdiv(rows_out * 2, 256), 4096)), block(256);
         unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
-        switch (dtype) {
-            case VTM_F32:
-                hipLaunchKernelGGL(refine_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
-                break;
-            case VTM_F16:
-                hipLaunchKernelGGL(refine_kernel<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
-                break;
-            default:
-                hipLaunchKernelGGL(refine_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
-        }
-    }
-    {   // persistent-style grid over the overflow list (usually empty: the blocks exit at once)
-        const dim3 grid(512), block(256);
-        unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
         const size_t lds = (size_t)C * sizeof(float);
         switch (dtype) {
             case VTM_F32:
-                hipLaunchKernelGGL(exact_rows_kernel<float>, grid, block, lds, s, (const float *)x0, P0, (const float *)x1,
-                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_rows, bp);
+                hipLaunchKernelGGL(refine_kernel<float>, grid, block, lds, s, (const float *)x0, P0, (const float *)x1, P1,
+                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp);
                 break;
             case VTM_F16:
-                hipLaunchKernelGGL(exact_rows_kernel<__half>, grid, block, lds, s, (const __half *)x0, P0,
-                                   (const __half *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_rows, bp);
+                hipLaunchKernelGGL(refine_kernel<__half>, grid, block, lds, s, (const __half *)x0, P0, (const __half *)x1,
+                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp);
                 break;
             default:
-                hipLaunchKernelGGL(exact_rows_kernel<vtm_bf16>, grid, block, lds, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_rows,
-                                   bp);
+                hipLaunchKernelGGL(refine_kernel<vtm_bf16>, grid, block, lds, s, (const vtm_bf16 *)x0, P0,
+                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp);
         }
     }
     if (int rc = vtm::launch_status("vtm_match_filtered")) return rc;
 
     // gated exact fallback (no-ops unless flags[0] != 0)
-    if (int rc = vtm::launch_write_operand(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, aop, L.Ns_pad, L.C32, flags, s))
-        return rc;
-    if (int rc = vtm::launch_write_operand(x0, P0, x1, P1, dtype, B, C, b_rows, Nd, nb, bop, L.Nd_pad, L.C32, flags, s))
+    if (int rc = vtm::launch_write_operand(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, aop, L.Ns_pad, L.C32, flags, s,
+                                           b_rows, Nd, nb, bop, L.Nd_pad))
         return rc;
     if (int rc = vtm::launch_match(aop, bop, B, Ns, Nd, L.Ns_pad, L.Nd_pad, L.C32, align, best, flags, false, s))
         return rc;

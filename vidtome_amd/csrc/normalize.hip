@@ -62,13 +62,25 @@ __global__ __launch_bounds__(256) void write_operand(const T *__restrict__ x0, i
                                                      int64_t C, const int32_t *__restrict__ rows,
                                                      int64_t n, const float *__restrict__ norms,
                                                      float *__restrict__ out, int64_t n_pad,
-                                                     int64_t C_pad, const int *__restrict__ gate) {
+                                                     int64_t C_pad, const int *__restrict__ gate,
+                                                     const int32_t *__restrict__ rows2, int64_t n2,
+                                                     const float *__restrict__ norms2, float *__restrict__ out2,
+                                                     int64_t n_pad2) {
     if (gate && *gate == 0) return;   // exact-fallback operands are only materialised when flagged
     // one thread per (8-channel group g, row i), rows fastest -> the two 16-byte panel stores of a wave are
     // contiguous 1 KiB segments.  Panel layout: out[b][g][kh][i][e] = xhat[b, i, 8g + 2e + kh].
+    // A launch may write two operands (threads beyond the first one's range take the second).
     const int64_t G = C_pad / 8;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * n_pad * G) return;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n_pad * G) {
+        idx -= B * n_pad * G;
+        rows = rows2;
+        n = n2;
+        norms = norms2;
+        out = out2;
+        n_pad = n_pad2;
+        if (idx >= B * n_pad * G) return;
+    }
     const int64_t i = idx % n_pad;
     const int64_t bg = idx / n_pad;  // b * G + g
     const int64_t g = bg % G, b = bg / G;
@@ -111,7 +123,8 @@ int run(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, int64
     if (total > 0) {
         hipLaunchKernelGGL(write_operand<T>, dim3((unsigned)vtm::cdiv(total, 256)), dim3(256), 0, s,
                            (const T *)x0, P0, (const T *)x1, P1, B, C, rows, n, norms, out, n_pad,
-                           C_pad, (const int *)nullptr);
+                           C_pad, (const int *)nullptr, (const int32_t *)nullptr, (int64_t)0, (const float *)nullptr,
+                           (float *)nullptr, (int64_t)0);
     }
     return vtm::launch_status("vtm_normalize_gather");
 }
@@ -144,22 +157,23 @@ int launch_row_norms(const void *x0, int64_t P0, const void *x1, int64_t P1, int
 }
 int launch_write_operand(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
                          int64_t C, const int32_t *rows, int64_t n, const float *norms, float *out,
-                         int64_t n_pad, int64_t C_pad, const int *gate, hipStream_t s) {
-    const int64_t total = B * n_pad * (C_pad / 8);
+                         int64_t n_pad, int64_t C_pad, const int *gate, hipStream_t s, const int32_t *rows2,
+                         int64_t n2, const float *norms2, float *out2, int64_t n_pad2) {
+    const int64_t total = B * (n_pad + n_pad2) * (C_pad / 8);
     if (total <= 0) return VTM_OK;
     const dim3 grid((unsigned)cdiv(total, 256)), block(256);
     switch (dtype) {
         case VTM_F32:
             hipLaunchKernelGGL(write_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                               B, C, rows, n, norms, out, n_pad, C_pad, gate);
+                               B, C, rows, n, norms, out, n_pad, C_pad, gate, rows2, n2, norms2, out2, n_pad2);
             break;
         case VTM_F16:
             hipLaunchKernelGGL(write_operand<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                               P1, B, C, rows, n, norms, out, n_pad, C_pad, gate);
+                               P1, B, C, rows, n, norms, out, n_pad, C_pad, gate, rows2, n2, norms2, out2, n_pad2);
             break;
         case VTM_BF16:
             hipLaunchKernelGGL(write_operand<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
-                               (const vtm_bf16 *)x1, P1, B, C, rows, n, norms, out, n_pad, C_pad, gate);
+                               (const vtm_bf16 *)x1, P1, B, C, rows, n, norms, out, n_pad, C_pad, gate, rows2, n2, norms2, out2, n_pad2);
             break;
         default: return fail(VTM_EINVAL, "unsupported dtype %d", dtype);
     }
