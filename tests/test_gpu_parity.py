@@ -124,6 +124,17 @@ def test_match_filtered_equals_exact(L, dtype, align):
         _filtered_vs_exact(L, x, Ns, Nd, align, expect_flag=0)
 
 
+def test_match_filtered_fuzz(L):
+    """Random shapes / dtypes / data regimes (tools/fuzz_match.py; 1 800 cases were run while developing)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_match", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_match.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(80, seed=3, verbose=False) == 0
+
+
 def test_match_filtered_hard_cases(L):
     g = torch.Generator().manual_seed(12)
     B, Ns, Nd, C = 2, 600, 900, 320

@@ -14,16 +14,13 @@ import torch  # noqa: E402
 from vidtome_amd import _lib as L  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=300)
-    ap.add_argument("--seed", type=int, default=0)
-    a = ap.parse_args()
-    g = torch.Generator().manual_seed(a.seed)
+def run(cases: int, seed: int, verbose: bool = True) -> int:
+    """Returns the number of mismatching cases."""
+    g = torch.Generator().manual_seed(seed)
     dev = "cuda"
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
     fails = 0
-    for case in range(a.cases):
+    for case in range(cases):
         B = ri(1, 3)
         C = [8, 24, 64, 160, 320, 640, 1280][ri(0, 6)]
         big = ri(0, 9) == 0
@@ -56,8 +53,17 @@ def main():
             fails += 1
             print("MISMATCH", dict(case=case, B=B, C=C, Ns=Ns, Nd=Nd, dtype=str(dtype), align=align, regime=regime,
                                    flags=flag.tolist(), bad=int((got != exact).sum())))
-    print(f"{a.cases} cases, {fails} mismatches")
-    return 1 if fails else 0
+    if verbose:
+        print(f"{cases} cases, {fails} mismatches")
+    return fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    return 1 if run(a.cases, a.seed) else 0
 
 
 if __name__ == "__main__":
