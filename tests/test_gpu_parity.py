@@ -504,6 +504,32 @@ def test_cross_attention_and_ff_vs_torch_fp32(L, B, N, Mk, C, heads):
         assert (z - r).abs().max() < 4e-3 * max(1.0, float(r.abs().max()))
 
 
+def test_attention_fuzz_vs_torch_fp32(L):
+    """Random (B, h, d, Mq, Mk) incl. every supported head dim, ragged lengths and Mq != Mk, against a plain PyTorch
+    fp32 softmax attention of the same fp16 inputs."""
+    g = torch.Generator().manual_seed(21)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for case in range(48):
+        d = [8, 16, 32, 40, 64, 80, 96, 128, 160][case % 9]
+        B, h = ri(1, 3), ri(1, 4)
+        Mk = ri(1, 700)
+        Mq = Mk if case % 3 == 0 else ri(1, 700)
+        C = h * d
+        Mqp, Mkp = (Mq + 7) // 8 * 8, (Mk + 7) // 8 * 8
+        q = torch.zeros(B, Mqp, C)
+        k = torch.zeros(B, Mkp, C)
+        v = torch.zeros(B, Mkp, C)
+        q[:, :Mq] = torch.randn(B, Mq, C, generator=g)
+        k[:, :Mk] = torch.randn(B, Mk, C, generator=g)
+        v[:, :Mk] = torch.randn(B, Mk, C, generator=g)
+        q, k, v = q.half().to(DEV), k.half().to(DEV), v.half().to(DEV)
+        o = L.attention_kv(q, k, v.transpose(1, 2).contiguous(), h, Mq, Mk, d ** -0.5)[:, :Mq].float()
+        qh, kh, vh = (t.float().reshape(B, -1, h, d).transpose(1, 2) for t in (q[:, :Mq], k[:, :Mk], v[:, :Mk]))
+        ref = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, dim=-1) @ vh).transpose(1, 2).reshape(B, Mq, C)
+        err = float((o - ref).abs().max())
+        assert err <= 1e-3 * max(1.0, float(ref.abs().max())), (case, B, h, d, Mq, Mk, err)
+
+
 def test_attention_split_last_round_equals_single_launch(L):
     """A launch whose last round of workgroups is nearly empty runs those query blocks as key-split workgroups plus
     a combine kernel (attention.hip, plan_tail).  Shape of the cfg-2 mid blocks: 272 workgroups on a 256-CU chip."""
