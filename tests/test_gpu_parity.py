@@ -200,6 +200,24 @@ def test_sort_desc(L, oracle, n):
     assert np.array_equal(perm, oracle.sort_desc(k))
 
 
+def test_sort_desc_fuzz_vs_torch_stable_sort(L):
+    """Random lengths (1 ... 120 000 keys, 1-3 rows) with heavy ties in every digit position, against torch's stable
+    descending sort of the same 32-bit keys (ties keep ascending index order)."""
+    g = torch.Generator().manual_seed(9)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for case in range(24):
+        rows = ri(1, 3)
+        n = [1, 2, 255, 256, 257, 1000, 4097, 12288, 49152, 110592][case % 10] if case < 10 else ri(1, 120000)
+        distinct = [2, 17, 300, 70000, 1 << 31][case % 5]
+        hi = torch.randint(0, distinct, (rows, n), generator=g, dtype=torch.int64)
+        if case % 4 == 1:
+            hi = hi << ri(0, 24) & 0xFFFFFFFF          # ties concentrated in the low / high digits
+        packed = (hi << 32) | torch.randint(0, 1 << 31, (rows, n), generator=g, dtype=torch.int64)
+        perm = L.sort_desc(packed.to(DEV)).cpu().to(torch.int64)
+        ref = torch.sort(hi, dim=1, descending=True, stable=True).indices
+        assert torch.equal(perm, ref), (case, rows, n, distinct)
+
+
 def test_gather_and_unmerge_add(L, oracle):
     g = torch.Generator().manual_seed(5)
     for dtype in (torch.float32, torch.float16, torch.bfloat16):
