@@ -783,6 +783,51 @@ def test_full_size_properties(L):
                            torch.arange(lv.Ns, device=DEV, dtype=torch.int32)[None].expand(B, -1))
 
 
+def test_compute_merge_fuzz_vs_oracle(L, oracle):
+    """End-to-end planner fuzz: random (B, F per chunk, token grid, C, ratios, align_batch, global merging, coin
+    threshold) over three consecutive chunks of a block; merged tokens, anchor tokens and the unmerge of a random
+    tensor must equal the CPU oracle's (patch.py:14-91 restated) exactly -- they are row copies, so any index
+    difference shows, and both sides draw from identically seeded generators."""
+    from vidtome_amd import patch as vpatch
+
+    class Blk(torch.nn.Module):
+        pass
+
+    g = torch.Generator().manual_seed(31)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for case in range(40):
+        B = ri(1, 3)
+        H, W = [(8, 8), (6, 10), (12, 4)][ri(0, 2)]
+        ds = ri(1, 2)
+        N = (H // ds) * (W // ds)
+        C = [8, 16, 40][ri(0, 2)]
+        args = dict(max_downsample=2, generator=None, seed=123, batch_size=B, align_batch=bool(ri(0, 1)),
+                    merge_global=bool(ri(0, 3)), global_merge_ratio=[0.3, 0.5, 0.8, 1.0][ri(0, 3)],
+                    local_merge_ratio=[0.3, 0.5, 0.9, 1.0][ri(0, 3)], global_rand=[0.0, 0.5, 1.0][ri(0, 2)],
+                    target_stride=4)
+        seed = ri(0, 10 ** 6)
+        blk = Blk()
+        blk.generator = torch.Generator().manual_seed(seed)
+        draws = oracle.RandomDraws.from_torch_generator(torch.Generator().manual_seed(seed))
+        state = {}
+        info = {"size": (H, W), "args": dict(args)}
+        for chunk in range(3):
+            F = ri(1, 9)
+            x = torch.randn(B * F, N, C, generator=g)
+            m_o, u_o, merged_o, _ = oracle.compute_merge(x.numpy(), (H, W), args, draws, state)
+            m, u, merged = vpatch.compute_merge(blk, x.to(DEV), info)
+            M = merged_o.shape[1]
+            tag = (case, chunk, B, F, N, C, args)
+            assert np.array_equal(merged[:, :M].cpu().numpy(), merged_o), tag
+            if args["merge_global"]:
+                assert np.array_equal(blk.global_tokens[:, :state["global_tokens"].shape[1]].cpu().numpy(),
+                                      state["global_tokens"]), tag
+            y = torch.randn(merged_o.shape, generator=g)
+            yp = torch.zeros(merged.shape)
+            yp[:, :M] = y
+            assert np.array_equal(u(yp.to(DEV)).cpu().numpy(), u_o(y.numpy())), tag
+
+
 # ---------------------------------------------------------------------------------------------------
 # caller-side tail of a step (SURVEY.md 8f rank 4): CFG combine + DDIM update vs the reference's pred_next_x
 # ---------------------------------------------------------------------------------------------------
