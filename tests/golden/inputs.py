@@ -24,3 +24,31 @@ def planted_inputs(Ns, Nd, C, seed, B=1):
         out_a.append(src.astype(np.float32))
         out_b.append((dst * dscale).astype(np.float32))
     return np.stack(out_a), np.stack(out_b)
+
+
+def fuzz_inputs(cfg):
+    """Chunk inputs of a fuzz_compute_merge.npz configuration: (B*F, N, C) fp32 per chunk, nothing but torch.randn on a
+    seeded CPU generator (shared by make_golden_fuzz.py and the tests)."""
+    import torch
+    g = torch.Generator().manual_seed(int(cfg["data_seed"]))
+    N = (int(cfg["H"]) // int(cfg["ds"])) * (int(cfg["W"]) // int(cfg["ds"]))
+    return [torch.randn(int(cfg["B"]) * int(F), N, int(cfg["C"]), generator=g) for F in cfg["frames"]]
+
+
+def fuzz_hash(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(a).astype(np.float32)).tobytes()).hexdigest()
+
+
+def load_fuzz_configs(path):
+    z = np.load(path)
+    keys = ["B", "H", "W", "ds", "C", "align", "merge_global", "global_ratio", "local_ratio", "global_rand", "gen_seed",
+            "data_seed"]
+    cfgs = []
+    for i in range(len(z["B"])):
+        c = {k: z[k][i].item() for k in keys}
+        c["frames"] = [int(f) for f in z["frames"][i]]
+        c["hashes"] = z["hashes"][i]
+        cfgs.append(c)
+    return cfgs
+

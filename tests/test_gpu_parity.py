@@ -783,6 +783,36 @@ def test_full_size_properties(L):
                            torch.arange(lv.Ns, device=DEV, dtype=torch.int32)[None].expand(B, -1))
 
 
+def test_compute_merge_reference_fuzz_gpu(L):
+    """The same 119 reference-generated configurations as tests/test_oracle_golden.py::test_oracle_vs_reference_fuzz,
+    through the HIP planner: merged tokens, stored anchor tokens and u(merged) hash-equal to the reference's."""
+    import os
+    from inputs import fuzz_hash, fuzz_inputs, load_fuzz_configs
+    from vidtome_amd import patch as vpatch
+
+    class Blk(torch.nn.Module):
+        pass
+
+    cfgs = load_fuzz_configs(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_compute_merge.npz"))
+    for cfg in cfgs:
+        blk = Blk()
+        blk.generator = torch.Generator().manual_seed(int(cfg["gen_seed"]))
+        info = {"size": (cfg["H"], cfg["W"]),
+                "args": dict(max_downsample=2, generator=None, seed=123, batch_size=cfg["B"], align_batch=bool(cfg["align"]),
+                             merge_global=bool(cfg["merge_global"]), global_merge_ratio=cfg["global_ratio"],
+                             local_merge_ratio=cfg["local_ratio"], global_rand=cfg["global_rand"], target_stride=4)}
+        for ck, x in enumerate(fuzz_inputs(cfg)):
+            m, u, merged = vpatch.compute_merge(blk, x.to(DEV), info)
+            plan = getattr(m, "plan", None)
+            M = plan.M if plan is not None else merged.shape[1]
+            want = cfg["hashes"][ck]
+            assert fuzz_hash(merged[:, :M].cpu().numpy()) == want[0], (cfg, ck)
+            if want[1]:
+                gt = blk.global_tokens
+                assert fuzz_hash(gt.cpu().numpy()) == want[1], (cfg, ck)
+            assert fuzz_hash(u(merged).cpu().numpy()) == want[2], (cfg, ck)
+
+
 def test_compute_merge_fuzz_vs_oracle(L, oracle):
     """End-to-end planner fuzz: random (B, F per chunk, token grid, C, ratios, align_batch, global merging, coin
     threshold) over three consecutive chunks of a block; merged tokens, anchor tokens and the unmerge of a random

@@ -233,3 +233,28 @@ def test_planted_full_cfg2_golden(oracle):
     if "planted_cfg2_top_l1" not in cases:
         pytest.skip("full-size planted fixture not generated")
     _planted_check(oracle, cases["planted_cfg2_top_l1"])
+
+
+def test_oracle_vs_reference_fuzz(oracle):
+    """119 random three-chunk configurations run through the REFERENCE's compute_merge (tests/golden/
+    make_golden_fuzz.py; hashes of the merged tokens, the stored global tokens and u(merged)): the oracle's
+    restatement of patch.py:14-91 must reproduce every one of them."""
+    import os
+    import torch
+    from inputs import fuzz_hash, fuzz_inputs, load_fuzz_configs
+    cfgs = load_fuzz_configs(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_compute_merge.npz"))
+    assert len(cfgs) >= 100
+    for cfg in cfgs:
+        args = dict(max_downsample=2, generator=None, seed=123, batch_size=cfg["B"], align_batch=bool(cfg["align"]),
+                    merge_global=bool(cfg["merge_global"]), global_merge_ratio=cfg["global_ratio"],
+                    local_merge_ratio=cfg["local_ratio"], global_rand=cfg["global_rand"], target_stride=4)
+        draws = oracle.RandomDraws.from_torch_generator(torch.Generator().manual_seed(int(cfg["gen_seed"])))
+        state = {}
+        for ck, x in enumerate(fuzz_inputs(cfg)):
+            m, u, merged, _ = oracle.compute_merge(x.numpy(), (cfg["H"], cfg["W"]), args, draws, state)
+            want = cfg["hashes"][ck]
+            assert fuzz_hash(merged) == want[0], (cfg, ck)
+            if want[1]:
+                assert fuzz_hash(state["global_tokens"]) == want[1], (cfg, ck)
+            assert fuzz_hash(u(merged)) == want[2], (cfg, ck)
+
