@@ -23,18 +23,18 @@ Differences that are design, not omissions:
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Callable, Dict, Optional, Tuple, Type
 
 import torch
 import torch.nn.functional as F
 
 from . import _lib, merge
+from .utils import init_generator, isinstance_str, join_frame, split_frame
 
 # Attention over the merged sequence computes outputs only for the rows unmerge() reads (see MergePlan.q_rows);
 # VIDTOME_LIVE_QUERIES=0 computes every row like the reference does (same block output, more work).
-import os as _os
-LIVE_QUERIES = _os.environ.get("VIDTOME_LIVE_QUERIES", "1") != "0"
-from .utils import init_generator, isinstance_str, join_frame, split_frame
+LIVE_QUERIES = os.environ.get("VIDTOME_LIVE_QUERIES", "1") != "0"
 
 
 # ----------------------------------------------------------------------------------------------------
