@@ -33,7 +33,7 @@ def fuzz_configs(n, seed=2024):
         cfg = dict(B=ri(1, 3), H=H, W=W, ds=ri(1, 2), C=[8, 16, 40][ri(0, 2)], align=ri(0, 1), merge_global=int(ri(0, 3) > 0),
                    global_ratio=[0.3, 0.5, 0.8, 1.0][ri(0, 3)], local_ratio=[0.3, 0.5, 0.9, 1.0][ri(0, 3)],
                    global_rand=[0.0, 0.5, 1.0][ri(0, 2)], gen_seed=ri(0, 10 ** 6), data_seed=ri(0, 10 ** 6),
-                   frames=[ri(1, 9) for _ in range(3)])
+                   frames=[ri(1, 9) if len(out) % 4 else ri(10, 20) for _ in range(3)])   # every 4th: 3+ local levels
         out.append(cfg)
     return out
 

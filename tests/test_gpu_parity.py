@@ -784,7 +784,7 @@ def test_full_size_properties(L):
 
 
 def test_compute_merge_reference_fuzz_gpu(L):
-    """The same 119 reference-generated configurations as tests/test_oracle_golden.py::test_oracle_vs_reference_fuzz,
+    """The same 115 reference-generated configurations as tests/test_oracle_golden.py::test_oracle_vs_reference_fuzz,
     through the HIP planner: merged tokens, stored anchor tokens and u(merged) hash-equal to the reference's."""
     import os
     from inputs import fuzz_hash, fuzz_inputs, load_fuzz_configs

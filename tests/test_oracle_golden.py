@@ -236,7 +236,7 @@ def test_planted_full_cfg2_golden(oracle):
 
 
 def test_oracle_vs_reference_fuzz(oracle):
-    """119 random three-chunk configurations run through the REFERENCE's compute_merge (tests/golden/
+    """115 random three-chunk configurations (frames per chunk 1-20) run through the REFERENCE's compute_merge (tests/golden/
     make_golden_fuzz.py; hashes of the merged tokens, the stored global tokens and u(merged)): the oracle's
     restatement of patch.py:14-91 must reproduce every one of them."""
     import os
