@@ -54,8 +54,11 @@ constexpr float INV_S2 = 1.0f / (1024.0f * 1024.0f);
 //   the canonical fp32 chain itself        <= C * 2^-24                       = 7.6e-5
 // EPS = 3.25e-4 (3 products) / 7.5e-4 (2) / 1.2e-3 (1); observed filter errors are ~1e-6 / ~1e-5 / ~2e-5.
 // Measured on the cfg-2 shapes: the wider window adds < 10 % surviving pairs (the refine pass is ~3 % of the call).
-constexpr bool SRC_LO = false;
-constexpr bool DST_LO = false;
+#ifndef VTM_FILTER_PRODUCTS
+#define VTM_FILTER_PRODUCTS 1   // build-time choice (1, 2 or 3); the shipped library uses 1
+#endif
+constexpr bool SRC_LO = VTM_FILTER_PRODUCTS >= 3;
+constexpr bool DST_LO = VTM_FILTER_PRODUCTS >= 2;
 static_assert(DST_LO || !SRC_LO, "the src lo half is only used together with the dst lo half");
 constexpr float WINDOW = SRC_LO ? 6.5e-4f : DST_LO ? 1.5e-3f : 2.4e-3f;   // 2 * EPS
 constexpr int MAX_C = 1280;                              // the budget above is derived for C <= 1280
