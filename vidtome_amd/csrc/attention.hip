@@ -367,6 +367,8 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             }
         }
         vec pf[4];
+        constexpr int NPRE = D <= 48 ? 2 : 0;   // V^T fragments of the last O^T row block fetched during the exps
+        vec vpre[NPRE > 0 ? NPRE : 1];
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             float p[8];
@@ -377,6 +379,14 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
                 if constexpr (!SPARE) l_run += p[e];
             }
             F::pack8(pf[st], p);
+            if constexpr (NPRE > 0) {
+                if (st == 1) {   // the first 32 scores are consumed: their registers can take fragments now
+                    const elem *vp = sV + buf * SV_TILE + ((DV - 1) * 32 + l31) * VT_STRIDE + 8 * hi;
+#pragma unroll
+                    for (int j = 0; j < NPRE; ++j) vpre[j] = *reinterpret_cast<const vec *>(vp + j * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
 
         // ---- O^T += V^T P^T : 4 steps of 16 keys; k-slot (hi, e) <-> key 16 st + 8 (e >> 2) + 4 hi + (e & 3)
@@ -385,7 +395,9 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             const elem *vp = sV + buf * SV_TILE + (dv * 32 + l31) * VT_STRIDE + 8 * hi;
 #pragma unroll
             for (int st = 0; st < 4; ++st)
-                o[dv] = F::mfma(*reinterpret_cast<const vec *>(vp + st * 16), pf[st], o[dv]);
+                o[dv] = F::mfma((dv == DV - 1 && st < NPRE) ? vpre[st < NPRE ? st : 0]
+                                                            : *reinterpret_cast<const vec *>(vp + st * 16),
+                                pf[st], o[dv]);
         }
     };
     using std::false_type;
