@@ -548,10 +548,12 @@ def test_attention_fuzz_vs_torch_fp32(L):
         assert err <= 1e-3 * max(1.0, float(ref.abs().max())), (case, B, h, d, Mq, Mk, err)
 
 
-def test_attention_split_last_round_equals_single_launch(L):
+@pytest.mark.parametrize("d,Mq", [(80, 8704), (40, 8448)])
+def test_attention_split_last_round_equals_single_launch(L, d, Mq):
     """A launch whose last round of workgroups is nearly empty runs those query blocks as key-split workgroups plus
-    a combine kernel (attention.hip, plan_tail).  Shape of the cfg-2 mid blocks: 272 workgroups on a 256-CU chip."""
-    B, h, d, Mq, Mk = 2, 8, 80, 8704, 4160          # 65 key tiles, the last one full; 17 x 16 = 272 workgroups
+    a combine kernel (attention.hip, plan_tail).  d = 80: shape of the cfg-2 mid blocks, 17 x 16 = 272 workgroups on
+    a 256-CU chip; d = 40 (16-row O^T blocks, their own record layout): 33 x 16 = 528 workgroups on 512 slots."""
+    B, h, Mk = 2, 8, 4160                           # 65 key tiles, the last one full
     C = h * d
     assert L.lib().vtm_attention_ws_bytes(B, h, Mq, Mk, d) > 0, "this shape is expected to take the split path"
     g = torch.Generator(device=DEV).manual_seed(3)

@@ -19,8 +19,11 @@
 //     one the S^T accumulator layout already has (keys 4*hi + {0..3} and 8 + 4*hi + {0..3} of every
 //     16-key group), and V^T is read from LDS with the same assignment -- no permute / LDS round trip;
 //   * V arrives TRANSPOSED (channel-major) from the projection GEMM, so V^T needs no transpose; when the
-//     head dim leaves a spare row in the last 32-row block of O^T (d = 40, 80), that V^T row is set to
-//     ones, so the MFMA itself accumulates the softmax denominator from the SAME fp16-rounded P.
+//     head dim leaves a spare row in the last row block of O^T (d = 40, 80), that V^T row is set to
+//     ones, so the MFMA itself accumulates the softmax denominator from the SAME fp16-rounded P;
+//   * d = 40 builds O^T from 16-row blocks (v_mfma_f32_16x16x32: 48 rows instead of 64, a quarter of the
+//     PV matrix work gone); P^T moves from the 32-query accumulator layout to the two 16-query B operands
+//     with v_permlane16_swap -- 8 swaps per tile, still no LDS round trip (PV16 below).
 #include "common.h"
 
 #include <type_traits>
@@ -28,6 +31,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
@@ -40,12 +45,27 @@ constexpr int KV = 64;           // keys per tile
 constexpr int VT_STRIDE = KV + 8;  // 72 elements = 144 B: 16-byte aligned rows, conflict-free ds_read_b128 over 32 rows
 constexpr float DEFER_THR = 8.0f;  // log2 units
 
+// PV16: O^T is built from 16-row blocks (v_mfma_f32_16x16x32) instead of 32-row blocks when that needs fewer
+// matrix-pipe cycles: d = 40 -> 48 rows (the denominator row included) instead of 64, a quarter of the PV work.
+// P^T leaves the QK^T accumulators with one query per lane & 31; two v_permlane16_swap per register pair turn
+// the fragments of two 16-key steps into the B operands (query = lane & 15) of the two 16-query halves.
+constexpr bool pv16_for(int D) { return (D % 32) != 0 && (D + 16) / 16 * 16 < (D + 31) / 32 * 32; }
+constexpr int vrows_for(int D) { return pv16_for(D) ? (D + 16) / 16 * 16 : (D + 31) / 32 * 32; }   // V^T tile rows
+// per-thread record a key-split workgroup leaves for attention_combine_kernel: accumulators, running max
+// (one per accumulator group), denominator
+constexpr int acc_floats(int D) { return pv16_for(D) ? (D + 16) / 16 * 8 : (D + 31) / 32 * 16; }
+constexpr int max_floats(int D) { return pv16_for(D) ? 2 : 1; }
+constexpr int rec_floats(int D) { return acc_floats(D) + max_floats(D) + 1; }
+
 template <typename T> struct Frag;
 template <> struct Frag<__half> {
     using vec = h16x8;
     using elem = _Float16;
     __device__ static f32x16 mfma(vec a, vec b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    __device__ static f32x4 mfma16(vec a, vec b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
     __device__ static void pack8(vec &dst, const float (&p)[8]) {
         // round-to-nearest (v_cvt_pk_f16_f32): a truncating pack would bias the numerator against the fp32
@@ -59,6 +79,9 @@ template <> struct Frag<vtm_bf16> {
     using elem = __bf16;
     __device__ static f32x16 mfma(vec a, vec b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ static f32x4 mfma16(vec a, vec b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
     __device__ static void pack8(vec &dst, const float (&p)[8]) {
 #pragma unroll
@@ -113,36 +136,81 @@ __device__ __forceinline__ void write_output(const f32x16 (&o)[(D + 31) / 32], f
     }
 }
 
+// PV16 layout: o[dv][qh][e] = O^T row 16 dv + 4 (lane >> 4) + e of query q0 + 16 qh + (lane & 15)
+template <typename T, int D>
+__device__ __forceinline__ void write_output16(const f32x4 (&o)[(D + 16) / 16][2], T *__restrict__ out, int64_t ldo,
+                                               int64_t b, int64_t h, int64_t q0, int64_t M, int64_t Mp, int lane) {
+    using elem = typename Frag<T>::elem;
+    constexpr int DV16 = (D + 16) / 16;
+    constexpr int LB = D / 16, LG = (D % 16) / 4, LE = D % 4;   // where the denominator row D sits
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+        const float inv_l = 1.0f / __shfl(o[LB][qh][LE], 16 * LG + l15, 64);
+        const int64_t qi = q0 + 16 * qh + l15;
+        if (qi < M) {
+            T *op = out + (b * Mp + qi) * ldo + h * D;
+#pragma unroll
+            for (int dv = 0; dv < DV16; ++dv) {
+                const int d0 = dv * 16 + 4 * g;
+                if (d0 < D) {   // D % 4 == 0 -> the 4 channels are all valid
+                    elem w[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (elem)(o[dv][qh][e] * inv_l);
+                    *reinterpret_cast<uint2 *>(op + d0) = *reinterpret_cast<uint2 *>(w);
+                }
+            }
+        }
+    }
+}
+
 // merges the `nsplit` partial states of a query block (same thread <-> register mapping as attention_kernel)
 template <typename T, int D>
 __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
     const float *__restrict__ partial, T *__restrict__ out, int64_t ldo, int64_t H, int64_t M, int64_t Mp, int64_t nqb,
     int64_t id0, int nsplit) {
     constexpr int WAVES = waves_for(D), NT = WAVES * 64, QB = WAVES * QW, DV = (D + 31) / 32;
+    constexpr bool PV16 = pv16_for(D);
+    constexpr int NA = acc_floats(D), NM = max_floats(D), REC = rec_floats(D);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int64_t lin = id0 + blockIdx.x;
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
-    f32x16 o[DV];
+    float acc[NA], m[NM], l = 0.0f;
 #pragma unroll
-    for (int dv = 0; dv < DV; ++dv)
+    for (int r = 0; r < NA; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dv][r] = 0.0f;
-    float m = -INFINITY, l = 0.0f;
+    for (int j = 0; j < NM; ++j) m[j] = -INFINITY;
     for (int sp = 0; sp < nsplit; ++sp) {
-        const float *pp = partial + ((int64_t)blockIdx.x * nsplit + sp) * (DV * 16 + 2) * NT + tid;
-        const float ms = pp[(DV * 16) * NT], ls = pp[(DV * 16 + 1) * NT];
-        const float mn = fmaxf(m, ms);
-        const float fa = __builtin_amdgcn_exp2f(m - mn), fb = __builtin_amdgcn_exp2f(ms - mn);   // exp2(-inf) = 0
-        m = mn;
-        l = l * fa + ls * fb;
+        const float *pp = partial + ((int64_t)blockIdx.x * nsplit + sp) * REC * NT + tid;
+        float fa[NM], fb[NM];
 #pragma unroll
-        for (int dv = 0; dv < DV; ++dv)
+        for (int j = 0; j < NM; ++j) {
+            const float ms = pp[(NA + j) * NT];
+            const float mn = fmaxf(m[j], ms);
+            fa[j] = __builtin_amdgcn_exp2f(m[j] - mn);   // exp2(-inf) = 0
+            fb[j] = __builtin_amdgcn_exp2f(ms - mn);
+            m[j] = mn;
+        }
+        l = l * fa[0] + pp[(NA + NM) * NT] * fb[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dv][r] = o[dv][r] * fa + pp[(dv * 16 + r) * NT] * fb;
+        for (int r = 0; r < NA; ++r) {
+            const int j = PV16 ? (r >> 2) & 1 : 0;   // PV16: accumulator (dv, qh, e) is register (dv * 2 + qh) * 4 + e
+            acc[r] = acc[r] * fa[j] + pp[r * NT] * fb[j];
+        }
     }
-    write_output<T, D>(o, l, out, ldo, b, h, q0, M, Mp, l31, hi);
+    if constexpr (PV16) {
+        f32x4 o[(D + 16) / 16][2];
+#pragma unroll
+        for (int r = 0; r < NA; ++r) o[r >> 3][(r >> 2) & 1][r & 3] = acc[r];
+        write_output16<T, D>(o, out, ldo, b, h, q0, M, Mp, lane);
+    } else {
+        f32x16 o[DV];
+#pragma unroll
+        for (int r = 0; r < NA; ++r) o[r >> 4][r & 15] = acc[r];
+        write_output<T, D>(o, l, out, ldo, b, h, q0, M, Mp, l31, hi);
+    }
 }
 
 template <typename T, int D>
@@ -163,6 +231,8 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     constexpr int WAVES = waves_for(D), NT = WAVES * 64, QB = WAVES * QW;
     constexpr int DK = (D + 15) / 16;      // k-steps of the QK^T contraction
     constexpr int DV = (D + 31) / 32;      // 32-row blocks of O^T
+    constexpr bool PV16 = pv16_for(D);     // ... or 16-row blocks (see pv16_for)
+    constexpr int DV16 = (D + 16) / 16, VROWS = vrows_for(D);
     constexpr bool SPARE = (D % 32) != 0;  // O^T row D is free -> softmax denominator through the MFMA
     // BIAS: the QK^T contraction has a spare k-slot (D % 16 != 0, e.g. d = 40 -> 48).  Channel D of every K row is
     // set to 1 and channel D of the (pre-scaled) query to -m, so the MFMA itself delivers s * scale * log2(e) - m
@@ -178,14 +248,15 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     constexpr int V_CHUNKS = D * (KV / 8);
     constexpr int K_PER_T = (K_CHUNKS + NT - 1) / NT;
     constexpr int V_PER_T = (V_CHUNKS + NT - 1) / NT;
-    constexpr int SK_TILE = KV * K_STRIDE, SV_TILE = DV * 32 * VT_STRIDE;
+    constexpr int SK_TILE = KV * K_STRIDE, SV_TILE = VROWS * VT_STRIDE;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     elem *sK = reinterpret_cast<elem *>(smem);   // [2][KV][K_STRIDE]
-    elem *sV = sK + 2 * SK_TILE;                 // [2][DV*32][VT_STRIDE]
+    elem *sV = sK + 2 * SK_TILE;                 // [2][VROWS][VT_STRIDE]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
+    const int l15 = lane & 15, g16 = lane >> 4;   // PV16 operand coordinates
     const int64_t lin = id0 + blockIdx.x / nsplit;
     const int split = (int)(blockIdx.x % nsplit);
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
@@ -199,9 +270,9 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
         const int row = i / (K_STRIDE - D), c = D + i % (K_STRIDE - D);
         sK[row * K_STRIDE + c] = (elem)((BIAS && c == D) ? 1.0f : 0.0f);
     }
-    if constexpr (DV * 32 > D) {
-        for (int i = tid; i < 2 * (DV * 32 - D) * VT_STRIDE; i += NT) {
-            const int bufi = i / ((DV * 32 - D) * VT_STRIDE), rem = i % ((DV * 32 - D) * VT_STRIDE);
+    if constexpr (VROWS > D) {
+        for (int i = tid; i < 2 * (VROWS - D) * VT_STRIDE; i += NT) {
+            const int bufi = i / ((VROWS - D) * VT_STRIDE), rem = i % ((VROWS - D) * VT_STRIDE);
             const int row = D + rem / VT_STRIDE, c = rem % VT_STRIDE;
             sV[bufi * SV_TILE + row * VT_STRIDE + c] = (elem)((row == D) ? 1.0f : 0.0f);
         }
@@ -296,11 +367,36 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             }
     };
 
-    f32x16 o[DV];
+    f32x16 o[PV16 ? 1 : DV];          // 32-row blocks: o[dv][r] = row 32 dv + (r & 3) + 8 (r >> 2) + 4 hi of query l31
+    f32x4 o16[PV16 ? DV16 : 1][2];    // PV16: o16[dv][qh][e] = row 16 dv + 4 g16 + e of query 16 qh + l15
 #pragma unroll
-    for (int dv = 0; dv < DV; ++dv)
+    for (int dv = 0; dv < (PV16 ? 1 : DV); ++dv)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dv][r] = 0.0f;
+#pragma unroll
+    for (int dv = 0; dv < (PV16 ? DV16 : 1); ++dv)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o16[dv][qh][e] = 0.0f;
+    // O^T *= alpha (alpha is per query, in the S^T layout: lane l31 and l31 + 32 hold the same value)
+    auto rescale = [&](float alpha) {
+        if constexpr (PV16) {
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                const float a = __shfl(alpha, 16 * qh + l15, 64);
+#pragma unroll
+                for (int dv = 0; dv < DV16; ++dv)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o16[dv][qh][e] *= a;
+            }
+        } else {
+#pragma unroll
+            for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+        }
+    };
     float m_run = -INFINITY;   // running max in scaled (log2) units
     float m_bias = 0.0f;       // BIAS: the fp16-representable shift currently held in channel D of the query
     float l_run = 0.0f;        // only used when there is no spare O^T row
@@ -343,10 +439,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
                 m_run = m_new;
                 m_bias = m_new;
                 l_run *= alpha;
-#pragma unroll
-                for (int dv = 0; dv < DV; ++dv)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+                rescale(alpha);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -360,17 +453,11 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
                 m_run = m_new;
                 l_run *= alpha;
-#pragma unroll
-                for (int dv = 0; dv < DV; ++dv)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+                rescale(alpha);
             }
         }
         vec pf[4];
-        constexpr int NPRE = D <= 48 ? 2 : 0;   // V^T fragments of the last O^T row block fetched during the exps
-        vec vpre[NPRE > 0 ? NPRE : 1];
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        auto softmax_step = [&](int st) {   // p of keys 16 st + (e & 3) + 8 (e >> 2) + 4 hi
             float p[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -379,25 +466,46 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
                 if constexpr (!SPARE) l_run += p[e];
             }
             F::pack8(pf[st], p);
-            if constexpr (NPRE > 0) {
-                if (st == 1) {   // the first 32 scores are consumed: their registers can take fragments now
-                    const elem *vp = sV + buf * SV_TILE + ((DV - 1) * 32 + l31) * VT_STRIDE + 8 * hi;
+        };
+        if constexpr (PV16) {
+            // ---- O^T += V^T P^T in 16-row blocks: 2 steps of 32 keys.  After the swaps pf[2 ks] / pf[2 ks + 1] are
+            // the B operands of queries 0-15 / 16-31: k-slot group g16 holds the keys of 16-key group
+            // 2 ks + (g16 & 1), lane half g16 >> 1 -- in the V^T tile that is ONE 16-byte piece (see voff)
 #pragma unroll
-                    for (int j = 0; j < NPRE; ++j) vpre[j] = *reinterpret_cast<const vec *>(vp + j * 16);
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < 2; ++ks) {
+                // the V^T fragments of this step are fetched before the exps so that the MFMAs never wait for LDS
+                const elem *vp = sV + buf * SV_TILE + l15 * VT_STRIDE + ks * 32 + (g16 & 1) * 16 + (g16 >> 1) * 8;
+                vec a[DV16];
+#pragma unroll
+                for (int dv = 0; dv < DV16; ++dv) a[dv] = *reinterpret_cast<const vec *>(vp + dv * 16 * VT_STRIDE);
+                __builtin_amdgcn_sched_barrier(0);
+                softmax_step(2 * ks);
+                softmax_step(2 * ks + 1);
+                u32x4 x = __builtin_bit_cast(u32x4, pf[2 * ks]), y = __builtin_bit_cast(u32x4, pf[2 * ks + 1]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(x[w], y[w], false, false);
+                    x[w] = r[0];
+                    y[w] = r[1];
+                }
+                const vec p0 = __builtin_bit_cast(vec, x), p1 = __builtin_bit_cast(vec, y);
+#pragma unroll
+                for (int dv = 0; dv < DV16; ++dv) {
+                    o16[dv][0] = F::mfma16(a[dv], p0, o16[dv][0]);
+                    o16[dv][1] = F::mfma16(a[dv], p1, o16[dv][1]);
                 }
             }
-        }
-
-        // ---- O^T += V^T P^T : 4 steps of 16 keys; k-slot (hi, e) <-> key 16 st + 8 (e >> 2) + 4 hi + (e & 3)
+        } else {
 #pragma unroll
-        for (int dv = 0; dv < DV; ++dv) {
-            const elem *vp = sV + buf * SV_TILE + (dv * 32 + l31) * VT_STRIDE + 8 * hi;
+            for (int st = 0; st < 4; ++st) softmax_step(st);
+            // ---- O^T += V^T P^T : 4 steps of 16 keys; k-slot (hi, e) <-> key 16 st + 8 (e >> 2) + 4 hi + (e & 3)
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
-                o[dv] = F::mfma((dv == DV - 1 && st < NPRE) ? vpre[st < NPRE ? st : 0]
-                                                            : *reinterpret_cast<const vec *>(vp + st * 16),
-                                pf[st], o[dv]);
+            for (int dv = 0; dv < DV; ++dv) {
+                const elem *vp = sV + buf * SV_TILE + (dv * 32 + l31) * VT_STRIDE + 8 * hi;
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    o[dv] = F::mfma(*reinterpret_cast<const vec *>(vp + st * 16), pf[st], o[dv]);
+            }
         }
     };
     using std::false_type;
@@ -435,16 +543,25 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     if (t < te) tile(true_type{}, buf, t * KV);
 
     if (partial) {   // split workgroup: hand the raw state to attention_combine_kernel
-        float *pp = partial + (int64_t)blockIdx.x * (DV * 16 + 2) * NT + tid;
+        constexpr int NA = acc_floats(D), NM = max_floats(D), REC = rec_floats(D);
+        float *pp = partial + (int64_t)blockIdx.x * REC * NT + tid;
+        if constexpr (PV16) {
 #pragma unroll
-        for (int dv = 0; dv < DV; ++dv)
+            for (int r = 0; r < NA; ++r) pp[r * NT] = o16[r >> 3][(r >> 2) & 1][r & 3];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pp[(dv * 16 + r) * NT] = o[dv][r];
-        pp[(DV * 16) * NT] = m_run;
-        pp[(DV * 16 + 1) * NT] = l_run;
+            for (int qh = 0; qh < 2; ++qh) pp[(NA + qh) * NT] = __shfl(m_run, 16 * qh + l15, 64);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NA; ++r) pp[r * NT] = o[r >> 4][r & 15];
+            pp[NA * NT] = m_run;
+        }
+        pp[(NA + NM) * NT] = l_run;
         return;
     }
-    write_output<T, D>(o, l_run, out, ldo, b, h, q0, M, Mp, l31, hi);
+    if constexpr (PV16)
+        write_output16<T, D>(o16, out, ldo, b, h, q0, M, Mp, lane);
+    else
+        write_output<T, D>(o, l_run, out, ldo, b, h, q0, M, Mp, l31, hi);
 }
 
 // Tail plan.  All workgroups of a launch take the same time, so the launch runs in "rounds" of as many workgroups
@@ -490,7 +607,7 @@ TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk) {
         if (ns > ntiles / 8) ns = ntiles / 8;
         if (ns >= 2) {
             p.nsplit = (int)ns;
-            p.ws_bytes = (size_t)rem * ns * (DV * 16 + 2) * (WAVES * 64) * sizeof(float);
+            p.ws_bytes = (size_t)rem * ns * rec_floats(D) * (WAVES * 64) * sizeof(float);
         }
     }
     if (p.nsplit == 1) p.full = p.total;
@@ -502,7 +619,7 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
            int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale, int share_groups,
            void *ws, size_t ws_bytes, hipStream_t s) {
     constexpr int DK = (D + 15) / 16, DV = (D + 31) / 32;
-    constexpr size_t lds = (size_t)2 * (KV * (DK * 16 + 8) + DV * 32 * VT_STRIDE) * 2;
+    constexpr size_t lds = (size_t)2 * (KV * (DK * 16 + 8) + vrows_for(D) * VT_STRIDE) * 2;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<T, D>),
