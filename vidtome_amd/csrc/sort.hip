@@ -6,15 +6,18 @@
 //
 // Design (v4): multi-workgroup LSD radix sort, 4 passes of 8-bit digits, every global access coalesced.
 // A row is cut into contiguous segments (one 256-thread workgroup each, a few 256-key tiles per segment),
-// so that ~64 CUs work on a row instead of one.  Per pass, two small kernels:
-//   hist     per-segment digit counts (wave-aggregated: one LDS add per distinct digit and wave) -> hist[row][seg][digit]
-//   scatter  every workgroup derives its 256 scatter offsets from the table (exclusive scan in (digit, segment)
-//            order), then scatters stably: offset + earlier tiles of the segment + lower waves of the tile + rank
-//            inside the wave (popcount of the same-digit lane mask below the lane)
+// so that ~64 CUs work on a row instead of one.  Kernels:
+//   hist     (first pass only) per-segment digit counts (wave-aggregated: one LDS add per distinct digit and
+//            wave) -> hist[0][row][seg][digit]; also clears the tables of the later passes
+//   scatter  every workgroup derives its 256 scatter offsets from the pass's table (exclusive scan in (digit,
+//            segment) order), then scatters stably: offset + earlier tiles of the segment + lower waves of the
+//            tile + rank inside the wave (popcount of the same-digit lane mask below the lane).  A key's
+//            destination tells which segment it belongs to in the NEXT pass, so the scatter also counts the next
+//            digit into the next pass's table (one global atomic per key; counts do not depend on order)
 // Thread order == index order inside a tile, tiles and segments are in index order, so equal digits keep
 // their order (stability).  The kernels are launch-latency sized (rows are <= ~110k keys, L2-resident), which
-// is why the digit is 8 bits wide and the scan lives inside the scatter kernel: 8 launches per sort (a 4-bit digit
-// with a separate scan kernel needs 24).
+// is why the digit is 8 bits wide, the scan lives inside the scatter kernel and the later histograms ride on the
+// scatters: 5 launches per sort (a 4-bit digit with separate hist / scan / scatter kernels needs 24).
 #include "common.h"
 
 namespace {
@@ -45,16 +48,18 @@ struct Geo {
     int nseg, tiles_per_seg;
 };
 
-__global__ __launch_bounds__(T) void sort_hist_kernel(const uint64_t *__restrict__ best,
-                                                      const uint32_t *__restrict__ ksrc_all, Geo g, int pass,
+__global__ __launch_bounds__(T) void sort_hist_kernel(const uint64_t *__restrict__ best, Geo g, int64_t table_ints,
                                                       int *__restrict__ hist) {
     __shared__ int cnt[RADIX];
     const int tid = threadIdx.x, lane = tid & 63;
     const int seg = blockIdx.x, row = blockIdx.y;
     const uint64_t *kin = best + (int64_t)row * g.n;
-    const uint32_t *ksrc = ksrc_all + (int64_t)row * g.n;
-    const int sh = pass * 8;
+    const uint32_t *ksrc = nullptr;
+    constexpr int pass = 0, sh = 0;
     cnt[tid] = 0;
+#pragma unroll
+    for (int p = 1; p < PASSES; ++p)   // the tables the scatters of passes 0 .. PASSES-2 count into
+        hist[p * table_ints + ((int64_t)row * g.nseg + seg) * RADIX + tid] = 0;
     __syncthreads();
     for (int t = 0; t < g.tiles_per_seg; ++t) {
         const int64_t i = ((int64_t)seg * g.tiles_per_seg + t) * T + tid;
@@ -72,7 +77,8 @@ __global__ __launch_bounds__(T) void sort_scatter_kernel(const uint64_t *__restr
                                                          const uint32_t *__restrict__ ksrc_all,
                                                          const int32_t *__restrict__ psrc_all,
                                                          uint32_t *__restrict__ kdst_all, int32_t *__restrict__ pdst_all,
-                                                         Geo g, int pass, int last, const int *__restrict__ hist) {
+                                                         Geo g, int pass, int last, const int *__restrict__ hist,
+                                                         int *__restrict__ hist_next) {
     // wcnt[w][d] = (tile tag << 16) | keys of digit d in wave w of the tagged tile; an entry with another tag
     // counts as zero, so the table never has to be cleared
     __shared__ uint32_t wcnt[WAVES][RADIX];
@@ -86,6 +92,8 @@ __global__ __launch_bounds__(T) void sort_scatter_kernel(const uint64_t *__restr
     uint32_t *kdst = kdst_all + (int64_t)row * g.n;
     int32_t *pdst = pdst_all + (int64_t)row * g.n;
     const int sh = pass * 8;
+    const int seg_keys = g.tiles_per_seg * T;
+    int *hnext = hist_next + (int64_t)row * g.nseg * RADIX;
     const unsigned long long below = (1ull << lane) - 1ull;
     // scatter offsets of this segment, straight from the histogram table (exclusive scan in (digit, segment)
     // order): thread d owns digit d -- keys of smaller digits in all segments + keys of digit d in earlier
@@ -134,7 +142,10 @@ __global__ __launch_bounds__(T) void sort_scatter_kernel(const uint64_t *__restr
                 const uint32_t e = wcnt[w][d];
                 if (w < wave && (e & 0xffff0000u) == tag) pos += (int)(e & 0xffffu);
             }
-            if (!last) kdst[pos] = key;
+            if (!last) {
+                kdst[pos] = key;
+                atomicAdd(&hnext[(pos / seg_keys) * RADIX + (int)((key >> (sh + 8)) & 255u)], 1);
+            }
             pdst[pos] = id;
         }
         __syncthreads();   // everyone has read running[] / wcnt[] of this tile
@@ -169,8 +180,8 @@ inline size_t aligned(size_t v) { return (v + 255) & ~(size_t)255; }
 VTM_EXPORT size_t vtm_sort_ws_bytes(int64_t rows, int64_t n) {
     if (rows <= 0 || n <= 0) return 0;
     const Geo g = make_geo(n);
-    // key / index ping-pong buffers + the histogram table
-    return aligned((size_t)rows * n * 16u) + aligned((size_t)rows * RADIX * g.nseg * sizeof(int));
+    // key / index ping-pong buffers + one histogram table per pass
+    return aligned((size_t)rows * n * 16u) + aligned((size_t)PASSES * rows * RADIX * g.nseg * sizeof(int));
 }
 
 VTM_EXPORT int vtm_sort_desc(const uint64_t *best, int64_t rows, int64_t n, int32_t *perm, void *ws,
@@ -189,6 +200,8 @@ VTM_EXPORT int vtm_sort_desc(const uint64_t *best, int64_t rows, int64_t n, int3
     int32_t *p0 = reinterpret_cast<int32_t *>(k1 + rows * n), *p1 = p0 + rows * n;
     int *hist = reinterpret_cast<int *>(w + aligned((size_t)rows * n * 16u));
     const dim3 grid((unsigned)g.nseg, (unsigned)rows), block(T);
+    const int64_t table_ints = rows * g.nseg * RADIX;
+    hipLaunchKernelGGL(sort_hist_kernel, grid, block, 0, s, best, g, table_ints, hist);
     for (int pass = 0; pass < PASSES; ++pass) {
         const uint32_t *ksrc = (pass & 1) ? k1 : k0;
         const int32_t *psrc = (pass & 1) ? p1 : p0;
@@ -196,8 +209,8 @@ VTM_EXPORT int vtm_sort_desc(const uint64_t *best, int64_t rows, int64_t n, int3
         int32_t *pdst = (pass & 1) ? p0 : p1;
         const int last = pass == PASSES - 1;
         if (last) pdst = perm;
-        hipLaunchKernelGGL(sort_hist_kernel, grid, block, 0, s, best, ksrc, g, pass, hist);
-        hipLaunchKernelGGL(sort_scatter_kernel, grid, block, 0, s, best, ksrc, psrc, kdst, pdst, g, pass, last, hist);
+        hipLaunchKernelGGL(sort_scatter_kernel, grid, block, 0, s, best, ksrc, psrc, kdst, pdst, g, pass, last,
+                           hist + pass * table_ints, hist + (last ? 0 : pass + 1) * table_ints);
     }
     return vtm::launch_status("vtm_sort_desc");
 }
