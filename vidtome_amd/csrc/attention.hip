@@ -14,7 +14,9 @@
 //     cross-half exchange per tile for the running max;
 //   * per score: one v_fma (scale folded, base 2) + one v_exp; the running max is only raised when it grew
 //     by more than 2^8 (deferred rescale: P <= 256 is exact enough in fp16 and the O-rescale, which would
-//     drag the accumulators through VALU every tile, becomes rare);
+//     drag the accumulators through VALU every tile, becomes rare).  Head dims with a spare k-slot (d = 40)
+//     carry the shift INSIDE the contraction (BIAS below): no v_fma, and the maximum is only checked
+//     afterwards, on the packed P;
 //   * P stays in registers: the PV contraction's k-slot <-> key assignment is chosen to be exactly the
 //     one the S^T accumulator layout already has (keys 4*hi + {0..3} and 8 + 4*hi + {0..3} of every
 //     16-key group), and V^T is read from LDS with the same assignment -- no permute / LDS round trip;
@@ -33,6 +35,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
@@ -67,6 +70,12 @@ template <> struct Frag<__half> {
     __device__ static f32x4 mfma16(vec a, vec b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
+    static constexpr uint32_t BITS_256 = 0x5C00u;   // 256.0
+    __device__ static uint32_t pmax3(uint32_t a, uint32_t b, uint32_t c) {   // packed maximum of 3 x 2 values
+        uint32_t d;
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
+    }
     __device__ static void pack8(vec &dst, const float (&p)[8]) {
         // round-to-nearest (v_cvt_pk_f16_f32): a truncating pack would bias the numerator against the fp32
         // denominator of the head dims without a spare O^T row
@@ -82,6 +91,14 @@ template <> struct Frag<vtm_bf16> {
     }
     __device__ static f32x4 mfma16(vec a, vec b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static constexpr uint32_t BITS_256 = 0x4380u;   // 256.0
+    __device__ static uint32_t pmax3(uint32_t a, uint32_t b, uint32_t c) {
+        // P >= 0: the bit patterns order like the values (inf and NaN on top), so an integer maximum will do
+        const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(u16x2, a),
+                                                                            __builtin_bit_cast(u16x2, b)),
+                                                  __builtin_bit_cast(u16x2, c));
+        return __builtin_bit_cast(uint32_t, m);
     }
     __device__ static void pack8(vec &dst, const float (&p)[8]) {
 #pragma unroll
@@ -406,56 +423,60 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
         constexpr bool TAIL = decltype(tail_tag)::value;
         // ---- S^T = K Q^T : 2 blocks of 32 keys
         f32x16 s[2];
+        auto compute_s = [&]() {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
-            const elem *kp = sK + buf * SK_TILE + (kb * 32 + l31) * K_STRIDE + hi * 8;
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+                const elem *kp = sK + buf * SK_TILE + (kb * 32 + l31) * K_STRIDE + hi * 8;
 #pragma unroll
-            for (int ks = 0; ks < DK; ++ks)
-                s[kb] = F::mfma(*reinterpret_cast<const vec *>(kp + ks * 16), qf[ks], s[kb]);
-        }
-        if constexpr (TAIL) {   // lane (l31, hi) holds keys key0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
-            const int lim = (int)(Mk - key0);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= lim) s[kb][r] = -INFINITY;
-        }
-
-        // ---- online softmax, base 2, deferred rescale
-        float mt = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[0][r]), s[1][r]);
-        if constexpr (BIAS) {
-            // scores arrive as s c - m_bias: mt is the growth over the current shift (m_run = -inf only before
-            // the first tile, which therefore always takes the branch and installs its own maximum)
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            if (!__all(m_bias + mt <= m_run + DEFER_THR)) {
-                const float m_new = (float)(elem)(fmaxf(m_run, m_bias + mt));   // fp16-representable
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
-                const float delta = m_bias - m_new;                             // exact: both are fp16 values
-                m_run = m_new;
-                m_bias = m_new;
-                l_run *= alpha;
-                rescale(alpha);
+                for (int ks = 0; ks < DK; ++ks)
+                    s[kb] = F::mfma(*reinterpret_cast<const vec *>(kp + ks * 16), qf[ks], s[kb]);
+            }
+            if constexpr (TAIL) {   // lane (l31, hi) holds keys key0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
+                const int lim = (int)(Mk - key0);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kb][r] += delta;   // this tile was computed with the old shift
-                if (hi == BIAS_HI) qf[DK - 1][BIAS_E] = (elem)(-m_new);
+                    for (int r = 0; r < 16; ++r)
+                        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= lim) s[kb][r] = -INFINITY;
             }
-        } else {
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
-            if (!__all(mt <= m_run + DEFER_THR)) {
-                const float m_new = fmaxf(m_run, mt);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
-                m_run = m_new;
-                l_run *= alpha;
-                rescale(alpha);
+        };
+
+        // ---- online softmax, base 2, deferred rescale: raises the shift when this tile's maximum outgrew it
+        auto raise_shift = [&]() {
+            float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = fmaxf(fmaxf(mt, s[0][r]), s[1][r]);
+            if constexpr (BIAS) {
+                // scores arrive as s c - m_bias: mt is the growth over the current shift (m_run = -inf only before
+                // the first tile, which therefore always takes the branch and installs its own maximum)
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+                if (!__all(m_bias + mt <= m_run + DEFER_THR)) {
+                    const float m_new = (float)(elem)(fmaxf(m_run, m_bias + mt));   // fp16-representable
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
+                    const float delta = m_bias - m_new;                             // exact: both are fp16 values
+                    m_run = m_new;
+                    m_bias = m_new;
+                    l_run *= alpha;
+                    rescale(alpha);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[kb][r] += delta;   // this tile was computed with the old shift
+                    if (hi == BIAS_HI) qf[DK - 1][BIAS_E] = (elem)(-m_new);
+                }
+            } else {
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
+                if (!__all(mt <= m_run + DEFER_THR)) {
+                    const float m_new = fmaxf(m_run, mt);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
+                    m_run = m_new;
+                    l_run *= alpha;
+                    rescale(alpha);
+                }
             }
-        }
+        };
         vec pf[4];
         auto softmax_step = [&](int st) {   // p of keys 16 st + (e & 3) + 8 (e >> 2) + 4 hi
             float p[8];
@@ -467,20 +488,42 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             }
             F::pack8(pf[st], p);
         };
+        compute_s();
         if constexpr (PV16) {
+            static_assert(BIAS, "16-row O^T blocks imply a spare k-slot");
+            // The shift already rides in the MFMA, so the exps run FIRST and the maximum is taken afterwards, on the
+            // packed P (8 packed 3-input maxima instead of 16 fp32 ones, and no cross-half exchange): P <= 2^8 means
+            // the shift still holds.  Otherwise -- the first tile, or scores that outgrew the shift by more than
+            // 2^8, possibly up to inf in P -- the tile is redone the exact way: scores again, maximum, new shift.
+            const elem *vp = sV + buf * SV_TILE + l15 * VT_STRIDE + (g16 & 1) * 16 + (g16 >> 1) * 8;
+            vec a[DV16];   // V^T fragments of the first 32 keys, fetched before the exps
+#pragma unroll
+            for (int st = 0; st < 4; ++st) softmax_step(st);
+            uint32_t pw[16];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const u32x4 w = __builtin_bit_cast(u32x4, pf[st]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pw[4 * st + j] = w[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) pw[j] = F::pmax3(pw[3 * j], pw[3 * j + 1], pw[3 * j + 2]);   // 16 -> 5 + 1
+            const uint32_t pr = F::pmax3(F::pmax3(pw[0], pw[1], pw[2]), F::pmax3(pw[3], pw[4], pw[15]), pw[15]);
+            const uint32_t ptop = max(pr >> 16, pr & 0xffffu);
+            if (__any(ptop > F::BITS_256 || m_run == -INFINITY)) {
+                compute_s();
+                raise_shift();
+#pragma unroll
+                for (int st = 0; st < 4; ++st) softmax_step(st);
+            }
             // ---- O^T += V^T P^T in 16-row blocks: 2 steps of 32 keys.  After the swaps pf[2 ks] / pf[2 ks + 1] are
             // the B operands of queries 0-15 / 16-31: k-slot group g16 holds the keys of 16-key group
             // 2 ks + (g16 & 1), lane half g16 >> 1 -- in the V^T tile that is ONE 16-byte piece (see voff)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                // the V^T fragments of this step are fetched before the exps so that the MFMAs never wait for LDS
-                const elem *vp = sV + buf * SV_TILE + l15 * VT_STRIDE + ks * 32 + (g16 & 1) * 16 + (g16 >> 1) * 8;
-                vec a[DV16];
 #pragma unroll
-                for (int dv = 0; dv < DV16; ++dv) a[dv] = *reinterpret_cast<const vec *>(vp + dv * 16 * VT_STRIDE);
-                __builtin_amdgcn_sched_barrier(0);
-                softmax_step(2 * ks);
-                softmax_step(2 * ks + 1);
+                for (int dv = 0; dv < DV16; ++dv)
+                    a[dv] = *reinterpret_cast<const vec *>(vp + ks * 32 + dv * 16 * VT_STRIDE);
                 u32x4 x = __builtin_bit_cast(u32x4, pf[2 * ks]), y = __builtin_bit_cast(u32x4, pf[2 * ks + 1]);
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
@@ -496,6 +539,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
                 }
             }
         } else {
+            raise_shift();
 #pragma unroll
             for (int st = 0; st < 4; ++st) softmax_step(st);
             // ---- O^T += V^T P^T : 4 steps of 16 keys; k-slot (hi, e) <-> key 16 st + 8 (e >> 2) + 4 hi + (e & 3)
@@ -588,7 +632,7 @@ inline int device_cus() {
 
 template <int D>
 TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk) {
-    constexpr int WAVES = waves_for(D), QB = WAVES * QW, DV = (D + 31) / 32;
+    constexpr int WAVES = waves_for(D), QB = WAVES * QW;
     constexpr int wg_per_cu = D <= 48 ? 2 : 1;   // resident workgroups per CU (launch bounds / LDS)
     TailPlan p;
     p.nqb = vtm::cdiv(Mq, QB);
@@ -618,7 +662,7 @@ template <typename T, int D>
 int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt, void *out,
            int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale, int share_groups,
            void *ws, size_t ws_bytes, hipStream_t s) {
-    constexpr int DK = (D + 15) / 16, DV = (D + 31) / 32;
+    constexpr int DK = (D + 15) / 16;
     constexpr size_t lds = (size_t)2 * (KV * (DK * 16 + 8) + vrows_for(D) * VT_STRIDE) * 2;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
