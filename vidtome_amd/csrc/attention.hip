@@ -424,6 +424,25 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
         // ---- S^T = K Q^T : 2 blocks of 32 keys
         f32x16 s[2];
         auto compute_s = [&]() {
+            if constexpr (PV16) {
+                // the two 32-key blocks one after the other: the exps of the first start beside the MFMAs of the second
+                vec kf[2][DK];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const elem *kp = sK + buf * SK_TILE + (kb * 32 + l31) * K_STRIDE + hi * 8;
+#pragma unroll
+                    for (int ks = 0; ks < DK; ++ks) kf[kb][ks] = *reinterpret_cast<const vec *>(kp + ks * 16);
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < DK; ++ks) s[kb] = F::mfma(kf[kb][ks], qf[ks], s[kb]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -432,6 +451,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
 #pragma unroll
                 for (int ks = 0; ks < DK; ++ks)
                     s[kb] = F::mfma(*reinterpret_cast<const vec *>(kp + ks * 16), qf[ks], s[kb]);
+            }
             }
             if constexpr (TAIL) {   // lane (l31, hi) holds keys key0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
                 const int lim = (int)(Mk - key0);
