@@ -1,13 +1,13 @@
 // vtm_layernorm: the block's norm1 (vidtome/patch.py:139-146, plain-LayerNorm branch: `self.norm1(hidden_states)`),
 // i.e. torch.nn.LayerNorm over the channel axis -- the first operation of the patched segment and the producer of
-// the matching metric.  One wave per token row, the row lives in registers: read once, write once (HBM-bound;
-// cfg-2 top site: 84 MB in + 84 MB out).  Statistics in fp32, two passes over the registers (mean, then the
+// the matching metric.  One wave per token row (2-4 rows per wave in flight), the rows live in registers: read once,
+// write once (HBM-bound; cfg-2 top site: 84 MB in + 84 MB out).  Statistics in fp32, two passes over the registers (mean, then the
 // centred sum of squares), y = (x - mean) * rstd * gamma + beta evaluated in fp32 and rounded once.
 #include "common.h"
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 4;   // 4 waves
+constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MAX_CHUNKS = 4;       // 8-channel chunks per lane: C <= 64 * 8 * 4 = 2048
 
 template <typename T>
@@ -55,55 +55,96 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <typename T>
-__global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void layernorm_kernel(const T *__restrict__ x, const T *__restrict__ gamma,
-                                                                        const T *__restrict__ beta, int64_t rows, int C,
-                                                                        float eps, T *__restrict__ out) {
+// NCH: 8-channel chunks per lane (C <= 512 NCH); R: rows per wave, all loaded before the first reduction so that
+// a wave keeps R rows of HBM traffic in flight (one row per wave leaves the kernel latency-bound: 2.4 TB/s)
+template <typename T, int NCH, int R>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_kernel(const T *__restrict__ x, const T *__restrict__ gamma,
+                                                                         const T *__restrict__ beta, int64_t rows, int C,
+                                                                         float eps, T *__restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
     const int chunks = C / 8;
-    const T *xr = x + row * C;
-    float v[MAX_CHUNKS][8];
-    float s = 0.0f;
+    float v[R][NCH][8];
+    float s[R];
 #pragma unroll
-    for (int i = 0; i < MAX_CHUNKS; ++i) {
-        const int c = lane + 64 * i;
-        if (c < chunks) {
-            load8(xr + c * 8, v[i]);
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;   // surplus rows recompute the last one, unstored
+        const T *xr = x + row * C;
+        s[r] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[i][j];
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < chunks) load8(xr + c * 8, v[r][i]);
         }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.0f;
 #pragma unroll
-    for (int i = 0; i < MAX_CHUNKS; ++i) {
-        if (lane + 64 * i < chunks) {
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = v[i][j] - mean;
-                q = __builtin_fmaf(d, d, q);
+        for (int i = 0; i < NCH; ++i)
+            if (lane + 64 * i < chunks) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[r] += v[r][i][j];
+            }
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) / (float)C;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (lane + 64 * i < chunks) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = v[r][i][j] - mean[r];
+                    q = __builtin_fmaf(d, d, q);
+                }
             }
         }
+        s[r] = q;
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-    T *orow = out + row * C;
 #pragma unroll
-    for (int i = 0; i < MAX_CHUNKS; ++i) {
+    for (int r = 0; r < R; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(s[r]) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
         if (c < chunks) {
-            float g[8], b[8], y[8];
+            float g[8], b[8];
             if (gamma) load8(gamma + c * 8, g);
             if (beta) load8(beta + c * 8, b);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float n = (v[i][j] - mean) * rstd;
-                y[j] = gamma ? (beta ? __builtin_fmaf(n, g[j], b[j]) : n * g[j]) : (beta ? n + b[j] : n);
+            for (int r = 0; r < R; ++r) {
+                if (row0 + r < rows) {
+                    float y[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float n = (v[r][i][j] - mean[r]) * rstd[r];
+                        y[j] = gamma ? (beta ? __builtin_fmaf(n, g[j], b[j]) : n * g[j]) : (beta ? n + b[j] : n);
+                    }
+                    store8(out + (row0 + r) * C + c * 8, y);
+                }
             }
-            store8(orow + c * 8, y);
         }
     }
+}
+
+template <typename T>
+void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_t rows, int64_t C, float eps, void *out,
+                      hipStream_t s) {
+    const int nch = (int)vtm::cdiv(C, 512);
+    const int R = nch == 1 ? 4 : 2;
+    const dim3 grid((unsigned)vtm::cdiv(rows, (int64_t)WAVES_PER_BLOCK * R)), block(WAVES_PER_BLOCK * 64);
+#define VTM_LN(NCH, RR)                                                                                               \
+    hipLaunchKernelGGL((layernorm_kernel<T, NCH, RR>), grid, block, 0, s, (const T *)x, (const T *)gamma, (const T *)beta, \
+                       rows, (int)C, eps, (T *)out)
+    switch (nch) {
+        case 1: VTM_LN(1, 4); break;
+        case 2: VTM_LN(2, 2); break;
+        case 3: VTM_LN(3, 2); break;
+        default: VTM_LN(4, 2); break;
+    }
+#undef VTM_LN
 }
 
 }  // namespace
@@ -114,21 +155,11 @@ VTM_EXPORT int vtm_layernorm(const void *x, const void *gamma, const void *beta,
     VTM_REQUIRE(C > 0 && C % 8 == 0 && C <= 64 * 8 * MAX_CHUNKS, "vtm_layernorm: C must be a multiple of 8, <= %d",
                 64 * 8 * MAX_CHUNKS);
     if (rows == 0) return VTM_OK;
-    const dim3 grid((unsigned)vtm::cdiv(rows, ROWS_PER_BLOCK)), block(ROWS_PER_BLOCK * 64);
     hipStream_t s = vtm::as_stream(stream);
     switch (dtype) {
-        case VTM_F32:
-            hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, (const float *)x, (const float *)gamma,
-                               (const float *)beta, rows, (int)C, eps, (float *)out);
-            break;
-        case VTM_F16:
-            hipLaunchKernelGGL(layernorm_kernel<__half>, grid, block, 0, s, (const __half *)x, (const __half *)gamma,
-                               (const __half *)beta, rows, (int)C, eps, (__half *)out);
-            break;
-        case VTM_BF16:
-            hipLaunchKernelGGL(layernorm_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x, (const vtm_bf16 *)gamma,
-                               (const vtm_bf16 *)beta, rows, (int)C, eps, (vtm_bf16 *)out);
-            break;
+        case VTM_F32: launch_layernorm<float>(x, gamma, beta, rows, C, eps, out, s); break;
+        case VTM_F16: launch_layernorm<__half>(x, gamma, beta, rows, C, eps, out, s); break;
+        case VTM_BF16: launch_layernorm<vtm_bf16>(x, gamma, beta, rows, C, eps, out, s); break;
         default: return vtm::fail(VTM_EINVAL, "vtm_layernorm: unsupported dtype %d", dtype);
     }
     return vtm::launch_status("vtm_layernorm");
