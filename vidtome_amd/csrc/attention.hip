@@ -516,7 +516,6 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             // the shift still holds.  Otherwise -- the first tile, or scores that outgrew the shift by more than
             // 2^8, possibly up to inf in P -- the tile is redone the exact way: scores again, maximum, new shift.
             const elem *vp = sV + buf * SV_TILE + l15 * VT_STRIDE + (g16 & 1) * 16 + (g16 >> 1) * 8;
-            vec a[DV16];   // V^T fragments of the first 32 keys, fetched before the exps
 #pragma unroll
             for (int st = 0; st < 4; ++st) softmax_step(st);
             uint32_t pw[16];
@@ -541,6 +540,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             // 2 ks + (g16 & 1), lane half g16 >> 1 -- in the V^T tile that is ONE 16-byte piece (see voff)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                vec a[DV16];
 #pragma unroll
                 for (int dv = 0; dv < DV16; ++dv)
                     a[dv] = *reinterpret_cast<const vec *>(vp + ks * 32 + dv * 16 * VT_STRIDE);
