@@ -10,8 +10,9 @@ transformer-block sites (10 merged: 5x N=4096/C=320/d=40 and 5x N=1024/C=640/d=8
 batch 2 (CFG [uncond | cond]) x 16 frames, local merge 0.5 + global merge 0.5 in steady state (the
 block's anchor tokens were populated by a preceding chunk, as for every chunk but the first of a step).
 Synthetic fp16 hidden states (frame-correlated), random-init weights; inputs are resident in HBM before
-the timed region.  N > 1: one process per GPU, each rank runs its own chunk (weak scaling, no data-path
-collective in this mode); value = chunks-steps per second over all ranks.
+the timed region.  N > 1: one process per GPU, each rank runs its own chunk (weak scaling); local merging needs
+no collective, the global level takes its anchor tokens from an RCCL all-gather of every rank's local merged tokens
+per merging block (chunk_parallel.AllGatherExchange); value = chunk-steps per second over all ranks.
 
 The JSON line also carries
   roofline:     the dominant kernel (attention_kernel: flash attention over the merged tokens, fp16 MFMA), its
@@ -28,6 +29,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails in hipIpcGetMemHandle)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
