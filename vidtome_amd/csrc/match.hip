@@ -34,7 +34,6 @@ constexpr int BD = 128;   // dst rows per tile (MFMA A operand, via LDS)
 constexpr int BS = 256;   // src rows per workgroup (MFMA B operand, registers): 64 per wave
 constexpr int BK = 32;    // channels per pipeline step = 4 groups of 8
 constexpr int THREADS = 256;
-constexpr int PANEL_ROWS_BYTES = 16;  // one row of one panel: 4 floats
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;

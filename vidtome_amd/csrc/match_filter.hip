@@ -594,7 +594,7 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     L.al = take((size_t)B * L.C64 * L.Ns_pad * 2);
     L.bh = take((size_t)B * L.C64 * L.Nd_pad * 2);
     L.bl = take((size_t)B * L.C64 * L.Nd_pad * 2);
-    L.amax = take((size_t)rows_out * 4);      // amax, cnt and flags are contiguous: one memset
+    L.amax = take((size_t)rows_out * 4);      // amax, cnt and flags are contiguous: cleared together
     L.cnt = take((size_t)rows_out * 4);
     L.flags = take(256);
     L.cand = take((size_t)rows_out * CAP * 8);
@@ -638,11 +638,10 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     float *aop = (float *)(w + L.aop), *bop = (float *)(w + L.bop);
     const int64_t rows_out = align ? Ns : B * Ns;
 
-    // amax, cnt and flags start from zero; `best` is zeroed by split_operand
-    hipError_t e = hipMemsetAsync(w + L.amax, 0, (L.cand - L.amax), s);
-    if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: memset: %s", hipGetErrorString(e));
-
-    if (int rc = vtm::launch_row_norms(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, s, b_rows, Nd, nb)) return rc;
+    // amax, cnt and flags start from zero (cleared by the row-norm launch); `best` is zeroed by split_operand
+    if (int rc = vtm::launch_row_norms(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, s, b_rows, Nd, nb, w + L.amax,
+                                       L.cand - L.amax))
+        return rc;
 
     VTM_REQUIRE(dtype == VTM_F32 || dtype == VTM_F16 || dtype == VTM_BF16, "vtm_match_filtered: bad dtype");
     {
@@ -722,7 +721,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     if (int rc = vtm::launch_match(aop, bop, B, Ns, Nd, L.Ns_pad, L.Nd_pad, L.C32, align, best, flags, false, s))
         return rc;
     if (flags_out) {
-        e = hipMemcpyAsync(flags_out, flags, 4 * sizeof(int), hipMemcpyDeviceToDevice, s);
+        const hipError_t e = hipMemcpyAsync(flags_out, flags, 4 * sizeof(int), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: copy: %s", hipGetErrorString(e));
     }
     return VTM_OK;

@@ -29,9 +29,12 @@ __global__ __launch_bounds__(256) void row_norms(const T *__restrict__ x0, int64
                                                  int64_t C, const int32_t *__restrict__ rows,
                                                  int64_t n, float *__restrict__ norms,
                                                  const int32_t *__restrict__ rows2, int64_t n2,
-                                                 float *__restrict__ norms2) {
+                                                 float *__restrict__ norms2, uint32_t *__restrict__ zero,
+                                                 int64_t zero_words) {
     // one launch may serve two row lists (the src and the dst rows of a match): threads >= B*n take the second
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // ... and clear a scratch region of the caller (the filtered matcher's counters: saves a memset launch)
+    for (int64_t w = idx; w < zero_words; w += (int64_t)gridDim.x * blockDim.x) zero[w] = 0u;
     if (idx >= B * n) {
         idx -= B * n;
         rows = rows2;
@@ -117,7 +120,8 @@ int run(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, int64
     if (B * n > 0) {
         const int64_t blocks = vtm::cdiv(B * n, 256);
         hipLaunchKernelGGL(row_norms<T>, dim3((unsigned)blocks), dim3(256), 0, s, (const T *)x0, P0,
-                           (const T *)x1, P1, B, C, rows, n, norms, (const int32_t *)nullptr, (int64_t)0, (float *)nullptr);
+                           (const T *)x1, P1, B, C, rows, n, norms, (const int32_t *)nullptr, (int64_t)0, (float *)nullptr,
+                           (uint32_t *)nullptr, (int64_t)0);
     }
     const int64_t total = B * n_pad * (C_pad / 8);
     if (total > 0) {
@@ -135,21 +139,23 @@ namespace vtm {
 // shared with match_filter.hip: the canonical row norms of gathered pool rows (same kernel, same bits)
 int launch_row_norms(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B, int64_t C,
                      const int32_t *rows, int64_t n, float *norms, hipStream_t s, const int32_t *rows2, int64_t n2,
-                     float *norms2) {
+                     float *norms2, void *zero, size_t zero_bytes) {
+    uint32_t *zp = static_cast<uint32_t *>(zero);
+    const int64_t zw = (int64_t)(zero_bytes / 4);   // callers pass 4-byte multiples
     if (B * (n + n2) <= 0) return VTM_OK;
     const dim3 grid((unsigned)cdiv(B * (n + n2), 256)), block(256);
     switch (dtype) {
         case VTM_F32:
             hipLaunchKernelGGL(row_norms<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1, B,
-                               C, rows, n, norms, rows2, n2, norms2);
+                               C, rows, n, norms, rows2, n2, norms2, zp, zw);
             break;
         case VTM_F16:
             hipLaunchKernelGGL(row_norms<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1, P1,
-                               B, C, rows, n, norms, rows2, n2, norms2);
+                               B, C, rows, n, norms, rows2, n2, norms2, zp, zw);
             break;
         case VTM_BF16:
             hipLaunchKernelGGL(row_norms<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0, (const vtm_bf16 *)x1,
-                               P1, B, C, rows, n, norms, rows2, n2, norms2);
+                               P1, B, C, rows, n, norms, rows2, n2, norms2, zp, zw);
             break;
         default: return fail(VTM_EINVAL, "unsupported dtype %d", dtype);
     }
