@@ -207,8 +207,9 @@ int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const 
 
 /* Optional workspace of vtm_attention / vtm_attention_kv (0 = none needed).  All workgroups of an attention launch
  * take the same time; when the last round of workgroups would leave most of the chip idle, those query blocks are
- * split along the key axis into a second launch whose partial results (fp32 accumulators, running max, denominator)
- * live in this workspace and are merged by a third kernel.  ws may be NULL (single launch, slower for such shapes). */
+ * split along the key axis into short workgroups (same launch, behind the whole ones) whose partial results (fp32
+ * accumulators, running max, denominator) live in this workspace and are merged by a second kernel.  ws may be NULL
+ * (no splitting, slower for such shapes). */
 size_t vtm_attention_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64_t Mk, int64_t d);
 
 /* The same kernel with separate query / key lengths: the block's cross-attention `self.attn2(...)`

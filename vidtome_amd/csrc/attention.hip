@@ -234,12 +234,13 @@ template <typename T, int D>
 __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1)) void attention_kernel(
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
-    int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t id0,
-    int nsplit, float *__restrict__ partial) {
+    int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t nwhole,
+    int nsplit_tail, float *__restrict__ partial_base) {
     // M / Mp: queries per sample and their row stride; Mk / Mkp: keys per sample and the row stride of k
     // (self-attention passes the same values; cross-attention, patch.py:178-183, has Mk = 77).
-    // Work decomposition: workgroup = (query block, head, sample) numbered id0 + blockIdx.x / nsplit, query blocks
-    // fastest; with nsplit > 1 a workgroup covers only the key tiles of split blockIdx.x % nsplit and leaves its
+    // Work decomposition: work item = (query block, head, sample), query blocks fastest.  Workgroups [0, nwhole) take
+    // one item each and all its key tiles; the workgroups behind them share the remaining items `nsplit_tail` ways
+    // along the key axis: each covers the key tiles of one split and leaves its
     // unnormalised accumulators, running max and denominator in `partial` for attention_combine_kernel (used for
     // the query blocks that do not fill a whole round of the chip, see launch()).
     using F = Frag<T>;
@@ -274,8 +275,12 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int l15 = lane & 15, g16 = lane >> 4;   // PV16 operand coordinates
-    const int64_t lin = id0 + blockIdx.x / nsplit;
-    const int split = (int)(blockIdx.x % nsplit);
+    const bool tail_wg = (int64_t)blockIdx.x >= nwhole;
+    const int64_t tail_id = (int64_t)blockIdx.x - nwhole;
+    const int nsplit = tail_wg ? nsplit_tail : 1;
+    const int64_t lin = tail_wg ? nwhole + tail_id / nsplit : (int64_t)blockIdx.x;
+    const int split = tail_wg ? (int)(tail_id % nsplit) : 0;
+    float *partial = tail_wg ? partial_base + tail_id * rec_floats(D) * (waves_for(D) * 64) : nullptr;
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t bq = b % src_batch;  // PnP injection: q/k of the source sample (pnp_utils.py:57-67)
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
@@ -607,8 +612,8 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     if (t < te) tile(true_type{}, buf, t * KV);
 
     if (partial) {   // split workgroup: hand the raw state to attention_combine_kernel
-        constexpr int NA = acc_floats(D), NM = max_floats(D), REC = rec_floats(D);
-        float *pp = partial + (int64_t)blockIdx.x * REC * NT + tid;
+        constexpr int NA = acc_floats(D), NM = max_floats(D);
+        float *pp = partial + tid;
         if constexpr (PV16) {
 #pragma unroll
             for (int r = 0; r < NA; ++r) pp[r * NT] = o16[r >> 3][(r >> 2) & 1][r & 3];
@@ -630,12 +635,13 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
 
 // Tail plan.  All workgroups of a launch take the same time, so the launch runs in "rounds" of as many workgroups
 // as the chip holds (slots); the last, partly filled round leaves most CUs idle for a whole workgroup time (cfg-2
-// mid blocks: 272 workgroups on 256 slots -> the launch takes two rounds for 6 % more work than one).  The
-// workgroups of that last round are therefore split along the key axis into `nsplit` shorter ones that fill the
-// chip, and merged by attention_combine_kernel.
+// mid blocks: 272 workgroups on 256 slots -> two rounds for 6 % more work than one; top blocks: 4.25 rounds).  The
+// work items of that last round are therefore split along the key axis into `nsplit` shorter workgroups that fill
+// the chip -- in the SAME launch, behind the whole ones, so they start as the slots of the last whole round free
+// up -- and merged by attention_combine_kernel.
 struct TailPlan {
     int64_t nqb, total, full;   // query blocks per (sample, head), all workgroups, workgroups in whole rounds
-    int nsplit;                 // splits of each remaining workgroup (1 = no tail launch)
+    int nsplit;                 // splits of each remaining work item (1 = none)
     size_t ws_bytes;
 };
 
@@ -662,10 +668,10 @@ TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk) {
     const int64_t rem = p.total - p.full, ntiles = vtm::cdiv(Mk, KV);
     p.nsplit = 1;
     p.ws_bytes = 0;
-    // worth it only behind at least one whole round, for long key axes, and when the last round is nearly empty:
-    // a workgroup that has its CU to itself already runs about twice as fast as in a full round, so a last round
-    // of a quarter of the slots costs ~half a round either way (measured: 128 of 512 -> no gain, 16 of 256 -> -18 %)
-    if (p.full > 0 && rem > 0 && rem * 8 <= slots && ntiles >= 32) {
+    // worth it only behind at least one whole round, for long key axes, and when the last round is at most a
+    // quarter full (a workgroup that has its CU to itself already runs about twice as fast as in a full round;
+    // measured: 128 of 512 -> -7 %, 16 of 256 -> -18 %, 192 or 256 of 512 -> no gain)
+    if (p.full > 0 && rem > 0 && rem * 4 <= slots && ntiles >= 32) {
         int64_t ns = slots / rem;
         if (ns > 16) ns = 16;
         if (ns > ntiles / 8) ns = ntiles / 8;
@@ -700,17 +706,15 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
     const float scale_log2e = scale * 1.4426950408889634f;
     const int64_t src_batch = B / share_groups;
     VTM_REQUIRE(p.total < (1ll << 31) / 16, "vtm_attention: grid too large");
-    hipLaunchKernelGGL((attention_kernel<T, D>), dim3((unsigned)p.full), dim3(WAVES * 64), lds, s, (const T *)q, ldq,
-                       (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp, scale_log2e, src_batch,
-                       p.nqb, (int64_t)0, 1, (float *)nullptr);
-    if (p.nsplit > 1) {
-        const int64_t rem = p.total - p.full;
-        hipLaunchKernelGGL((attention_kernel<T, D>), dim3((unsigned)(rem * p.nsplit)), dim3(WAVES * 64), lds, s,
-                           (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
-                           scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws);
+    // one launch: the whole workgroups first, the key-split ones of the last round behind them (they start as the
+    // slots of the last whole round free up -- no launch boundary to drain)
+    const int64_t rem = p.total - p.full;
+    hipLaunchKernelGGL((attention_kernel<T, D>), dim3((unsigned)(p.full + rem * p.nsplit)), dim3(WAVES * 64), lds, s,
+                       (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
+                       scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws);
+    if (p.nsplit > 1)
         hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem), dim3(WAVES * 64), 0, s,
                            (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit);
-    }
     return vtm::launch_status("vtm_attention");
 }
 
