@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Sweep the dst-split count of the filtered matcher (VTM_DEBUG_NSPLIT hook) over the cfg-2 shapes.
+    python tools/sweep_nsplit.py            (needs an MI355X)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vidtome_amd import _lib  # noqa: E402
+
+SHAPES = {"top_l1": (2, 49152, 16384, 320), "top_l2": (2, 12288, 28672, 320), "top_g": (2, 34816, 34816, 320),
+          "mid_l1": (2, 12288, 4096, 640), "mid_l2": (2, 3072, 7168, 640), "mid_g": (2, 8704, 8704, 640)}
+
+
+def timeit(fn, iters=7):
+    fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2]
+
+
+def main():
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for name, (B, Ns, Nd, C) in SHAPES.items():
+        # frame-correlated tokens like bench.py's: every src row has a near copy among the dst rows
+        base = torch.randn(B, Nd, C, generator=g, device="cuda")
+        idx = torch.arange(Ns + Nd, device="cuda") % Nd
+        x = (base[:, idx] + 0.1 * torch.randn(B, Ns + Nd, C, generator=g, device="cuda")).half()
+        ra = torch.arange(Ns, dtype=torch.int32, device="cuda").expand(B, Ns).contiguous()
+        rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device="cuda").expand(B, Nd).contiguous()
+        os.environ.pop("VTM_DEBUG_NSPLIT", None)
+        ref = _lib.match_filtered(x, None, ra, rb, False)
+        out = [f"default {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}"]
+        for ns in range(2, 9):
+            os.environ["VTM_DEBUG_NSPLIT"] = str(ns)
+            assert torch.equal(_lib.match_filtered(x, None, ra, rb, False), ref)
+            out.append(f"{ns}: {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}")
+        print(f"{name:7s} us  " + "  ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -645,17 +645,6 @@ struct TailPlan {
     size_t ws_bytes;
 };
 
-inline int device_cus() {
-    static int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        return n;
-    }();
-    return cus;
-}
-
 template <int D>
 TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk) {
     constexpr int WAVES = waves_for(D), QB = WAVES * QW;
@@ -663,7 +652,7 @@ TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk) {
     TailPlan p;
     p.nqb = vtm::cdiv(Mq, QB);
     p.total = p.nqb * h * B;
-    const int64_t slots = (int64_t)device_cus() * wg_per_cu;
+    const int64_t slots = (int64_t)vtm::device_cus() * wg_per_cu;
     p.full = p.total / slots * slots;
     const int64_t rem = p.total - p.full, ntiles = vtm::cdiv(Mk, KV);
     p.nsplit = 1;

@@ -35,6 +35,18 @@ template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; 
 template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
 template <> __device__ __forceinline__ float to_f32<vtm_bf16>(vtm_bf16 v) { return __bfloat162float(v); }
 
+// compute units of the current device (256 on MI355X; 8 XCDs of 32)
+inline int device_cus() {
+    static int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    return cus;
+}
+
 // internal cross-file launchers (not part of the C ABI)
 int launch_row_norms(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B, int64_t C,
                      const int32_t *rows, int64_t n, float *norms, hipStream_t s, const int32_t *rows2 = nullptr,

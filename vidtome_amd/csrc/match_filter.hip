@@ -23,6 +23,8 @@
 // the ordinary fp32 kernel (match.hip) from a no-op into a full recomputation of the call.
 #include "common.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -667,15 +669,6 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
 
     {
         const int ns_tiles = (int)(L.Ns_pad / FBS), nd_tiles = (int)(L.Nd_pad / FBD);
-        // dst splits: enough workgroups to fill the chip, >= 4 dst tiles each, at most 8 (every split
-        // contributes >= 1 candidate per row), and 8 whenever the dst axis is long enough (L2 patching)
-        int64_t want = vtm::cdiv(1536, (int64_t)ns_tiles * B);
-        int nsplit = (int)(want < 1 ? 1 : want);
-        if (nd_tiles >= 32) nsplit = 8;
-        if (nsplit > nd_tiles / 4) nsplit = nd_tiles / 4 > 0 ? nd_tiles / 4 : 1;
-        if (nsplit > 8) nsplit = 8;
-        const int tiles_per_split = (int)vtm::cdiv(nd_tiles, nsplit);
-        nsplit = (int)vtm::cdiv(nd_tiles, tiles_per_split);
         const int total_src_tiles = (int)(B * ns_tiles);
         // patch size: at most 16 src tiles while their (hi) operands fit comfortably in one L2 (16 x 256 rows x C x
         // 2 B <= 3 MiB), else 8 -- and balanced: patch g runs on XCD g % 8, so the tiles are cut into equal patches
@@ -686,6 +679,34 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         const int patches_per_xcd = (int)vtm::cdiv(tiles_per_xcd, max_patch);
         const int patch_tiles = (int)vtm::cdiv(tiles_per_xcd, patches_per_xcd);
         const int ngroups = (int)vtm::cdiv(total_src_tiles, patch_tiles);
+        // dst splits: enough workgroups to fill the chip, >= 4 dst tiles each, at most 8 (every split
+        // contributes >= 1 candidate per row), and 8 whenever the dst axis is long enough (L2 patching)
+        int64_t want = vtm::cdiv(1536, (int64_t)ns_tiles * B);
+        int nsplit = (int)(want < 1 ? 1 : want);
+        if (nd_tiles >= 32) nsplit = 8;
+        if (nsplit > nd_tiles / 4) nsplit = nd_tiles / 4 > 0 ? nd_tiles / 4 : 1;
+        if (nsplit > 8) nsplit = 8;
+        // workgroups one XCD has to run (2 per CU at a time) for a split count
+        auto wgs_per_xcd = [&](int ns) {
+            const int tps = (int)vtm::cdiv(nd_tiles, ns);
+            return patches_per_xcd * patch_tiles * (int)vtm::cdiv(nd_tiles, tps);
+        };
+        // a bit more than one round of workgroups takes almost two: 7 or 6 splits instead of 8 when that
+        // brings an XCD's share down to a single round (cfg-2 mid global level: 80 -> 60 workgroups, -15 %)
+        if (nsplit == 8) {
+            const int slots = vtm::device_cus() / 8 * 2;
+            for (int ns = 7; ns >= 6; --ns)
+                if (wgs_per_xcd(8) > slots && wgs_per_xcd(ns) <= slots) {
+                    nsplit = ns;
+                    break;
+                }
+        }
+        if (const char *dbg = getenv("VTM_DEBUG_NSPLIT")) {   // tuning hook (tools/sweep_nsplit.py)
+            const int v = atoi(dbg);
+            if (v >= 1 && v <= 8 && v <= nd_tiles) nsplit = v;
+        }
+        const int tiles_per_split = (int)vtm::cdiv(nd_tiles, nsplit);
+        nsplit = (int)vtm::cdiv(nd_tiles, tiles_per_split);
         const int64_t grid = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit;
         hipLaunchKernelGGL(filter_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
                            L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles, amax,
