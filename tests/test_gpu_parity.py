@@ -181,6 +181,16 @@ def test_match_filtered_full_size(L):
     _filtered_vs_exact(L, x, Ns, Nd, False, expect_flag=0)
 
 
+def test_match_filtered_mid_global_size(L):
+    """cfg-2 mid-block global level (8 704 x 8 704, C = 640): the shape whose dst-split count is lowered to 6 so that
+    an XCD's share of workgroups fits one round (match_filter.hip launcher) -- filtered == exact, no fallback."""
+    g = torch.Generator().manual_seed(14)
+    B, Ns, Nd, C = 2, 8704, 8704, 640
+    base = torch.randn(B, Nd, C, generator=g)
+    x = (base.repeat(1, 2, 1) + 0.3 * torch.randn(B, Ns + Nd, C, generator=g)).half().to(DEV)
+    _filtered_vs_exact(L, x, Ns, Nd, False, expect_flag=0)
+
+
 @pytest.mark.parametrize("n", [1, 17, 1000, 1024, 5000, 49152, 110592])
 def test_sort_desc(L, oracle, n):
     rng = np.random.default_rng(n)
