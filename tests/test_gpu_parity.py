@@ -558,6 +558,36 @@ def test_attention_fuzz_vs_torch_fp32(L):
         assert err <= 1e-3 * max(1.0, float(ref.abs().max())), (case, B, h, d, Mq, Mk, err)
 
 
+def test_attention_d40_wide_scores_fuzz(L):
+    """d = 40 carries the softmax shift inside the contraction and only checks the maximum after the exps (on the
+    packed P): inputs scaled so that the scores span tens of log2 units make that check fire in many tiles, in
+    both directions (a late large score, long runs of very negative ones)."""
+    g = torch.Generator().manual_seed(29)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    d, worst = 40, 0.0
+    for case in range(24):
+        B, h = ri(1, 2), ri(1, 3)
+        Mk, Mq = ri(65, 2500), ri(1, 900)
+        sq, sk = [1.0, 2.0, 4.0][case % 3], [1.0, 3.0][case % 2]
+        C = h * d
+        Mqp, Mkp = (Mq + 7) // 8 * 8, (Mk + 7) // 8 * 8
+        q, k, v = torch.zeros(B, Mqp, C), torch.zeros(B, Mkp, C), torch.zeros(B, Mkp, C)
+        q[:, :Mq] = sq * torch.randn(B, Mq, C, generator=g)
+        k[:, :Mk] = sk * torch.randn(B, Mk, C, generator=g)
+        v[:, :Mk] = torch.randn(B, Mk, C, generator=g)
+        if case % 4 == 1:   # ascending key norms: the running maximum keeps growing along the key axis
+            k[:, :Mk] *= torch.linspace(0.2, 1.0, Mk)[None, :, None]
+        q, k, v = q.half().to(DEV), k.half().to(DEV), v.half().to(DEV)
+        o = L.attention_kv(q, k, v.transpose(1, 2).contiguous(), h, Mq, Mk, d ** -0.5)[:, :Mq].float()
+        assert torch.isfinite(o).all(), (case, B, h, Mq, Mk)
+        qh, kh, vh = (t.float().reshape(B, -1, h, d).transpose(1, 2) for t in (q[:, :Mq], k[:, :Mk], v[:, :Mk]))
+        ref = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, dim=-1) @ vh).transpose(1, 2).reshape(B, Mq, C)
+        err = float((o - ref).abs().max())
+        worst = max(worst, err)
+        # peaky softmax: the output is nearly one V row, whose fp16 rounding (|v| up to ~4.5) is part of the budget
+        assert err <= 2e-3 * max(1.0, float(ref.abs().max())), (case, B, h, Mq, Mk, sq, sk, err)
+
+
 @pytest.mark.parametrize("d,Mq", [(80, 8704), (40, 8448)])
 def test_attention_split_last_round_equals_single_launch(L, d, Mq):
     """A launch whose last round of workgroups is nearly empty runs those query blocks as key-split workgroups plus
