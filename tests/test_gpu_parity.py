@@ -584,7 +584,9 @@ def test_attention_d40_wide_scores_fuzz(L):
         ref = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, dim=-1) @ vh).transpose(1, 2).reshape(B, Mq, C)
         err = float((o - ref).abs().max())
         worst = max(worst, err)
-        # peaky softmax: the output is nearly one V row, whose fp16 rounding (|v| up to ~4.5) is part of the budget
+        # a stress test of the shift logic, not of the accuracy contract (pinned at 1e-3 on realistic score ranges by
+        # the tests above): with scores of up to +-60 log2 units the one fp16 rounding of the pre-scaled query
+        # (relative 2^-12 per product) is worth ~1e-3 in the softmax weights of the few keys that compete
         assert err <= 2e-3 * max(1.0, float(ref.abs().max())), (case, B, h, Mq, Mk, sq, sk, err)
 
 
