@@ -55,6 +55,27 @@ def test_error_convention(built):
     assert L.vtm_attention(None, 8, None, 8, None, 8, None, 8, 1, 1, 1, 8, 8, 40, 1.0, 1, None, 0, None) == -1
 
 
+def test_workspace_sizing_is_pure_host_arithmetic(built):
+    """The *_ws_bytes exports are host-side planners (no device needed; the CU count defaults to MI355X's 256):
+    the attention tail plan asks for a workspace exactly when the last round of workgroups is at most a quarter
+    full behind at least one whole round (attention.hip, plan_tail)."""
+    from vidtome_amd import _lib
+    L = _lib.lib()
+    ws = L.vtm_attention_ws_bytes
+    # d = 40: 256-query workgroups, 512 resident -> 2 x 8 x 128 = 2048 = 4.00 rounds / 2176 = 4.25 / 2304 = 4.5
+    assert ws(2, 8, 32768, 52224, 40) == 0
+    assert ws(2, 8, 34816, 52224, 40) > 0
+    assert ws(2, 8, 36864, 52224, 40) == 0
+    # d = 80: 512-query workgroups, 256 resident -> cfg-2 mid blocks: 17 x 16 = 272 workgroups
+    assert ws(2, 8, 8704, 13056, 80) > 0
+    assert ws(2, 8, 8192, 13056, 80) == 0
+    # short key axes and launches below one round are never split
+    assert ws(2, 8, 34816, 77, 40) == 0 and ws(1, 1, 300, 52224, 40) == 0
+    assert ws(0, 8, 34816, 52224, 40) == 0 and ws(2, 8, 34816, 52224, 41) == 0
+    assert L.vtm_sort_ws_bytes(2, 49152) >= 2 * 49152 * 16 and L.vtm_sort_ws_bytes(0, 10) == 0
+    assert L.vtm_match_filtered_ws_bytes(2, 320, 49152, 16384, 0) > L.vtm_match_filtered_ws_bytes(2, 320, 4096, 4096, 0) > 0
+
+
 def test_cpu_tensors_fail_loudly(built):
     """There is no CPU fallback: the mirrored API raises on CPU tensors instead of computing elsewhere."""
     from vidtome_amd import merge
