@@ -118,7 +118,8 @@ def pmc_traffic():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             d = json.load(f)
-        for key in ("attention_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224 (r01_f)",
+        for key in ("attention_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224 (r01_k)",
+                    "attention_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224 (r01_f)",
                     "attention_kernel<half,40> B=2 h=8 M=52224 (r01_e)", "attention_kernel<half,40> B=2 h=8 M=52224"):
             if key in d:
                 return int(d[key]["hbm_bytes_per_launch"])
