@@ -393,8 +393,11 @@ def test_chain_golden_gpu(L, name):
                         ti += 1
                     # merged tokens are row copies of the (torch) LayerNorm output: tight tolerance
                     np.testing.assert_allclose(plan.merged[:, :plan.M].cpu().numpy(), ref_merged, rtol=1e-5, atol=1e-6)
-                # attention runs in fp16 MFMA on this fp32 fixture: 1e-3-class tolerance on the block output
-                np.testing.assert_allclose(outs[bi].cpu().numpy(), z[f"c{ck}/b{bi}/out"], rtol=2e-2, atol=4e-3)
+                # fp32 fixture: projections run in fp32, the attention core on the fp16 MFMA (fp32 accumulate):
+                # the block output is held to north_star's 1e-3 (of the output scale)
+                ref_out = z[f"c{ck}/b{bi}/out"]
+                err = np.abs(outs[bi].cpu().numpy() - ref_out).max()
+                assert err < 1e-3 * max(1.0, np.abs(ref_out).max()), (ck, bi, err)
             assert f"c{ck}/t{ti}/kind" not in z.files
             gts = vidtome_amd.collect_from_patch(unet, attr="global_tokens")
             for bi, nme in enumerate(names):

@@ -109,7 +109,7 @@ def test_patch_api_mechanics(built):
         ("local_merge_ratio", 0.9), ("merge_global", False), ("global_merge_ratio", 0.8), ("max_downsample", 2),
         ("seed", 123), ("batch_size", 2), ("include_control", False), ("align_batch", False),
         ("target_stride", 4), ("global_rand", 0.5)]                                     # patch.py:234-245
-    out = vidtome_amd.apply_patch(pipe if False else unet, local_merge_ratio=0.5, merge_global=True)
+    out = vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True)
     assert out is unet
     blocks = list(unet.blocks())
     assert all(b.__class__.__name__ == "ToMeBlock" and b._parent.__name__ == "BasicTransformerBlock" for b in blocks)
@@ -161,3 +161,175 @@ def test_pnp_closure_detection():
     assert vpatch._pnp_num_inputs(a) == 3
     a.vtm_num_inputs = 2
     assert vpatch._pnp_num_inputs(a) == 2
+
+
+class _ControlNet(torch.nn.Module):                      # a second patched tree, named like Diffusers' ModelMixin models
+    def __init__(self):
+        super().__init__()
+        from standin import BasicTransformerBlock
+        self.blocks = torch.nn.ModuleList([BasicTransformerBlock(16, 2) for _ in range(2)])
+
+
+class DiffusionPipeline:                                 # apply_patch tests class NAMES in the MRO (patch.py:279-280)
+    def __init__(self, unet):
+        self.unet = unet
+
+
+class StableDiffusionControlNetPipeline(DiffusionPipeline):                       # ... and this one at patch.py:292
+    def __init__(self, unet, controlnet):
+        self.unet, self.controlnet = unet, controlnet
+
+
+def test_apply_patch_on_pipelines_and_controlnet(built):
+    """patch.py:279-295, 337-355: a pipeline is patched through `.unet`; `include_control` only acts on a class named
+    StableDiffusionControlNetPipeline and then patches `.controlnet` with its own _tome_info; remove_patch looks for
+    the ControlNet on the UNet (the reference's quirk), so a pipeline's ControlNet stays patched."""
+    import vidtome_amd
+    from standin import Pipe, StandInUNet
+
+    # (1) a plain pipeline object (class not named like Diffusers') is rejected like any non-diffusers model
+    with pytest.raises(RuntimeError, match="Stable Diffusion / Latent Diffusion"):
+        vidtome_amd.apply_patch(Pipe(StandInUNet(16, 2)))
+    # (2) a DiffusionPipeline: patched through .unet, the pipeline object itself is returned
+    unet = StandInUNet(16, 2)
+    pipe = DiffusionPipeline(unet)
+    assert vidtome_amd.apply_patch(pipe, merge_global=True, batch_size=3) is pipe
+    assert all(b.__class__.__name__ == "ToMeBlock" for b in unet.blocks())
+    assert unet._tome_info["args"]["batch_size"] == 3 and not hasattr(pipe, "_tome_info")
+    assert vidtome_amd.update_patch(pipe, global_tokens=None) is unet            # the reference returns the tree
+    assert set(vidtome_amd.collect_from_patch(pipe, attr="global_tokens")) == \
+        {n for n, m in unet.named_modules() if hasattr(m, "_tome_info")}
+    assert vidtome_amd.remove_patch(pipe) is unet
+    assert all(b.__class__.__name__ == "BasicTransformerBlock" for b in unet.blocks())
+
+    # (3) ControlNet pipeline: untouched without include_control (what generate.py:97-98 does) ...
+    unet, cn = StandInUNet(16, 2), _ControlNet()
+    cpipe = StableDiffusionControlNetPipeline(unet, cn)
+    vidtome_amd.apply_patch(cpipe)
+    assert not hasattr(cn, "_tome_info") and all(b.__class__.__name__ == "BasicTransformerBlock" for b in cn.blocks)
+    # ... patched with it, with a _tome_info of its own (sizes are recorded per model, patch.py:297-313)
+    vidtome_amd.apply_patch(cpipe, include_control=True, local_merge_ratio=0.7)
+    assert all(b.__class__.__name__ == "ToMeBlock" for b in cn.blocks)
+    assert cn._tome_info is not unet._tome_info and cn._tome_info["args"]["local_merge_ratio"] == 0.7
+    assert all(b._tome_info is cn._tome_info for b in cn.blocks)
+    assert len(cn._tome_info["hooks"]) == 1 + len(cn.blocks)
+    # update / collect see both trees (they look for .controlnet on the object they are given, patch.py:361,376)
+    assert vidtome_amd.update_patch(cpipe, foo=7) is cn
+    assert unet.foo == 7 and cn.foo == 7 and all(b.foo == 7 for b in cn.blocks)
+    got = vidtome_amd.collect_from_patch(cpipe, attr="foo")
+    assert "blocks.0" in got and "up_blocks.1.attentions.0.transformer_blocks.0" in got
+    # remove_patch(pipe) unwraps to the UNet first and looks for .controlnet THERE: the ControlNet stays patched
+    assert vidtome_amd.remove_patch(cpipe) is unet
+    assert all(b.__class__.__name__ == "BasicTransformerBlock" for b in unet.blocks())
+    assert all(b.__class__.__name__ == "ToMeBlock" for b in cn.blocks) and len(cn._tome_info["hooks"]) == 3
+    # a UNet that carries the ControlNet as an attribute is cleaned completely (the case the quirk serves)
+    unet.controlnet = cn
+    assert vidtome_amd.remove_patch(unet) is cn
+    assert all(b.__class__.__name__ == "BasicTransformerBlock" for b in cn.blocks) and not cn._tome_info["hooks"]
+    # include_control on a pipeline with another name is ignored (patch.py:292)
+    other = DiffusionPipeline(StandInUNet(16, 2))
+    other.controlnet = _ControlNet()
+    vidtome_amd.apply_patch(other, include_control=True)
+    assert not hasattr(other.controlnet, "_tome_info")
+
+
+def test_fused_attention_predicate(built):
+    """The fused attn1 / attn2 path is taken only for the plain arithmetic; everything else calls the module."""
+    from standin import Attention
+    from vidtome_amd import patch as vpatch
+
+    class FakeCuda(torch.Tensor):          # predicate needs x.is_cuda; emulate it without a device
+        @property
+        def is_cuda(self):
+            return True
+
+    x = torch.zeros(2, 8, 64).as_subclass(FakeCuda)
+    ok = lambda a, **k: vpatch.fused_attention_ok(a, x, **k)
+    a = Attention(64, 2)
+    assert ok(a)
+    assert not vpatch.fused_attention_ok(a, torch.zeros(2, 8, 64))              # CPU tensor
+    b = Attention(48, 2)                                                          # head dim 24: no kernel instantiation
+    assert not vpatch.fused_attention_ok(b, torch.zeros(2, 8, 48).as_subclass(FakeCuda))
+
+    class LoRALinear(torch.nn.Module):                                            # PEFT-style wrapper, not a Linear
+        def __init__(self, base):
+            super().__init__()
+            self.base_layer = base
+            self.weight = base.weight
+
+    a = Attention(64, 2)
+    a.to_k = LoRALinear(a.to_k)
+    assert not ok(a)
+
+    class LoRACompatibleLinear(torch.nn.Linear):                                  # Diffusers' subclass
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.lora_layer = None
+    a = Attention(64, 2)
+    a.to_q = LoRACompatibleLinear(64, 64, bias=False)
+    assert ok(a)
+    a.to_q.lora_layer = torch.nn.Linear(64, 64)
+    assert not ok(a)
+    for attr, val in (("rescale_output_factor", 2.0), ("residual_connection", True), ("group_norm", torch.nn.Identity()),
+                      ("norm_cross", torch.nn.Identity())):
+        a = Attention(64, 2)
+        setattr(a, attr, val)
+        assert not ok(a), attr
+
+    class CustomProc:
+        pass
+
+    class AttnProcessor2_0:
+        pass
+    a = Attention(64, 2)
+    a.processor = CustomProc()
+    assert not ok(a)
+    a.processor = AttnProcessor2_0()
+    assert ok(a)
+    a.upcast_attention = True                         # SD-2.1: fp32 scores -- what the kernel does anyway
+    assert ok(a)
+    a = Attention(64, 2)
+    a.forward = lambda x, **k: x                      # replaced forward that is not the PnP closure
+    assert not ok(a)
+
+    def register(mod, num_inputs):                    # the reference's PnP closure IS understood (self-attention only)
+        def forward(x, encoder_hidden_states=None, attention_mask=None, **kw):
+            return x * num_inputs
+        mod.forward = forward
+    a = Attention(64, 2)
+    register(a, 3)
+    assert ok(a) and not ok(a, self_attn=False)
+
+
+def test_pnp_register_time_stamps_resnets(built):
+    """utils/pnp_utils.py:12-37 sets `t` on attn1, attn2 AND the down / up resnets (register_conv_control reads it)."""
+    from vidtome_amd import pnp
+
+    class Blk(torch.nn.Module):
+        def __init__(self, attn):
+            super().__init__()
+            self.resnets = torch.nn.ModuleList([torch.nn.Identity(), torch.nn.Identity()])
+            if attn:
+                t = torch.nn.Module()
+                t.transformer_blocks = torch.nn.ModuleList([torch.nn.Module()])
+                t.transformer_blocks[0].attn1 = torch.nn.Identity()
+                t.transformer_blocks[0].attn2 = torch.nn.Identity()
+                self.attentions = torch.nn.ModuleList([t])
+
+    class U(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.up_blocks = torch.nn.ModuleList([Blk(False), Blk(True)])
+            self.down_blocks = torch.nn.ModuleList([Blk(True), Blk(False)])
+            self.mid_block = Blk(True)
+
+    class P:
+        unet = U()
+    pnp.register_time(P, 481)
+    u = P.unet
+    for g in list(u.up_blocks) + list(u.down_blocks):
+        assert all(r.t == 481 for r in g.resnets)
+        for att in getattr(g, "attentions", []):
+            assert att.transformer_blocks[0].attn1.t == 481 and att.transformer_blocks[0].attn2.t == 481
+    assert u.mid_block.attentions[0].transformer_blocks[0].attn1.t == 481
+    assert not hasattr(u.mid_block.resnets[0], "t")                     # the reference leaves the mid resnets alone

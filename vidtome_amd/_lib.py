@@ -10,6 +10,7 @@ torch must be imported before the library is loaded so that both bind the same H
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 from typing import Optional, Tuple
 
@@ -88,7 +89,24 @@ def _check(rc: int, what: str) -> None:
 
 
 def _stream() -> int:
+    """Raw HIP stream the launch goes to: torch's current stream of the CURRENT device -- every wrapper below runs
+    under `_on_device`, which makes the operands' device the current one first."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def _on_device(fn):
+    """Run the wrapper with its first tensor argument's device as the current HIP device (a model moved to cuda:1
+    in a process whose current device is cuda:0 must launch on cuda:1's stream, not enqueue foreign pointers on
+    cuda:0).  The common case -- already current -- costs one integer comparison."""
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        dev = next((a.device if isinstance(a, torch.Tensor) else a for a in args
+                    if isinstance(a, (torch.Tensor, torch.device))), None)
+        if dev is None or dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev.index):
+            return fn(*args, **kwargs)
+    return guarded
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -119,6 +137,7 @@ def pad_k(c: int) -> int:
 
 
 # --------------------------------------------------------------------------------------------------
+@_on_device
 def normalize_gather(x0: torch.Tensor, x1: Optional[torch.Tensor], rows: torch.Tensor
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
     """rows (B, n) int32 pool ids -> (operand (B, C_pad/8, 2, n_pad, 4) fp32 k-panels, norms (B, n))."""
@@ -134,6 +153,7 @@ def normalize_gather(x0: torch.Tensor, x1: Optional[torch.Tensor], rows: torch.T
     return out, norms
 
 
+@_on_device
 def match(a: torch.Tensor, b: torch.Tensor, Ns: int, Nd: int, align: bool) -> torch.Tensor:
     """Packed (orderable(max) << 32 | ~argmax) per src row: (B, Ns) or (1, Ns) when aligned (int64 bits)."""
     B, G, _, Ns_pad, _ = a.shape
@@ -144,6 +164,7 @@ def match(a: torch.Tensor, b: torch.Tensor, Ns: int, Nd: int, align: bool) -> to
     return best
 
 
+@_on_device
 def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.Tensor, b_rows: torch.Tensor,
                    align: bool, want_flag: bool = False):
     """Same packed result as normalize_gather x2 + match, through the fp16-filter / fp32-refine path."""
@@ -161,6 +182,7 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
     return (best, flag) if want_flag else best
 
 
+@_on_device
 def decode_best(best: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     nm = torch.empty(best.shape, dtype=torch.float32, device=best.device)
     ni = torch.empty(best.shape, dtype=torch.int32, device=best.device)
@@ -168,6 +190,7 @@ def decode_best(best: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return nm, ni
 
 
+@_on_device
 def sort_desc(best: torch.Tensor) -> torch.Tensor:
     rows, n = best.shape
     perm = torch.empty((rows, n), dtype=torch.int32, device=best.device)
@@ -184,6 +207,7 @@ def partition_counts(N_in: int, unm_pre: int, tnum: int, ts: int, randf: int) ->
     return int(ns.value), int(nd.value)
 
 
+@_on_device
 def partition_local(cur: Optional[torch.Tensor], B: int, N_in: int, unm_pre: int, tnum: int, ts: int,
                     randf: int, device) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     Ns, Nd = partition_counts(N_in, unm_pre, tnum, ts, randf)
@@ -195,6 +219,7 @@ def partition_local(cur: Optional[torch.Tensor], B: int, N_in: int, unm_pre: int
     return a_pos, b_pos, a_rows, b_rows
 
 
+@_on_device
 def partition_global(cur_local: torch.Tensor, anchor_base: int, Mg: int, local_is_src: bool
                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     B, Ml = cur_local.shape
@@ -208,6 +233,7 @@ def partition_global(cur_local: torch.Tensor, anchor_base: int, Mg: int, local_i
     return a_pos, b_pos, a_rows, b_rows
 
 
+@_on_device
 def plan_apply(best, perm, a_pos, b_pos, a_rows, b_rows, r: int, align: bool, want_indices: bool):
     B, Ns = a_rows.shape
     Nd = b_rows.shape[1]
@@ -224,6 +250,7 @@ def plan_apply(best, perm, a_pos, b_pos, a_rows, b_rows, r: int, align: bool, wa
     return new_cur, inv, unm_idx, src_idx, dst_idx
 
 
+@_on_device
 def compose(inv_acc: Optional[torch.Tensor], inv_level: torch.Tensor, n: int, offset: int = 0) -> torch.Tensor:
     B, level_len = inv_level.shape
     out = torch.empty((B, n), dtype=torch.int32, device=inv_level.device)
@@ -232,6 +259,7 @@ def compose(inv_acc: Optional[torch.Tensor], inv_level: torch.Tensor, n: int, of
     return out
 
 
+@_on_device
 def gather_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], idx: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
     """out (B, M_pad, C): rows [0, M) = pool[idx]; rows >= M (padding up to a multiple of pad_to) are zero."""
     _req(x0, "x0"), _req(idx, "map")
@@ -245,6 +273,7 @@ def gather_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], idx: torch.Tensor,
     return out
 
 
+@_on_device
 def unmerge_add(y: torch.Tensor, inv: torch.Tensor, resid: Optional[torch.Tensor]) -> torch.Tensor:
     """out[b, i] = y[b, inv[b, i]] (+ resid[b, i]);  y is (B, Mp, C) (only rows < M are referenced)."""
     _req(y, "y"), _req(inv, "inv")
@@ -268,6 +297,7 @@ def _attention_ws(B: int, heads: int, Mq: int, Mk: int, d: int, device):
     return torch.empty(nb, dtype=torch.uint8, device=device), nb
 
 
+@_on_device
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, M: int, scale: float,
               share_groups: int = 1) -> torch.Tensor:
     """q, k: (B, Mp, C) views with arbitrary last-dim-contiguous row stride; vt: (B, C, ldvt) = v transposed.
@@ -287,6 +317,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, M:
     return out
 
 
+@_on_device
 def cfg_ddim(x: Optional[torch.Tensor], eps_uncond: torch.Tensor, eps_cond: Optional[torch.Tensor], guidance: float,
              a: float, b: float, c: float, d: float, want_eps: bool = False):
     """generate.py:276-278 + 281-311 fused: returns x_next (and the guided eps when want_eps)."""
@@ -305,6 +336,7 @@ def cfg_ddim(x: Optional[torch.Tensor], eps_uncond: torch.Tensor, eps_cond: Opti
     return (x_out, eps_out) if want_eps else (x_out if x is not None else eps_out)
 
 
+@_on_device
 def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float) -> torch.Tensor:
     """torch.nn.LayerNorm over the last axis (patch.py:139-146 `self.norm1(hidden_states)`)."""
     _req(x, "x")
@@ -320,6 +352,7 @@ def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[to
     return out
 
 
+@_on_device
 def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, Mq: int, Mk: int, scale: float,
                  use_workspace: bool = True) -> torch.Tensor:
     """Cross-attention core (patch.py:178-183): q (B, Mqp, C), k (B, Mkp, C) views contiguous along the last axis,
@@ -340,6 +373,7 @@ def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
     return out
 
 
+@_on_device
 def geglu(x: torch.Tensor) -> torch.Tensor:
     """value * gelu(gate) over the two halves of the last axis (the GEGLU feed-forward, patch.py:187-199)."""
     _req(x, "x")

@@ -679,12 +679,16 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
            void *ws, size_t ws_bytes, hipStream_t s) {
     constexpr int DK = (D + 15) / 16;
     constexpr size_t lds = (size_t)2 * (KV * (DK * 16 + 8) + vrows_for(D) * VT_STRIDE) * 2;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<T, D>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_attention: LDS attribute: %s", hipGetErrorString(e));
-        attr_set = true;
+    if (lds > 64 * 1024) {   // opt in to > 64 KB of dynamic LDS once per (kernel instantiation, device)
+        static std::atomic<bool> attr_set[vtm::MAX_DEVICES];
+        const int dev = vtm::current_device();
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<T, D>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess)
+                return vtm::fail(VTM_ELAUNCH, "vtm_attention: LDS attribute: %s", hipGetErrorString(e));
+            attr_set[dev].store(true, std::memory_order_release);
+        }
     }
     constexpr int WAVES = waves_for(D);
     TailPlan p = plan_tail<D>(B, h, M, Mk);

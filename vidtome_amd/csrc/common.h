@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -35,16 +36,23 @@ template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; 
 template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
 template <> __device__ __forceinline__ float to_f32<vtm_bf16>(vtm_bf16 v) { return __bfloat162float(v); }
 
-// compute units of the current device (256 on MI355X; 8 XCDs of 32)
+// compute units of the CURRENT device (256 on MI355X; 8 XCDs of 32), cached per device ordinal: a process may
+// drive several devices (one stream each), and a planner called for device 1 must not see device 0's answer
+constexpr int MAX_DEVICES = 64;
+inline int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    return dev;
+}
 inline int device_cus() {
-    static int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        return n;
-    }();
-    return cus;
+    static std::atomic<int> cus[MAX_DEVICES];       // zero-initialised; racing first calls store the same value
+    const int dev = current_device();
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 // internal cross-file launchers (not part of the C ABI)

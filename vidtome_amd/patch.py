@@ -232,12 +232,73 @@ def _fused_weights(attn: torch.nn.Module, dtype, device):
     return cache[1], cache[2]
 
 
+_HEAD_DIMS = (8, 16, 32, 40, 64, 80, 96, 128, 160)          # instantiations of attention_kernel (attention.hip)
+_PLAIN_PROCESSORS = ("AttnProcessor", "AttnProcessor2_0", "XFormersAttnProcessor")
+_warned = set()
+
+
+def _warn_once(key: str, msg: str) -> None:
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn(msg, stacklevel=3)
+
+
+def _plain_linear(m) -> bool:
+    """A projection the fused path may read `.weight` / `.bias` from: a plain Linear (or Diffusers' LoRA-compatible
+    subclass with no LoRA attached).  PEFT / LoRA wrappers compute more than `x W^T + b`; reading the base weight
+    would silently drop the adapter."""
+    return (isinstance(m, torch.nn.Linear) and type(m).__name__ in ("Linear", "LoRACompatibleLinear")
+            and getattr(m, "lora_layer", None) is None)
+
+
+def _out_linear(attn: torch.nn.Module):
+    to_out = attn.to_out
+    return to_out[0] if isinstance(to_out, (torch.nn.ModuleList, torch.nn.Sequential, list, tuple)) else to_out  # pnp_utils.py:41-45
+
+
+def fused_attention_ok(attn: torch.nn.Module, x: torch.Tensor, self_attn: bool = True) -> bool:
+    """True when `attn(x)` is exactly `to_out[0](softmax(to_q(x) to_k(.)^T * scale) to_v(.))` -- the arithmetic of
+    utils/pnp_utils.py:47-95 -- so that the fused path (projection GEMMs + vtm_attention) computes what the module
+    would.  Anything else (LoRA / PEFT projections, custom processors or a replaced forward, group / cross norms,
+    output rescaling or an inner residual, head dims without a kernel instantiation, dropout in training) makes the
+    patched block call the module itself on the merged tokens, like the reference does (patch.py:157-162)."""
+    if not (x.is_cuda and x.dim() == 3 and x.dtype in (torch.float16, torch.bfloat16, torch.float32)):
+        return False
+    if not all(hasattr(attn, a) for a in ("to_q", "to_k", "to_v", "to_out", "heads")):
+        return False
+    if not all(_plain_linear(m) for m in (attn.to_q, attn.to_k, attn.to_v, _out_linear(attn))):
+        return False
+    C = x.shape[-1]
+    if attn.to_q.out_features != C or C % attn.heads or (C // attn.heads) not in _HEAD_DIMS:
+        return False
+    if any(getattr(attn, a, None) is not None for a in ("group_norm", "spatial_norm", "norm_cross", "norm_q", "norm_k")):
+        return False
+    if getattr(attn, "rescale_output_factor", 1.0) != 1.0 or getattr(attn, "residual_connection", False):
+        return False
+    proc = getattr(attn, "processor", None)
+    if proc is not None and type(proc).__name__ not in _PLAIN_PROCESSORS:
+        return False
+    if "forward" in attn.__dict__ and not (self_attn and _pnp_num_inputs(attn) is not None):
+        return False                              # replaced forward: only the PnP closure is understood
+    to_out = attn.to_out
+    if attn.training and isinstance(to_out, (torch.nn.ModuleList, torch.nn.Sequential)) and len(to_out) > 1 \
+            and getattr(to_out[1], "p", 0.0) != 0.0:
+        return False
+    return True
+
+
 def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = None,
                    q_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``attn1(x)`` for self-attention without mask (patch.py:157-162), arithmetic of pnp_utils.py:47-95:
     q,k,v projections -> softmax(q k^T * scale) v per head -> to_out[0] (+ dropout(0)).
     x is (B, Mp, C) whose first M rows per sample are the sequence.  With ``q_rows`` (B, Mq) only those rows act
-    as queries (every row stays a key / value) and the result is (B, Mq rounded up to 8, C) in q_rows order."""
+    as queries (every row stays a key / value) and the result is (B, Mq rounded up to 8, C) in q_rows order.
+    The caller has checked ``fused_attention_ok(attn, x)``.
+
+    fp16 / bf16 models run everything in their dtype.  fp32 models keep the four projections in fp32 and only the
+    attention core's operands (q, k, v^T) are rounded to fp16 for the MFMA (fp32 accumulation, fp32 softmax): the
+    result is within the 1e-3 class of the fp32 reference, and a warning says so once."""
     B, Mp, C = x.shape
     M = Mp if M is None else M
     heads = attn.heads
@@ -250,19 +311,19 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
         pad = 8 - x.shape[1] % 8
         x = F.pad(x, (0, 0, 0, pad))
         Mp = x.shape[1]
-    out_dtype = x.dtype
+    core = x.dtype
     if x.dtype == torch.float32:
-        # the attention core is an fp16/bf16 MFMA kernel with fp32 accumulation; fp32 models (tests) run
-        # their projections and attention in fp16 -- the matching path above stays exact fp32
-        x = x.to(torch.float16)
+        core = torch.float16
+        _warn_once("fp32-core", "vidtome_amd: fp32 model -- the self-attention core (QK^T, softmax, PV) runs on the "
+                                "fp16 MFMA with fp32 accumulation; projections, matching and merging stay fp32")
     wqk, bqk = _fused_weights(attn, x.dtype, x.device)
     if q_rows is None:
-        qk = F.linear(x, wqk, bqk)                                       # (B, Mp, 2C): one GEMM for q and k
+        qk = F.linear(x, wqk, bqk).to(core)                              # (B, Mp, 2C): one GEMM for q and k
         q_op, k_op = qk[:, :, :C], qk[:, :, C:]
     else:
         xq = _lib.gather_rows(x, None, q_rows, pad_to=8)                 # (B, Mqp, C) query tokens
-        q_op = F.linear(xq, wqk[:C], None if bqk is None else bqk[:C])
-        k_op = F.linear(x, wqk[C:], None if bqk is None else bqk[C:])
+        q_op = F.linear(xq, wqk[:C], None if bqk is None else bqk[:C]).to(core)
+        k_op = F.linear(x, wqk[C:], None if bqk is None else bqk[C:]).to(core)
     wv = attn.to_v.weight.to(x.dtype)
     if B <= 4:                                                           # merged sites: few long sequences
         vt = torch.empty((B, C, Mp), dtype=x.dtype, device=x.device)     # V^T straight from the GEMM:
@@ -272,13 +333,14 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
         vt = torch.matmul(wv, x.transpose(1, 2))
     if getattr(attn.to_v, "bias", None) is not None:
         vt = vt + attn.to_v.bias.to(x.dtype)[None, :, None]
+    vt = vt.to(core)
     if q_rows is None:
         o = _lib.attention(q_op, k_op, vt, heads, M, scale, share)
     else:
         o = _lib.attention_kv(q_op, k_op, vt, heads, q_rows.shape[1], M, scale)
-    to_out = attn.to_out[0] if isinstance(attn.to_out, (torch.nn.ModuleList, torch.nn.Sequential, list, tuple)) \
-        else attn.to_out                                                 # pnp_utils.py:41-45
-    return F.linear(o, to_out.weight.to(o.dtype), None if to_out.bias is None else to_out.bias.to(o.dtype)).to(out_dtype)
+    to_out = _out_linear(attn)
+    o = o.to(x.dtype)
+    return F.linear(o, to_out.weight.to(o.dtype), None if to_out.bias is None else to_out.bias.to(o.dtype))
 
 
 def cross_attention(attn: torch.nn.Module, x: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor],
@@ -286,11 +348,9 @@ def cross_attention(attn: torch.nn.Module, x: torch.Tensor, encoder_hidden_state
     """`self.attn2(norm_hidden_states, encoder_hidden_states=..., attention_mask=...)` (patch.py:178-183) -- the
     un-merged tokens attending to the conditioning (77 text tokens in SD).  The plain case (projection Linears, no
     mask, no processor kwargs) runs on vtm_attention_kv; everything else is the module's own forward."""
-    plain = (encoder_hidden_states is not None and attention_mask is None and not kwargs and x.is_cuda
-             and all(hasattr(attn, a) for a in ("to_q", "to_k", "to_v", "to_out", "heads"))
-             and x.dim() == 3 and encoder_hidden_states.dim() == 3 and x.shape[-1] % (8 * attn.heads) == 0
-             and x.dtype in (torch.float16, torch.bfloat16)
-             and getattr(attn, "norm_cross", None) is None and getattr(attn, "group_norm", None) is None)
+    plain = (encoder_hidden_states is not None and attention_mask is None and not kwargs
+             and encoder_hidden_states.dim() == 3 and x.dtype in (torch.float16, torch.bfloat16)
+             and fused_attention_ok(attn, x, self_attn=False))
     if not plain:
         return attn(x, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, **kwargs)
     B, N, C = x.shape
@@ -308,9 +368,7 @@ def cross_attention(attn: torch.nn.Module, x: torch.Tensor, encoder_hidden_state
     k = lin(attn.to_k, enc)
     vt = lin(attn.to_v, enc).transpose(1, 2).contiguous()               # (B, C, Mkp): 77 keys, negligible
     o = _lib.attention_kv(q, k, vt, heads, N, Mk, scale)
-    to_out = attn.to_out[0] if isinstance(attn.to_out, (torch.nn.ModuleList, torch.nn.Sequential, list, tuple)) \
-        else attn.to_out
-    return lin(to_out, o)[:, :N]
+    return lin(_out_linear(attn), o)[:, :N]
 
 
 def feed_forward(ff: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
@@ -319,7 +377,7 @@ def feed_forward(ff: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
     runs as vtm_geglu (the two Linears stay library GEMMs), otherwise the module runs unchanged."""
     net = getattr(ff, "net", None)
     if (net is not None and len(net) == 3 and net[0].__class__.__name__ == "GEGLU" and hasattr(net[0], "proj")
-            and isinstance(net[2], torch.nn.Linear) and x.is_cuda and not ff.training
+            and _plain_linear(net[0].proj) and _plain_linear(net[2]) and x.is_cuda and not ff.training
             and x.dtype in (torch.float16, torch.bfloat16, torch.float32) and net[0].proj.out_features % 16 == 0):
         return net[2](_lib.geglu(net[0].proj(x)))
     return ff(x)
@@ -337,9 +395,10 @@ def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.
     cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
     plan = getattr(m_a, "plan", None)
     custom = encoder_hidden_states is not None and block.only_cross_attention
-    if custom or attention_mask is not None or cross_attention_kwargs:
-        # not the hot path (SD never masks self-attention nor makes attn1 a cross-attention): run the
-        # module's own attention on the merged tokens exactly as the reference does
+    if custom or attention_mask is not None or cross_attention_kwargs or not fused_attention_ok(block.attn1, merged):
+        # not the hot path (SD never masks self-attention nor makes attn1 a cross-attention; LoRA'd / custom
+        # attention modules are not the plain arithmetic): run the module's own attention on the merged tokens
+        # exactly as the reference does
         M = plan.M if plan is not None else merged.shape[1]
         attn_output = block.attn1(merged[:, :M],
                                   encoder_hidden_states=encoder_hidden_states if block.only_cross_attention else None,
@@ -491,46 +550,49 @@ def apply_patch(model: torch.nn.Module, local_merge_ratio: float = 0.9, merge_gl
     return model
 
 
+def _patched_roots(model: torch.nn.Module, controlnet_on_unet: bool):
+    """The module trees the reference walks: the UNet (`model.unet` for a pipeline) and, if present, a ControlNet.
+    `remove_patch` looks for `.controlnet` on the UNet it just unwrapped (patch.py:338-341, a quirk: a pipeline's
+    ControlNet hangs off the pipeline), `update_patch` / `collect_from_patch` on the object they were given
+    (patch.py:359-362, 374-377)."""
+    unet = model.unet if hasattr(model, "unet") else model
+    owner = unet if controlnet_on_unet else model
+    return unet, ([unet, owner.controlnet] if hasattr(owner, "controlnet") else [unet])
+
+
 def remove_patch(model: torch.nn.Module):
-    """vidtome/patch.py:337-355 (including its quirk of looking for ``.controlnet`` on the unet)."""
-    model = model.unet if hasattr(model, "unet") else model
-    model_ls = [model]
-    if hasattr(model, "controlnet"):
-        model_ls.append(model.controlnet)
-    for model in model_ls:
-        for _, module in model.named_modules():
-            if hasattr(module, "_tome_info"):
-                for hook in module._tome_info["hooks"]:
+    """vidtome/patch.py:337-355: drop the hooks, give every ToMeBlock its parent class back; returns the UNet."""
+    unet, roots = _patched_roots(model, controlnet_on_unet=True)
+    for root in roots:
+        for module in root.modules():
+            info = getattr(module, "_tome_info", None)
+            if info is not None:
+                for hook in info["hooks"]:
                     hook.remove()
-                module._tome_info["hooks"].clear()
+                info["hooks"].clear()
             if module.__class__.__name__ == "ToMeBlock":
                 module.__class__ = module._parent
-    return model
+    return roots[-1]                     # the reference returns its loop variable: the last tree walked
 
 
 def update_patch(model: torch.nn.Module, **kwargs):
-    """vidtome/patch.py:358-370: setattr on every module that carries ``_tome_info``."""
-    model0 = model.unet if hasattr(model, "unet") else model
-    model_ls = [model0]
-    if hasattr(model, "controlnet"):
-        model_ls.append(model.controlnet)
-    for model in model_ls:
-        for _, module in model.named_modules():
+    """vidtome/patch.py:358-370: setattr on every module that carries ``_tome_info`` (the root included);
+    returns the last tree walked, like the reference."""
+    _, roots = _patched_roots(model, controlnet_on_unet=False)
+    for root in roots:
+        for module in root.modules():
             if hasattr(module, "_tome_info"):
                 for k, v in kwargs.items():
                     setattr(module, k, v)
-    return model
+    return roots[-1]
 
 
 def collect_from_patch(model: torch.nn.Module, attr="tome"):
-    """vidtome/patch.py:373-387."""
-    model0 = model.unet if hasattr(model, "unet") else model
-    model_ls = [model0]
-    if hasattr(model, "controlnet"):
-        model_ls.append(model.controlnet)
-    ret_dict = dict()
-    for model in model_ls:
-        for name, module in model.named_modules():
+    """vidtome/patch.py:373-387: {module name: getattr(module, attr)} over the patched trees."""
+    _, roots = _patched_roots(model, controlnet_on_unet=False)
+    found = {}
+    for root in roots:
+        for name, module in root.named_modules():
             if hasattr(module, attr):
-                ret_dict[name] = getattr(module, attr)
-    return ret_dict
+                found[name] = getattr(module, attr)
+    return found

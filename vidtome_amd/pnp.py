@@ -24,12 +24,19 @@ def register_attention_control(model, injection_schedule, num_inputs):
 
 
 def register_time(model, t):
-    """utils/pnp_utils.py:12-37: stamp the current timestep on every attention module that has one."""
+    """utils/pnp_utils.py:12-37: stamp the current timestep on everything the PnP hooks read it from -- the
+    self- and cross-attention of every transformer block AND the resnets of the down / up blocks (the reference's
+    `register_conv_control` forward, pnp_utils.py:108-172, reads `self.t` on a resnet, and `init_pnp`,
+    generate.py:317-320, always installs it).  Walks whatever blocks the UNet has instead of the reference's fixed
+    SD index tables; on an SD UNet the two visit the same modules."""
     unet = model.unet
     groups = list(getattr(unet, "up_blocks", [])) + list(getattr(unet, "down_blocks", []))
+    for g in groups:
+        for res in getattr(g, "resnets", []):
+            setattr(res, "t", t)
     mid = getattr(unet, "mid_block", None)
     if mid is not None:
-        groups.append(mid)
+        groups.append(mid)              # the reference stamps the mid block's attention only (pnp_utils.py:34-37)
     for g in groups:
         for att in getattr(g, "attentions", []):
             blk = att.transformer_blocks[0]

@@ -1,64 +1,100 @@
-"""Chunk scheduling of a denoising step and the anchor-token lifetime -- counterpart of the caller side of the
-hot path (generate.py:172-203 `get_chunks`, :205-224 `ddim_sample` chunk loop, :233-236 `post_iter`).
+"""Chunk scheduling of a denoising step and the anchor-token lifetime -- the caller side of the hot path
+(reference behaviour: generate.py:172-203 `get_chunks`, :205-224 the chunk loop of `ddim_sample`, :233-236
+`post_iter`).
 
-The scheduler decides, per denoising step, how the F frames of a video are cut into chunks and in which order
-the chunks are processed; with global merging the order matters because the per-block anchor tokens flow from
-one chunk to the next (patch.py:59-82) and are reset after every step.  The draws come from the SAME global
-RNGs in the SAME order as the reference (`np.random.randint`, `np.random.rand`, `torch.randperm`), so a run
-seeded like the reference's `seed_everything` produces the same chunk lists
-(tests/golden/chunks.npz, generated by calling the reference's own `Generator.get_chunks`).
+A step's schedule is fully described by three random draws, so this module separates them from the index
+arithmetic:
+
+    StepDraws      what is random:  first chunk length, walk direction, a permutation of the chunk ids
+    cut_frames()   what is not:     [0, flen) cut into the (start, stop) frame ranges the draws imply
+    visit_order()                   the order in which those ranges are processed ("seq" / "rand" / "mix-k")
+
+`ChunkScheduler.draw()` takes the draws from the SAME global generators in the SAME sequence as the reference
+(`np.random.randint`, `np.random.rand`, then `torch.randperm` on the number of chunks the first draw produced), so a
+process seeded like the reference's `seed_everything` walks the same schedule; tests/golden/chunks.npz (recorded from
+the reference's own `Generator.get_chunks`) pins that.  With global merging the order matters: the per-block anchor
+tokens flow from one chunk to the next (patch.py:59-82) and die at the end of the step.  Because a schedule is plain
+data it can be drawn once (rank 0) and broadcast, or replayed, by the chunk-parallel runner (chunk_parallel.py).
 """
 from __future__ import annotations
 
-from typing import Callable, Iterable, List, Sequence
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
 
+@dataclass(frozen=True)
+class StepDraws:
+    first_len: int                       # length of the first chunk, 1..chunk_size      (generate.py:176)
+    backwards: bool                      # walk the video from its end                   (generate.py:179-180)
+    perm: Optional[Tuple[int, ...]]      # permutation of the chunk ids, None for "seq"  (generate.py:187,190)
+
+
+def cut_frames(flen: int, first_len: int, chunk_size: int) -> List[Tuple[int, int]]:
+    """Frame ranges of one step: a first chunk of `first_len` frames, then runs of `chunk_size`, the last one as
+    short as what is left.  A first chunk that already covers the video leaves a single range."""
+    head = min(first_len, flen)
+    return [(0, head)] + [(s, min(s + chunk_size, flen)) for s in range(head, flen, chunk_size)]
+
+
+def visit_order(n: int, mode: str, perm: Optional[Sequence[int]], perm_div: float) -> List[int]:
+    """Processing order of n chunks.  "seq": as cut; "rand": the permutation; "mix": the first n / perm_div entries of
+    the permutation are visited first, the remaining chunks follow in ascending or descending order -- whichever end
+    lies closer to the last randomly visited chunk (generate.py:189-199)."""
+    if mode == "rand":
+        return list(perm)
+    if mode != "mix":
+        return list(range(n))
+    n_rand = int(n / perm_div)
+    lead, rest = list(perm[:n_rand]), sorted(perm[n_rand:])
+    if lead and abs(rest[-1] - lead[-1]) < abs(rest[0] - lead[-1]):
+        rest.reverse()
+    return lead + rest
+
+
 class ChunkScheduler:
-    """generate.py:70-71,86-89 (configuration) and :172-203 (`get_chunks`)."""
+    """Configuration as in generate.py:70-71,86-89: `chunk_ord` is "seq", "rand", "mix" or "mix-<divisor>"."""
 
     def __init__(self, chunk_size: int, merge_global: bool = True, chunk_ord: str = "mix-4"):
         self.chunk_size = int(chunk_size)
         self.merge_global = bool(merge_global)
-        self.chunk_ord = chunk_ord
-        self.perm_div = 3.0
-        if "mix" in self.chunk_ord:                                              # generate.py:87-89
-            self.perm_div = float(self.chunk_ord.split("-")[-1]) if "-" in self.chunk_ord else 3.0
-            self.chunk_ord = "mix"
+        name, _, div = chunk_ord.partition("-")
+        self.perm_div = float(div) if ("mix" in chunk_ord and div) else 3.0
+        self.chunk_ord = "mix" if "mix" in chunk_ord else name
+
+    def n_chunks(self, flen: int, first_len: int) -> int:
+        return len(cut_frames(flen, first_len, self.chunk_size))
+
+    def draw(self, flen: int) -> StepDraws:
+        """The step's draws, consumed from the global numpy / torch generators in the reference's sequence.  The
+        permutation is only drawn when the order matters (global merging) and the mode uses one."""
+        first_len = int(np.random.randint(0, self.chunk_size)) + 1
+        backwards = bool(np.random.rand() > 0.5)
+        perm = None
+        if self.merge_global and self.chunk_ord in ("rand", "mix"):
+            perm = tuple(torch.randperm(self.n_chunks(flen, first_len)).tolist())
+        return StepDraws(first_len, backwards, perm)
+
+    def schedule(self, flen: int, draws: StepDraws) -> List[Tuple[int, int]]:
+        """Pure function of the draws: the (start, stop) ranges in processing order."""
+        spans = cut_frames(flen, draws.first_len, self.chunk_size)
+        if draws.backwards:
+            spans.reverse()
+        if not self.merge_global:                    # the order only matters for the anchor chain
+            return spans
+        return [spans[i] for i in visit_order(len(spans), self.chunk_ord, draws.perm, self.perm_div)]
 
     def get_chunks(self, flen: int) -> List[torch.Tensor]:
-        x_index = torch.arange(flen)
-        rand_first = np.random.randint(0, self.chunk_size) + 1                   # generate.py:176
-        chunks = x_index[rand_first:].split(self.chunk_size, dim=0)
-        chunks = [x_index[:rand_first]] + list(chunks) if len(chunks[0]) > 0 else [x_index[:rand_first]]
-        if np.random.rand() > 0.5:                                               # generate.py:179-180
-            chunks = chunks[::-1]
-        if not self.merge_global:                                                # generate.py:183-184
-            return chunks
-        if self.chunk_ord == "rand":
-            order = torch.randperm(len(chunks)).tolist()
-        elif self.chunk_ord == "mix":                                            # generate.py:189-199
-            randord = torch.randperm(len(chunks)).tolist()
-            rand_len = int(len(randord) / self.perm_div)
-            seqord = sorted(randord[rand_len:])
-            if rand_len > 0:
-                randord = randord[:rand_len]
-                if abs(seqord[-1] - randord[-1]) < abs(seqord[0] - randord[-1]):
-                    seqord = seqord[::-1]
-                order = randord + seqord
-            else:
-                order = seqord
-        else:
-            order = list(range(len(chunks)))
-        return [chunks[i] for i in order]
+        """Same result as the reference's `Generator.get_chunks`: frame-index tensors in processing order."""
+        return [torch.arange(a, b) for a, b in self.schedule(flen, self.draw(flen))]
 
 
 def run_step(model, scheduler: ChunkScheduler, n_frames: int,
              process_chunk: Callable[[torch.Tensor], None]) -> List[torch.Tensor]:
-    """One denoising step's chunk loop (generate.py:215-219) followed by the anchor reset of
-    `post_iter` (generate.py:233-236): anchors live for exactly one step."""
+    """One denoising step's chunk loop (generate.py:215-219) followed by the anchor reset of `post_iter`
+    (generate.py:233-236): anchors live for exactly one step."""
     from . import patch
     chunks = scheduler.get_chunks(n_frames)
     for chunk in chunks:
@@ -68,7 +104,8 @@ def run_step(model, scheduler: ChunkScheduler, n_frames: int,
     return chunks
 
 
-def assign_chunks_to_ranks(chunks: Sequence[torch.Tensor], world: int) -> List[List[int]]:
-    """Chunk-parallel mapping used by chunk_parallel.py: rank r processes chunks r, r + world, ... in the
-    scheduler's order (so that with the ring exchange rank r's predecessor in the anchor chain is rank r-1)."""
+def assign_chunks_to_ranks(chunks: Sequence, world: int) -> List[List[int]]:
+    """Chunk-parallel mapping used by chunk_parallel.py: rank r processes chunks r, r + world, ... of the schedule,
+    so the predecessor of a chunk in the anchor chain always lives on rank (r - 1) mod world (rank world-1 hands
+    over to rank 0 for the next round)."""
     return [list(range(r, len(chunks), world)) for r in range(world)]

@@ -1,4 +1,8 @@
-"""Patch helpers -- the counterpart of vidtome/utils.py (same names and behaviour)."""
+"""Patch helpers -- the counterpart of vidtome/utils.py (same names and behaviour).
+
+The reference's closure-composition helpers (`func_warper` / `join_warper` / `split_warper`, vidtome/utils.py:42-60)
+have no counterpart here: a block's merge / unmerge chains are composed into single row maps on the device
+(`vtm_compose`, see patch.compute_merge), and joining / splitting frames are views."""
 from __future__ import annotations
 
 import torch
@@ -31,26 +35,3 @@ def split_frame(x: torch.Tensor, fsize: int) -> torch.Tensor:
     """vidtome/utils.py:37-40: 'B (F N) C -> (B F) N C'."""
     B, FN, C = x.shape
     return x.reshape(B * fsize, FN // fsize, C)
-
-
-def func_warper(funcs):
-    """vidtome/utils.py:42-48."""
-    def fn(x, **kwarg):
-        for func in funcs:
-            x = func(x, **kwarg)
-        return x
-    return fn
-
-
-def join_warper(fsize):
-    """vidtome/utils.py:50-54."""
-    def fn(x, **kwarg):
-        return join_frame(x, fsize)
-    return fn
-
-
-def split_warper(fsize):
-    """vidtome/utils.py:56-60."""
-    def fn(x, **kwarg):
-        return split_frame(x, fsize)
-    return fn
