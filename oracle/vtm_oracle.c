@@ -391,3 +391,60 @@ VTMO_API int vtmo_attention(const float *q, const float *k, const float *v, int6
                             int64_t M, int64_t d, float scale, int share_groups, float *out) {
     return vtmo_attention_rows(q, k, v, B, h, M, d, scale, share_groups, 0, M, out);
 }
+
+/* attention with a separate query set: q (B, Mq, C), k and v (B, Mk, C) -> out (B, Mq, C).  Same arithmetic as
+ * vtmo_attention_rows (pnp_utils.py:47-95 with q / k of different lengths, which is what the patched block's
+ * cross-attention, patch.py:178-183, and its live-query self-attention evaluate); the softmax denominator and the
+ * PV sums are accumulated in double so that a 1e-3 comparison over ~50 000 keys measures the kernel under test,
+ * not the summation order of the checker.  Used with a SAMPLE of query rows at the full BASELINE sizes. */
+VTMO_API int vtmo_attention_qkv(const float *q, const float *k, const float *v, int64_t B, int64_t h, int64_t Mq,
+                                int64_t Mk, int64_t d, float scale, float *out) {
+    if (!q || !k || !v || !out || B <= 0 || h <= 0 || Mq <= 0 || Mk <= 0 || d <= 0) return -1;
+    const int64_t C = h * d;
+    int err = 0;
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t hh = 0; hh < h; ++hh) {
+            float *kt = (float *)malloc((size_t)(d * Mk) * sizeof(float));
+            if (!kt) return -2;
+#pragma omp parallel for schedule(static)
+            for (int64_t j = 0; j < Mk; ++j)
+                for (int64_t dd = 0; dd < d; ++dd) kt[dd * Mk + j] = k[(b * Mk + j) * C + hh * d + dd];
+#pragma omp parallel
+            {
+                float *s = (float *)malloc((size_t)Mk * sizeof(float));
+                double *o = (double *)malloc((size_t)d * sizeof(double));
+                if (!s || !o) err = 1;
+#pragma omp for schedule(dynamic, 4)
+                for (int64_t m = 0; m < Mq; ++m) {
+                    if (!s || !o) continue;
+                    const float *qr = q + (b * Mq + m) * C + hh * d;
+                    for (int64_t j = 0; j < Mk; ++j) s[j] = 0.0f;
+                    for (int64_t dd = 0; dd < d; ++dd) {
+                        const float qv = qr[dd];
+                        const float *kr = kt + dd * Mk;
+#pragma omp simd
+                        for (int64_t j = 0; j < Mk; ++j) s[j] += qv * kr[j];
+                    }
+                    float mx = -INFINITY;
+                    for (int64_t j = 0; j < Mk; ++j) {
+                        s[j] *= scale;
+                        mx = s[j] > mx ? s[j] : mx;
+                    }
+                    double sum = 0.0;
+                    for (int64_t dd = 0; dd < d; ++dd) o[dd] = 0.0;
+                    for (int64_t j = 0; j < Mk; ++j) {
+                        const double p = (double)expf(s[j] - mx);
+                        sum += p;
+                        const float *vr = v + (b * Mk + j) * C + hh * d;
+                        for (int64_t dd = 0; dd < d; ++dd) o[dd] += p * (double)vr[dd];
+                    }
+                    float *orow = out + (b * Mq + m) * C + hh * d;
+                    for (int64_t dd = 0; dd < d; ++dd) orow[dd] = (float)(o[dd] / sum);
+                }
+                free(s);
+                free(o);
+            }
+            free(kt);
+        }
+    return err ? -2 : 0;
+}

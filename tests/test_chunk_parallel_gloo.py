@@ -1,7 +1,9 @@
-"""World-size-2 gloo tests (CPU) of the chunk-parallel anchor exchange: the protocol objects in
-vidtome_amd/chunk_parallel.py move the right tensors and -- with the draw replay -- a ring run over 2 ranks
-reproduces the sequential run (reference order) exactly.  The merge itself is computed by the CPU oracle here
-(tests may use it); on the GPU box the same exchange objects are driven by the HIP path."""
+"""World-size-2 gloo tests (CPU) of the chunk-parallel anchor exchange (vidtome_amd/chunk_parallel.py): a step of
+FIVE chunks of unequal length (more chunks than ranks, a single-frame chunk, a 6-frame chunk whose level sizes depend
+on the draw) dealt round-robin to two ranks must reproduce the sequential run -- indices, merged tokens, anchors and
+the generator state at the end of the step -- in the exact ring mode, and the documented "parallel anchors" semantics
+in the neighbour / all-gather modes.  The merge itself is computed by the CPU oracle here (tests may use it) through
+the same protocol calls `patch.compute_merge` makes; tests/test_gpu_parity.py drives the HIP path through them."""
 import os
 import socket
 import sys
@@ -17,13 +19,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ARGS = {"batch_size": 2, "max_downsample": 2, "target_stride": 4, "local_merge_ratio": 0.5,
         "merge_global": True, "global_merge_ratio": 0.5, "align_batch": False, "global_rand": 0.5}
 B, C, HW = 2, 16, (4, 4)
-CHUNKS = [6, 4]          # frames per chunk: F=6 makes the level sizes depend on the randf draw
 NBLK = 2
+STEPS = {"ring": [[3, 6, 4, 1, 4], [2, 4, 4]], "neighbour": [[3, 6, 4, 1, 4], [2, 4, 4]], "allgather": [[3, 6, 4, 1], [4, 2]]}
 
 
-def _hidden(chunk, blk):
-    g = torch.Generator().manual_seed(100 * chunk + blk)
-    return torch.randn(B * CHUNKS[chunk], HW[0] * HW[1], C, generator=g).numpy()
+def _hidden(step, chunk, blk, frames):
+    g = torch.Generator().manual_seed(1000 * step + 100 * chunk + blk)
+    return torch.randn(B * frames, HW[0] * HW[1], C, generator=g).numpy()
 
 
 def _fork(seed=123):
@@ -31,15 +33,31 @@ def _fork(seed=123):
     return torch.Generator(device="cpu").set_state(torch.get_rng_state())
 
 
-def _sequential(oracle):
-    res = {}
+def _local_tokens(oracle, h, gen):
+    """The chunk's tokens after its local levels, computed with a COPY of the generator (same draws)."""
+    g = torch.Generator(device="cpu").set_state(gen.get_state())
+    return oracle.compute_merge(h, HW, dict(ARGS, merge_global=False), oracle.RandomDraws.from_torch_generator(g), {})[2]
+
+
+def _reference(oracle, mode, steps):
+    """Sequential run (generate.py:215-219 order).  ring: the reference's chained anchors; otherwise every chunk
+    merges against the LOCAL tokens of the chunk before it."""
+    res, end_state = {}, {}
     for blk in range(NBLK):
-        draws = oracle.RandomDraws.from_torch_generator(_fork())
-        state = {"global_tokens": None}
-        for ck in range(len(CHUNKS)):
-            m, u, merged, trace = oracle.compute_merge(_hidden(ck, blk), HW, ARGS, draws, state)
-            res[(ck, blk)] = (merged.copy(), state["global_tokens"].copy(), trace)
-    return res
+        gen = _fork()
+        draws = oracle.RandomDraws.from_torch_generator(gen)
+        for s, frames in enumerate(steps):
+            state, prev_local = {"global_tokens": None}, None
+            for ck, F in enumerate(frames):
+                h = _hidden(s, ck, blk, F)
+                local = _local_tokens(oracle, h, gen)
+                if mode != "ring":
+                    state = {"global_tokens": prev_local}
+                m, u, merged, trace = oracle.compute_merge(h, HW, ARGS, draws, state)
+                res[(s, ck, blk)] = (merged.copy(), state["global_tokens"].copy(), trace)
+                prev_local = local
+        end_state[blk] = gen.get_state()
+    return res, end_state
 
 
 def _free_port():
@@ -50,6 +68,11 @@ def _free_port():
     return p
 
 
+class _Module:                     # what the exchange needs from a patched block: its generator
+    def __init__(self, gen):
+        self.generator = gen
+
+
 def _worker(rank, world, port, mode, q):
     try:
         sys.path.insert(0, ROOT)
@@ -57,45 +80,59 @@ def _worker(rank, world, port, mode, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from oracle import oracle
         from vidtome_amd import chunk_parallel as cp
-        seq = _sequential(oracle)
+        steps = STEPS[mode]
+        ref, ref_end = _reference(oracle, mode, steps)
         tpf = HW[0] * HW[1]
-        ok = True
-        if mode == "ring":
-            ex = cp.RingExchange()
-            for blk in range(NBLK):
-                gen = _fork()
-                cp.replay_draws(gen, CHUNKS[:rank], tpf, ARGS)          # draws of the chunks before mine
-                draws = oracle.RandomDraws.from_torch_generator(gen)
-                like = torch.zeros(1)
-                got = ex.anchors_for(f"b{blk}", lambda: None, like)
-                state = {"global_tokens": None if got is None else got.numpy()}
-                m, u, merged, trace = oracle.compute_merge(_hidden(rank, blk), HW, ARGS, draws, state)
-                ex.publish(f"b{blk}", torch.from_numpy(state["global_tokens"]))
-                ref_merged, ref_anchors, ref_trace = seq[(rank, blk)]
-                ok &= np.array_equal(merged, ref_merged) and np.array_equal(state["global_tokens"], ref_anchors)
-                for lv, rl in zip(trace["levels"], ref_trace["levels"]):
-                    ok &= all(np.array_equal(lv[n], rl[n]) for n in ("unm_idx", "src_idx", "dst_idx"))
-                ok &= (trace["global"] is None) == (ref_trace["global"] is None)
-                if trace["global"] is not None:
-                    ok &= all(np.array_equal(trace["global"][n], ref_trace["global"][n])
-                              for n in ("unm_idx", "src_idx", "dst_idx"))
-                    ok &= trace["global"]["coin"] == ref_trace["global"]["coin"]
-            ok &= (ex.bytes_sent > 0) == (rank == 0)
-        else:
-            ex = cp.AllGatherExchange()
-            local_args = dict(ARGS, merge_global=False)
-            for blk in range(NBLK):
-                # every rank runs the SAME chunk length here so the gathered tensors have one shape
-                def local_of(r):
-                    draws = oracle.RandomDraws.from_torch_generator(_fork())
-                    h = _hidden(1, blk) + np.float32(r)
-                    return oracle.compute_merge(h, HW, local_args, draws, {})[2]
-                mine = torch.from_numpy(local_of(rank))
-                got = ex.anchors_for(f"b{blk}", lambda: mine, mine)
-                ok &= np.array_equal(got.numpy(), local_of((rank - 1) % world))
-            ok &= ex.bytes_gathered > 0
-        q.put((rank, bool(ok), ""))
-    except Exception as e:  # pragma: no cover
+        ex = cp.AnchorExchange(mode)
+        mods = [_Module(_fork()) for _ in range(NBLK)]
+        ok, why = True, []
+
+        def check(cond, what):
+            nonlocal ok
+            if not cond:
+                ok = False
+                why.append(what)
+
+        for s, frames in enumerate(steps):
+            ex.begin_step(frames)
+            mine = ex.my_chunks()
+            check(mine == list(range(rank, len(frames), world)), "chunk assignment")
+            for i in mine:
+                ex.begin_chunk(i)
+                for blk in range(NBLK):
+                    key, mod = f"b{blk}", mods[blk]
+                    h = _hidden(s, i, blk, frames[i])
+                    like = torch.from_numpy(h).reshape(B, frames[i] * tpf, C)
+                    ex.begin_block(mod, key, frames[i], tpf, ARGS, like)          # what patch.compute_merge does
+                    local = _local_tokens(oracle, h, mod.generator)
+
+                    class State(dict):
+                        def get(self, k, d=None):
+                            if k != "global_tokens":
+                                return dict.get(self, k, d)
+                            got = ex.anchors_for(key, lambda: torch.from_numpy(local), like)
+                            return None if got is None else got.numpy()
+                    state = State()
+                    m, u, merged, trace = oracle.compute_merge(h, HW, ARGS, oracle.RandomDraws.from_torch_generator(mod.generator), state)
+                    ex.publish(key, torch.from_numpy(np.ascontiguousarray(state["global_tokens"])))
+                    r_merged, r_anchors, r_trace = ref[(s, i, blk)]
+                    check(np.array_equal(merged, r_merged), f"merged s{s} c{i} b{blk}")
+                    check(np.array_equal(state["global_tokens"], r_anchors), f"anchors s{s} c{i} b{blk}")
+                    for lv, rl in zip(trace["levels"], r_trace["levels"]):
+                        check(all(np.array_equal(lv[n], rl[n]) for n in ("unm_idx", "src_idx", "dst_idx")), "local idx")
+                    check((trace["global"] is None) == (r_trace["global"] is None) == (i == 0), "global presence")
+                    if trace["global"] is not None and r_trace["global"] is not None:
+                        check(all(np.array_equal(trace["global"][n], r_trace["global"][n])
+                                  for n in ("unm_idx", "src_idx", "dst_idx")), "global idx")
+                        check(trace["global"]["coin"] == r_trace["global"]["coin"], "coin")
+            ex.end_step()
+        for blk in range(NBLK):      # every rank's generators end where the sequential run's do
+            check(torch.equal(mods[blk].generator.get_state(), ref_end[blk]), f"generator state b{blk}")
+        check(ex.bytes_received > 0, "nothing received")
+        if mode != "allgather":
+            check(ex.bytes_sent > 0, "nothing sent")
+        q.put((rank, bool(ok), "; ".join(why)))
+    except Exception:  # pragma: no cover
         import traceback
         q.put((rank, False, traceback.format_exc()))
     finally:
@@ -103,7 +140,7 @@ def _worker(rank, world, port, mode, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["ring", "allgather"])
+@pytest.mark.parametrize("mode", ["ring", "neighbour", "allgather"])
 def test_two_rank_exchange_gloo(oracle, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -116,6 +153,46 @@ def test_two_rank_exchange_gloo(oracle, mode):
         p.join(timeout=60)
     for rank, ok, err in results:
         assert ok, f"rank {rank} failed: {err}"
+
+
+def test_three_fake_ranks_in_process(oracle):
+    """the single-process N-fake-rank replay -- three exchange endpoints on an in-memory transport,
+    the chunks executed in schedule order, equal the sequential run (ring) bit for bit."""
+    from vidtome_amd import chunk_parallel as cp
+    steps = STEPS["ring"]
+    for mode in ("ring", "neighbour"):
+        ref, ref_end = _reference(oracle, mode, steps)
+        tpf = HW[0] * HW[1]
+        fabric = cp.LocalTransport.fabric(3)
+        exs = [cp.AnchorExchange(mode, transport=t) for t in fabric]
+        mods = [[_Module(_fork()) for _ in range(NBLK)] for _ in range(3)]
+        for s, frames in enumerate(steps):
+            for ex in exs:
+                ex.begin_step(frames)
+            for i, F in enumerate(frames):
+                ex, r = exs[i % 3], i % 3
+                ex.begin_chunk(i)
+                for blk in range(NBLK):
+                    key, mod = f"b{blk}", mods[r][blk]
+                    h = _hidden(s, i, blk, F)
+                    like = torch.from_numpy(h).reshape(B, F * tpf, C)
+                    ex.begin_block(mod, key, F, tpf, ARGS, like)
+                    local = _local_tokens(oracle, h, mod.generator)
+
+                    class State(dict):
+                        def get(self, k, d=None):
+                            got = ex.anchors_for(key, lambda: torch.from_numpy(local), like)
+                            return None if got is None else got.numpy()
+                    state = State()
+                    merged = oracle.compute_merge(h, HW, ARGS, oracle.RandomDraws.from_torch_generator(mod.generator), state)[2]
+                    ex.publish(key, torch.from_numpy(np.ascontiguousarray(state["global_tokens"])))
+                    assert np.array_equal(merged, ref[(s, i, blk)][0]), (mode, s, i, blk)
+                    assert np.array_equal(state["global_tokens"], ref[(s, i, blk)][1]), (mode, s, i, blk)
+            for ex in exs:
+                ex.end_step()
+        for r in range(3):
+            for blk in range(NBLK):
+                assert torch.equal(mods[r][blk].generator.get_state(), ref_end[blk])
 
 
 def test_simulated_draws_match_compute_merge(oracle):

@@ -620,6 +620,48 @@ def test_attention_split_last_round_equals_single_launch(L, d, Mq):
     assert (a2.float() - b2.float()).abs().max() <= 1e-3
 
 
+@pytest.mark.parametrize("name,B,h,d,Mq,Mk", [
+    ("cfg-2 top block (live queries x all keys)", 2, 8, 40, 34816, 52224),
+    ("cfg-2 top block, every row a query (VIDTOME_LIVE_QUERIES=0)", 2, 8, 40, 52224, 52224),
+    ("cfg-2 mid block", 2, 8, 80, 8704, 13056),
+    ("cfg-4 top block", 2, 8, 40, 18432, 27648),
+    ("cfg-5 top block (SD-2.1-768)", 2, 5, 64, 64513, 90319),
+])
+def test_attention_full_size_vs_oracle(L, oracle, name, B, h, d, Mq, Mk):
+    """The launches bench.py times (and cfg-4 / cfg-5's largest), at FULL size, against the oracle on sampled query
+    rows: 1e-3 of the output scale (north_star).  The sample covers the first and last query blocks, the key-split
+    tail workgroups of the last round (workspace path on) and rows spread over the rest; ragged Mq / Mk at cfg-5."""
+    C = h * d
+    Mqp, Mkp = (Mq + 7) // 8 * 8, (Mk + 7) // 8 * 8
+    g = torch.Generator(device=DEV).manual_seed(Mq + Mk)
+    # frame-correlated keys (merged video tokens are) and moderately peaked softmax rows
+    base = torch.randn(B, 1, C, generator=g, device=DEV)
+    q = torch.zeros(B, Mqp, C, device=DEV, dtype=torch.float16)
+    k = torch.zeros(B, Mkp, C, device=DEV, dtype=torch.float16)
+    q[:, :Mq] = (1.5 * torch.randn(B, Mq, C, generator=g, device=DEV)).half()
+    k[:, :Mk] = (0.3 * base + torch.randn(B, Mk, C, generator=g, device=DEV)).half()
+    vt = torch.zeros(B, C, Mkp, device=DEV, dtype=torch.float16)
+    vt[:, :, :Mk] = torch.randn(B, C, Mk, generator=g, device=DEV).half()
+    # which of these launches end in key-split tail workgroups (attention.hip, plan_tail, on a 256-CU chip)
+    assert (L.lib().vtm_attention_ws_bytes(B, h, Mq, Mk, d) > 0) == name.startswith(("cfg-2 top block (live", "cfg-2 mid",
+                                                                                     "cfg-4 top"))
+    out = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5)
+    rs = np.random.default_rng(Mq)
+    rows = np.unique(np.concatenate([np.arange(0, 64), np.arange(Mq - 96, Mq), rs.choice(Mq, 384, replace=False)]))
+    assert len(rows) >= 512
+    ridx = torch.from_numpy(rows).to(DEV)
+    got = out[:, ridx].float().cpu().numpy()
+    ref = oracle.attention_qkv(q[:, ridx].float().cpu().numpy(), k[:, :Mk].float().cpu().numpy(),
+                               vt[:, :, :Mk].transpose(1, 2).float().cpu().numpy(), h, d ** -0.5)
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    assert scale > 0.2, "the comparison should not be about zeros"
+    assert err < 1e-3 * max(1.0, scale), (name, err, scale)
+    assert torch.isfinite(out[:, :Mq]).all()
+    if Mqp != Mq:
+        assert (out[:, Mq:] == 0).all()
+
+
 @pytest.mark.parametrize("d", [40, 64])
 @pytest.mark.parametrize("case", ["spike_late", "spike_every_tile", "all_very_negative", "wide_range"])
 def test_attention_rescale_paths(L, oracle, d, case):

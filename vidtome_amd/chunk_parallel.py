@@ -1,25 +1,39 @@
-"""Chunk-parallel execution of the global-merge anchor chain: one process per GPU, one video chunk per rank.
+"""Chunk-parallel execution of the global-merge anchor chain: one process per GPU, the chunks of a denoising step
+dealt round-robin to the ranks (chunk i runs on rank i mod W).
 
-In the reference the chunks of a denoising step run sequentially on one device and the per-block anchor
-tokens flow chunk -> chunk through ``module.global_tokens`` (generate.py:215-219, patch.py:59-82).  Local
-merging is independent per chunk; only this anchor hand-off couples ranks.  Two exchanges are provided:
+In the reference the chunks of a step run sequentially on one device and the per-block anchor tokens flow
+chunk -> chunk through ``module.global_tokens`` (generate.py:215-219, patch.py:59-82).  Local merging is independent
+per chunk; only this hand-off couples ranks.  Three exchange modes, one class (`AnchorExchange`):
 
-``RingExchange`` (exact)   rank k receives the anchors rank k-1 produced at the SAME block (point-to-point,
-                           one xGMI link) right before its global level and sends its own updated anchors to
-                           rank k+1 right after it -- a wavefront pipeline whose skew is one compute_merge per
-                           hop.  Together with ``replay_draws`` (every rank replays the generator draws of the
-                           chunks before it) this reproduces the sequential run's indices bit-exactly.
-``AllGatherExchange``      the north-star mode: every rank all-gathers its *local* merged tokens per block
-                           (RCCL all-gather over xGMI) and merges against the tokens of rank (k-1) mod n.  No
-                           serial dependency; a documented semantic deviation (anchors are "parallel", not
-                           chained), reported separately.
+``ring``  (exact)      chunk i receives, point-to-point over ONE xGMI link, the anchors chunk i-1 produced at the
+                       SAME block, right before its own global level, and forwards its updated anchors to the rank of
+                       chunk i+1 -- rank W-1 hands over to rank 0 for the next round, so a step may have any number
+                       of chunks.  A wavefront pipeline whose skew is one compute_merge per hop.  Reproduces the
+                       sequential run bit for bit.
+``neighbour``          every chunk merges against the LOCAL merged tokens of chunk i-1 (sent by its rank as soon as
+                       its local levels are done).  No serial chain: all ranks of a round run concurrently.  A
+                       documented semantic deviation (anchors are "parallel", not chained).
+``allgather``          the same semantics through one RCCL all-gather per merging block (north_star's wording); each
+                       rank uses only its predecessor's shard, so ``neighbour`` moves 1/(W-1) of the bytes.
 
-The classes only move tensors through ``torch.distributed`` (backend "nccl" == RCCL on ROCm; "gloo" in the CPU
-tests) and are independent of how the merge itself is computed.
+What makes this work without host round trips:
+
+* The random draws of a block are host-side and depend only on the frame counts of the chunks seen so far, so every
+  rank REPLAYS the draws of the chunks it does not process (`simulate_block_draws`): its own draws then equal the
+  sequential run's, and it knows the merged length of every other chunk -- i.e. the SHAPE of what it is about to
+  receive (the first chunk of a step has a random length, generate.py:176-178, so shapes differ between ranks).
+  No shape header, no `.tolist()`.
+* Receives are posted as soon as a block starts (before its local levels), sends as soon as the tensor exists; both
+  are asynchronous (`isend` / `irecv`: RCCL runs them on its own stream, the compute stream only waits -- on the
+  device -- right where the anchors are consumed).
+
+The classes move tensors through a `Transport` (``torch.distributed``: backend "nccl" == RCCL on ROCm, "gloo" in the
+CPU tests; or an in-process mailbox for the single-process N-rank replay of SURVEY.md 8e) and are independent of how
+the merge itself is computed.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -60,79 +74,342 @@ def simulate_block_draws(generator: torch.Generator, frames: int, tokens_per_fra
 
 
 def replay_draws(generator: torch.Generator, chunk_frames: Sequence[int], tokens_per_frame: int, args: Dict,
-                 first_has_anchors: bool = False) -> None:
-    """Consume the draws of a run of consecutive chunks (the ones another rank processes)."""
-    has = first_has_anchors
+                 first_has_anchors: bool = False) -> List[int]:
+    """Consume the draws of a run of consecutive chunks (the ones other ranks process); returns their merged
+    local lengths."""
+    has, lens = first_has_anchors, []
     for f in chunk_frames:
-        simulate_block_draws(generator, f, tokens_per_frame, args, has)
+        lens.append(simulate_block_draws(generator, f, tokens_per_frame, args, has)["M_local"])
         has = True
+    return lens
 
 
 # ----------------------------------------------------------------------------------------------------
-# exchanges
+# transports
 # ----------------------------------------------------------------------------------------------------
-class RingExchange:
-    """Exact mode.  ``anchors_for`` blocks (on the stream for NCCL) until the previous rank's anchors of this
-    block arrive; ``publish`` forwards the updated anchors to the next rank."""
+class _Done:
+    def __init__(self, tensor=None):
+        self.tensor = tensor
+
+    def wait(self):
+        return self.tensor
+
+
+class DistTransport:
+    """``torch.distributed`` point-to-point + all-gather.  With RCCL the operations run on the communicator's own
+    stream; `wait()` makes the CURRENT stream wait for them (no host block).
+
+    Ring traffic goes rank -> rank + 1, plus the wrap-around W-1 -> 0.  torch keeps ONE communicator (and one stream)
+    per pair of ranks, so with two ranks both directions would share a stream, and a send queued behind a receive
+    that waits for the peer's send -- itself queued behind a receive -- never starts.  The wrap-around therefore
+    gets a group (= communicator) of its own.
+
+    gloo (the CPU test backend) moves host memory only: device tensors are staged through the host there -- a
+    test-only path, it synchronises."""
 
     def __init__(self, group=None):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self._gloo = dist.get_backend(group) == "gloo"
+        self._wrap_group = group
+        if not self._gloo and self.world == 2:
+            ranks = None if group is None else dist.get_process_group_ranks(group)
+            self._wrap_group = dist.new_group(ranks)          # collective: every rank of `group` constructs one
+
+    def _group_for(self, src: int, dst: int):
+        return self._wrap_group if dst < src else self.group
+
+    def _global(self, r: int) -> int:
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def isend(self, tensor: torch.Tensor, dst: int):
+        if self._gloo and tensor.is_cuda:
+            tensor = tensor.cpu()
+        work = dist.isend(tensor, dst=self._global(dst), group=self._group_for(self.rank, dst))
+
+        class _Send:
+            keep = tensor                                  # the buffer must outlive the transfer
+
+            def wait(_self):
+                work.wait()
+        return _Send()
+
+    def irecv(self, shape, dtype, device, src: int):
+        stage = self._gloo and torch.device(device).type == "cuda"
+        buf = torch.empty(tuple(shape), dtype=dtype, device="cpu" if stage else device)
+        work = dist.irecv(buf, src=self._global(src), group=self._group_for(src, self.rank))
+
+        class _Recv:
+            def wait(_self):
+                work.wait()
+                return buf.to(device) if stage else buf
+        return _Recv()
+
+    def all_gather(self, tensor: torch.Tensor) -> torch.Tensor:
+        if self._gloo:
+            src = tensor.cpu() if tensor.is_cuda else tensor
+            parts = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(parts, src, group=self.group)
+            return torch.stack(parts).to(tensor.device)
+        out = torch.empty((self.world,) + tuple(tensor.shape), dtype=tensor.dtype, device=tensor.device)
+        dist.all_gather_into_tensor(out, tensor, group=self.group)
+        return out
+
+
+class LocalTransport:
+    """In-process mailbox: N "ranks" of one process executed one after the other in chunk order (the
+    single-process N-fake-rank replay).  `LocalTransport.fabric(n)` returns the n endpoints of one fabric."""
+
+    def __init__(self, rank: int, world: int, boxes: Dict):
+        self.rank, self.world, self._boxes = rank, world, boxes
+
+    @staticmethod
+    def fabric(world: int) -> List["LocalTransport"]:
+        boxes: Dict[Tuple[int, int], List[torch.Tensor]] = {}
+        return [LocalTransport(r, world, boxes) for r in range(world)]
+
+    def isend(self, tensor: torch.Tensor, dst: int):
+        self._boxes.setdefault((self.rank, dst), []).append(tensor)
+        return _Done()
+
+    def irecv(self, shape, dtype, device, src: int):
+        boxes, key = self._boxes, (src, self.rank)
+
+        class _Recv:
+            def wait(_self):
+                q = boxes.get(key)
+                if not q:
+                    raise RuntimeError(f"LocalTransport: nothing was sent {key[0]} -> {key[1]} (run the fake ranks in "
+                                       "chunk order)")
+                t = q.pop(0)
+                if tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+                    raise RuntimeError(f"LocalTransport: expected {tuple(shape)} {dtype}, got {tuple(t.shape)} {t.dtype}")
+                return t
+        return _Recv()
+
+    def all_gather(self, tensor):
+        raise RuntimeError("LocalTransport has no collectives: use the 'ring' or 'neighbour' mode")
+
+
+# ----------------------------------------------------------------------------------------------------
+# the exchange
+# ----------------------------------------------------------------------------------------------------
+class _BlockState:
+    __slots__ = ("module", "tsize", "args", "drawn", "lens", "recv", "carry")
+
+    def __init__(self, module, tsize, args):
+        self.module, self.tsize, self.args = module, tsize, args
+        self.drawn = 0          # chunks of the current step whose draws this block's generator has consumed
+        self.lens: Dict[int, int] = {}    # chunk index -> merged local length (simulated or own)
+        self.recv = None        # pending receive of the predecessor's tokens
+        self.carry = None       # tokens of this rank's previous chunk (world == 1 / all-gather wrap-around)
+
+
+class AnchorExchange:
+    """See the module docstring.  Protocol, per denoising step::
+
+        ex.begin_step(frames_per_chunk)            # the step's schedule (same on every rank)
+        for i in ex.my_chunks():                   # i = rank, rank + W, ...
+            ex.begin_chunk(i)
+            model(chunk i)                         # patched blocks call begin_block / anchors_for / publish
+        ex.end_step()                              # flush draws + outstanding sends; the caller resets the anchors
+    """
+
+    def __init__(self, mode: str = "ring", transport=None, group=None):
+        if mode not in ("ring", "neighbour", "allgather"):
+            raise ValueError(f"unknown exchange mode {mode!r}")
+        self.mode = mode
+        self.t = transport if transport is not None else DistTransport(group)
+        self.rank, self.world = self.t.rank, self.t.world
         self.bytes_sent = 0
+        self.bytes_received = 0
+        self._frames: List[int] = []
+        self._cur: Optional[int] = None
+        self._blocks: Dict[str, _BlockState] = {}
+        self._inflight: List[Tuple[object, torch.Tensor]] = []     # (work, tensor kept alive until the send is done)
+
+    # ---- step / chunk bookkeeping (host side only)
+    @property
+    def exact(self) -> bool:
+        return self.mode == "ring"
+
+    def begin_step(self, frames_per_chunk: Sequence[int]) -> None:
+        if self._cur is not None:
+            raise RuntimeError("begin_step inside a step (call end_step first)")
+        self._frames = [int(f) for f in frames_per_chunk]
+        if self.mode == "allgather" and len(self._frames) % self.world:
+            raise ValueError("the all-gather mode is a collective per round: the step needs a multiple of "
+                             f"{self.world} chunks (got {len(self._frames)}); use 'neighbour' or 'ring'")
+        for st in self._blocks.values():
+            st.drawn, st.lens, st.recv, st.carry = 0, {}, None, None
+
+    def my_chunks(self) -> List[int]:
+        return list(range(self.rank, len(self._frames), self.world))
+
+    def begin_chunk(self, index: int) -> None:
+        if index % self.world != self.rank:
+            raise RuntimeError(f"chunk {index} belongs to rank {index % self.world}, not {self.rank}")
+        self._cur = index
+
+    def end_step(self) -> None:
+        """Consume the draws of the chunks after this rank's last one (the next step continues the same generator
+        streams, like the sequential run) and retire the sends."""
+        n = len(self._frames)
+        for st in self._blocks.values():
+            self._replay(st, n)
+            if st.recv is not None:                       # a posted receive nobody consumed (cannot happen in a
+                st.recv.wait()                            # well-formed step; drain it rather than leak it)
+                st.recv = None
+        for work, _ in self._inflight:
+            if work is not None:
+                work.wait()
+        self._inflight.clear()
+        self._cur = None
+
+    def _replay(self, st: _BlockState, upto: int) -> None:
+        """Advance the block's generator over chunks [st.drawn, upto) that other ranks process."""
+        while st.drawn < upto:
+            c = st.drawn
+            sim = simulate_block_draws(st.module.generator, self._frames[c], st.tsize, st.args, has_anchors=c > 0)
+            st.lens[c] = sim["M_local"]
+            st.drawn += 1
+
+    def _owner(self, chunk: int) -> int:
+        return chunk % self.world
+
+    # ---- called by patch.compute_merge
+    def begin_block(self, module, key: str, fsize: int, tsize: int, args: Dict, like: torch.Tensor) -> None:
+        """Before the block's first draw: bring its generator to where the sequential run would be, and post the
+        receive of the predecessor chunk's tokens (their shape follows from the replayed draws)."""
+        i = self._cur
+        if i is None:
+            raise RuntimeError("chunk-parallel exchange: begin_chunk() was not called")
+        if fsize != self._frames[i]:
+            raise RuntimeError(f"chunk {i} has {fsize} frames, the step schedule says {self._frames[i]}")
+        st = self._blocks.get(key)
+        if st is None or st.module is not module:
+            st = self._blocks[key] = _BlockState(module, tsize, args)
+        st.tsize, st.args = tsize, args
+        self._replay(st, i)
+        st.drawn = i + 1                                   # compute_merge itself makes chunk i's draws
+        if not args["merge_global"] or i == 0 or self.mode == "allgather":
+            return
+        src = self._owner(i - 1)
+        if src == self.rank:                               # world == 1: the predecessor ran here
+            return
+        B = like.shape[0]
+        st.recv = self.t.irecv((B, st.lens[i - 1], like.shape[2]), like.dtype, like.device, src)
 
     def anchors_for(self, key: str, local_tokens_fn: Callable[[], torch.Tensor], like: torch.Tensor
                     ) -> Optional[torch.Tensor]:
-        if self.rank == 0:
-            return None                                    # first chunk of the step (generate.py:233-236)
-        # chunk lengths differ (first chunk is random-length, generate.py:176-178): shape header first
-        hdr = torch.empty(3, dtype=torch.int64, device=like.device)
-        dist.recv(hdr, src=self.rank - 1, group=self.group)
-        buf = torch.empty(tuple(int(v) for v in hdr.tolist()), dtype=like.dtype, device=like.device)
-        dist.recv(buf, src=self.rank - 1, group=self.group)
-        return buf
-
-    def publish(self, key: str, anchors: torch.Tensor) -> None:
-        if self.rank + 1 < self.world:
-            a = anchors.contiguous()
-            hdr = torch.tensor(list(a.shape), dtype=torch.int64, device=a.device)
-            dist.send(hdr, dst=self.rank + 1, group=self.group)
-            dist.send(a, dst=self.rank + 1, group=self.group)
-            self.bytes_sent += a.numel() * a.element_size()
-
-
-class AllGatherExchange:
-    """North-star mode: all-gather of every rank's local merged tokens; rank k merges against rank k-1's."""
-
-    def __init__(self, group=None):
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-        self.bytes_gathered = 0
-
-    def anchors_for(self, key: str, local_tokens_fn: Callable[[], torch.Tensor], like: torch.Tensor
-                    ) -> Optional[torch.Tensor]:
-        if self.world == 1:
-            return None
+        """The tokens chunk i merges against at this block (None for the first chunk of a step).  The parallel modes
+        first publish this chunk's own local merged tokens (``local_tokens_fn()``)."""
+        i, st = self._cur, self._blocks[key]
+        n = len(self._frames)
+        if self.mode == "ring":
+            if i == 0:
+                return None
+            if st.recv is None:
+                return st.carry                            # world == 1
+            got, st.recv = st.recv.wait(), None
+            self.bytes_received += got.numel() * got.element_size()
+            return got
         local = local_tokens_fn().contiguous()
-        out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-        if dist.get_backend(self.group) == "gloo":
-            parts = [torch.empty_like(local) for _ in range(self.world)]
-            dist.all_gather(parts, local, group=self.group)
-            out = torch.stack(parts)
-        else:
-            dist.all_gather_into_tensor(out, local, group=self.group)
-        self.bytes_gathered += out.numel() * out.element_size()
-        return out[(self.rank - 1) % self.world]
+        st.lens[i] = local.shape[1]
+        if self.mode == "neighbour":
+            if i + 1 < n:
+                self._send(local, self._owner(i + 1), st)
+            if i == 0:
+                return None
+            if st.recv is None:
+                got, st.carry = st.carry, local            # world == 1
+                return got
+            got, st.recv = st.recv.wait(), None
+            self.bytes_received += got.numel() * got.element_size()
+            return got
+        # all-gather: chunk lengths differ between ranks -> pad to the round's maximum (known from the replay)
+        first = i - self.rank
+        st_lens = dict(st.lens)
+        # lengths of the later chunks of this round: simulate on a COPY of the generator (their draws are consumed
+        # for real when this rank replays them before its next chunk)
+        gen = torch.Generator(device="cpu").set_state(st.module.generator.get_state())
+        self._skip_own_draws(gen, st, i)
+        for c in range(i + 1, min(first + self.world, n)):
+            st_lens[c] = simulate_block_draws(gen, self._frames[c], st.tsize, st.args, has_anchors=c > 0)["M_local"]
+        round_chunks = range(first, min(first + self.world, n))
+        m_max = max(st_lens[c] for c in round_chunks)
+        B, Ml, C = local.shape
+        padded = local if Ml == m_max else torch.cat([local, local.new_zeros(B, m_max - Ml, C)], dim=1)
+        gathered = self.t.all_gather(padded)               # every rank calls it once per round, also the idle ones
+        self.bytes_received += gathered.numel() * gathered.element_size()
+        prev_round_last, st.carry = st.carry, None
+        last = first + self.world - 1
+        if last < n:
+            st.carry = gathered[self.world - 1][:, :st_lens[last]]
+        if i == 0:
+            return None
+        if self.rank == 0:
+            return prev_round_last                         # chunk i-1 ran on rank W-1 in the previous round
+        return gathered[self.rank - 1][:, :st_lens[i - 1]]
+
+    def _skip_own_draws(self, gen: torch.Generator, st: _BlockState, i: int) -> None:
+        """all-gather only: `gen` is a copy taken after this chunk's LOCAL draws; the coin of its global level (made by
+        compute_merge right after anchors_for returns) still lies ahead of the later chunks' draws."""
+        if st.args["merge_global"] and i > 0:
+            torch.rand(1, generator=gen, device=gen.device)
 
     def publish(self, key: str, anchors: torch.Tensor) -> None:
-        return None
+        """After the block stored its new anchors (patch.py:80,82).  Exact mode forwards them to the next chunk."""
+        i, st = self._cur, self._blocks[key]
+        st.lens.setdefault(i, anchors.shape[1])
+        if self.mode != "ring":
+            return
+        if i + 1 >= len(self._frames):
+            return
+        dst = self._owner(i + 1)
+        if dst == self.rank:
+            st.carry = anchors
+            return
+        self._send(anchors.contiguous(), dst, st)
+
+    def _send(self, tensor: torch.Tensor, dst: int, st: _BlockState) -> None:
+        if dst == self.rank:
+            return
+        work = self.t.isend(tensor, dst)
+        self._inflight.append((work, tensor))
+        self.bytes_sent += tensor.numel() * tensor.element_size()
+
+
+class RingExchange(AnchorExchange):
+    """Exact mode (bit-identical to the sequential run)."""
+
+    def __init__(self, group=None, transport=None):
+        super().__init__("ring", transport, group)
+
+
+class NeighbourExchange(AnchorExchange):
+    """Parallel anchors from the predecessor chunk's local tokens, point-to-point."""
+
+    def __init__(self, group=None, transport=None):
+        super().__init__("neighbour", transport, group)
+
+
+class AllGatherExchange(AnchorExchange):
+    """Parallel anchors through one RCCL all-gather per merging block (north_star's wording)."""
+
+    def __init__(self, group=None, transport=None):
+        super().__init__("allgather", transport, group)
+
+    @property
+    def bytes_gathered(self) -> int:
+        return self.bytes_received
 
 
 # ----------------------------------------------------------------------------------------------------
 # wiring into the patched model
 # ----------------------------------------------------------------------------------------------------
-def enable(model: torch.nn.Module, exchange) -> None:
+def enable(model: torch.nn.Module, exchange: AnchorExchange) -> None:
     """Attach ``exchange`` to every patched block; compute_merge consults ``module._vtm_exchange``."""
     root = model.unet if hasattr(model, "unet") else model
     for name, m in root.named_modules():
@@ -146,3 +423,19 @@ def disable(model: torch.nn.Module) -> None:
     for _, m in root.named_modules():
         if hasattr(m, "_vtm_exchange"):
             del m._vtm_exchange
+
+
+def run_step(model: torch.nn.Module, exchange: AnchorExchange, frames_per_chunk: Sequence[int],
+             process_chunk: Callable[[int], None], reset_anchors: bool = True) -> List[int]:
+    """This rank's share of one denoising step (generate.py:215-219 + :233-236): its chunks in schedule order, then
+    the anchor reset.  ``process_chunk(i)`` runs the patched model on chunk i.  Returns the chunk indices processed."""
+    from . import patch
+    exchange.begin_step(frames_per_chunk)
+    mine = exchange.my_chunks()
+    for i in mine:
+        exchange.begin_chunk(i)
+        process_chunk(i)
+    exchange.end_step()
+    if reset_anchors:
+        patch.update_patch(model, global_tokens=None)
+    return mine

@@ -89,9 +89,15 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
 
     plan = MergePlan()
     plan.fsize = fsize
+    # chunk-parallel runs (chunk_parallel.py): the exchange replays the draws of the chunks other ranks process
+    # and posts the receive of the predecessor's anchor tokens before this block's own first draw
+    exchange = getattr(module, "_vtm_exchange", None)
+    xkey = getattr(module, "_vtm_key", "")
     with torch.no_grad():
         xj = join_frame(x.contiguous(), fsize)                                     # patch.py:37 (a view)
         B, L, C = xj.shape
+        if exchange is not None:
+            exchange.begin_block(module, xkey, fsize, tsize, args, xj)
         plan.x_joined, plan.L = xj, L
         cur: Optional[torch.Tensor] = None      # pool row id of every token of the current sequence
         inv: Optional[torch.Tensor] = None      # composed unmerge map so far
@@ -114,10 +120,8 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
 
         anchors_out = None
         if args["merge_global"]:                                                   # patch.py:59-82
-            exchange = getattr(module, "_vtm_exchange", None)     # chunk-parallel runs (chunk_parallel.py)
             if exchange is not None:
-                gt = exchange.anchors_for(getattr(module, "_vtm_key", ""),
-                                          lambda: xj if cur is None else _lib.gather_rows(xj, None, cur), xj)
+                gt = exchange.anchors_for(xkey, lambda: xj if cur is None else _lib.gather_rows(xj, None, cur), xj)
             else:
                 gt = getattr(module, "global_tokens", None)
             if gt is not None:
@@ -156,9 +160,8 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 # patch.py:82: first chunk of a step stores its local tokens (device-resident, shared
                 # with `merged`, which nothing mutates)
                 module.global_tokens = merged[:, :Ml] if merged.shape[1] != Ml else merged
-            exchange = getattr(module, "_vtm_exchange", None)
             if exchange is not None:
-                exchange.publish(getattr(module, "_vtm_key", ""), module.global_tokens)
+                exchange.publish(xkey, module.global_tokens)
 
     def m(t: torch.Tensor, **kwarg) -> torch.Tensor:                               # patch.py:84
         tj = join_frame(t.contiguous(), fsize)
