@@ -11,15 +11,20 @@ batch 2 (CFG [uncond | cond]) x 16 frames, local merge 0.5 + global merge 0.5 in
 block's anchor tokens were populated by a preceding chunk, as for every chunk but the first of a step).
 Synthetic fp16 hidden states (frame-correlated), random-init weights; inputs are resident in HBM before
 the timed region.  N > 1: one process per GPU, each rank runs its own chunk (weak scaling); local merging needs
-no collective, the global level takes its anchor tokens from an RCCL all-gather of every rank's local merged tokens
-per merging block (chunk_parallel.AllGatherExchange); value = chunk-steps per second over all ranks.
+no collective, the global level takes its anchor tokens from the previous rank's chunk (chunk_parallel.py:
+`--exchange neighbour` = point-to-point shift of every rank's local merged tokens over one xGMI link, the default;
+`allgather` = the same semantics through an RCCL all-gather per merging block; `ring` = the exact serial chain);
+value = chunk-steps per second over all ranks.
 
 The JSON line also carries
   roofline:     the dominant kernel (attention_kernel: flash attention over the merged tokens, fp16 MFMA), its
-                algorithmic FLOPs / HIP-event time over the timed region vs the 2.5 PFLOP/s dense fp16 peak;
-  matching:     the fused cosine score + row top-1 step (fp32-exact), algorithmic FLOPs / HIP-event time;
-  cpu_baseline: the CPU oracle (a port of the reference's algorithm) timed on this host's cores on a
-                bounded sample of the same workload and extrapolated to a whole step.
+                executed FLOPs / HIP-event time over the timed region vs the 2.5 PFLOP/s dense fp16 peak;
+  matching:     the fused similarity + top-1 step (fp16-MFMA filter + exact fp32 refine): executed fp16 FLOPs / HIP-event
+                time vs the same fp16 peak (the exact fp32-MFMA fallback would be bounded by 157.3 TFLOP/s);
+  gather_path:  the HBM-bound kernels (LayerNorm, merge gather, unmerge + residual): algorithmic bytes / HIP-event time
+                vs 8 TB/s, next to the counter-derived (rocprofv3 FETCH_SIZE / WRITE_SIZE) rates from profiles/;
+  cpu_baseline: a plain-PyTorch CPU restatement of the same segment (oracle/torch_baseline.py: bmm + max + argsort +
+                gather + SDPA, fp32) TIMED on this host's cores on one full site of every kind and summed to a step.
 """
 import argparse
 import json
@@ -37,6 +42,7 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3          # MI355X fp32 vector / fp32-MFMA peak (MI355X_MICROARCH.md)
 FP16_PEAK_TFLOPS = 2500.0         # dense fp16/bf16 MFMA peak (not the 2:1-sparse marketing figure)
+HBM_PEAK_GBPS = 8000.0            # HBM3E spec (~6300 achievable, MI355X_MICROARCH.md)
 BATCH, FRAMES, LATENT = 2, 16, (64, 64)
 LOCAL_RATIO, GLOBAL_RATIO = 0.5, 0.5
 
@@ -47,7 +53,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=150.0,
+                    help="time budget of the CPU baseline: a top site whose full batch would not fit is timed on one "
+                         "batch sample and doubled")
+    ap.add_argument("--cpu-baseline", choices=["torch", "port"], default="torch",
+                    help="torch = plain-PyTorch restatement, timed on full sites; port = the C/OpenMP oracle, row slices")
+    ap.add_argument("--exchange", choices=["neighbour", "allgather", "ring"], default="neighbour",
+                    help="N > 1: how the global level gets its anchor tokens (chunk_parallel.py)")
     ap.add_argument("--local-only", action="store_true", help="merge_global=False variant (not the headline)")
     return ap.parse_args()
 
@@ -60,7 +72,7 @@ class KernelTimer:
     def __init__(self, lib_mod):
         self.lib_mod = lib_mod
         self.orig = {}
-        self.records = {"attention": [], "matching": []}
+        self.records = {"attention": [], "matching": [], "layernorm": [], "gather_rows": [], "unmerge_add": []}
         self.enabled = False
 
     def _wrap(self, name, kind, flops_of):
@@ -87,6 +99,13 @@ class KernelTimer:
         self._wrap("match_filtered", "matching",
                    lambda x0, x1, ar, br, align, want_flag=False: 2.0 * x0.shape[0] * ar.shape[1] * br.shape[1] * x0.shape[2])
         self._wrap("match", "matching", lambda a, b, Ns, Nd, align: 2.0 * a.shape[0] * Ns * Nd * a.shape[1] * 8)
+        # the HBM-bound kernels: algorithmic BYTES per call (rows read + rows written, indices ignored)
+        esz = lambda t: t.element_size()
+        self._wrap("layernorm", "layernorm", lambda x, w, b, eps: 2.0 * x.numel() * esz(x))
+        self._wrap("gather_rows", "gather_rows",
+                   lambda x0, x1, idx, pad_to=1: 2.0 * idx.numel() * x0.shape[2] * esz(x0))
+        self._wrap("unmerge_add", "unmerge_add",
+                   lambda y, inv, resid: (2.0 + (resid is not None)) * inv.numel() * y.shape[2] * esz(y))
         return self
 
     def __exit__(self, *exc):
@@ -110,26 +129,42 @@ class KernelTimer:
         return top, sum(r[1].elapsed_time(r[2]) for r in sel) / len(sel), len(sel)
 
 
+def _profile_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f), name
+    except Exception:
+        return None, None
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel's largest configuration (top-block attention: 34 816 live queries
-    x 52 224 keys),
-    from the rocprofv3 PMC passes recorded in profiles/r01_pmc_traffic.json (FETCH_SIZE doubled per the gfx950
-    note + WRITE_SIZE); None if the profile file is absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            d = json.load(f)
-        for key in ("attention_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224 (r01_k)",
-                    "attention_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224 (r01_f)",
-                    "attention_kernel<half,40> B=2 h=8 M=52224 (r01_e)", "attention_kernel<half,40> B=2 h=8 M=52224"):
-            if key in d:
-                return int(d[key]["hbm_bytes_per_launch"])
-        return None
-    except Exception:
-        return None
+    x 52 224 keys).  NOT measured in this run: read from the committed rocprofv3 PMC passes under profiles/
+    (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, separate --pmc runs of tools/kbench.py on the same shape).
+    Returns (bytes or None, source string)."""
+    for fname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        d, src = _profile_json(fname)
+        if not d:
+            continue
+        for key in sorted(d, reverse=True):
+            if key.startswith("attention_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224") and "hbm_bytes_per_launch" in d[key]:
+                return int(d[key]["hbm_bytes_per_launch"]), f"profiles/{src}: {key} (rocprofv3 --pmc, not this run)"
+    return None, None
 
 
-def cpu_baseline(target_seconds: float):
-    """Time the CPU oracle on a bounded sample of the cfg-2 step and extrapolate to the whole step.
+def pmc_gather_path():
+    """Counter-derived HBM rates of the gather-path kernels at working sets beyond the 256 MB Infinity Cache
+    (profiles/r02_pmc_traffic.json, section "gather_path"); None when the profile is absent."""
+    d, src = _profile_json("r02_pmc_traffic.json")
+    if not d or "gather_path" not in d:
+        return None
+    out = dict(d["gather_path"])
+    out["source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not this run)"
+    return out
+
+
+def cpu_baseline_port(target_seconds: float):
+    """`--cpu-baseline port`: time the C/OpenMP CPU oracle on a bounded sample of the cfg-2 step and extrapolate to the whole step.
     Sample: for one top site (N=4096, C=320) and one mid site (N=1024, C=640): the three matching levels on a
     slice of src rows, the attention on a slice of query rows, and the projections on a slice of rows; the
     un-merged sites are cheap and measured on one site each.  Everything is scaled by (full rows / sampled
@@ -142,7 +177,7 @@ def cpu_baseline(target_seconds: float):
     total = 0.0
     spent = 0.0
     detail = {}
-    scale_rows = max(0.25, target_seconds / 20.0)
+    scale_rows = max(0.25, min(target_seconds, 20.0) / 20.0)
 
     def timed(fn):
         t0 = time.perf_counter()
@@ -197,6 +232,35 @@ def cpu_baseline(target_seconds: float):
             "seconds_per_step_estimate": round(total, 1)}
 
 
+def cpu_baseline_torch(budget_s: float):
+    """The reference's PyTorch CPU path, restated (oracle/torch_baseline.py), TIMED on this host: one full site of
+    every kind of the cfg-2 step in steady state (anchors populated), fp32, all host threads; a step = sum over the 16
+    sites.  Nothing is extrapolated from slices; if the top site's full batch would exceed the budget it is timed on
+    one of the two batch samples and doubled (every operation of the path is independent per sample)."""
+    from oracle import torch_baseline as tb
+    from vidtome_amd import sites
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    args = {"max_downsample": 2, "target_stride": 4, "local_merge_ratio": LOCAL_RATIO, "merge_global": True,
+            "global_merge_ratio": GLOBAL_RATIO, "global_rand": 0.5}
+    r = tb.time_step(BATCH, FRAMES, LATENT, sites.sd15_sites(), args, budget_s)
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except Exception:
+        pass
+    how = "every site kind timed in full" if not r["sampled"] else \
+        f"site kinds {r['sampled']} timed on 1 of {BATCH} batch samples and doubled, the others in full"
+    return {"value": 1.0 / r["seconds_per_step"], "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "torch",
+            "cpu": cpu,
+            "sample": f"plain-PyTorch fp32 restatement of the segment (LayerNorm, normalise, bmm score matrix, max, "
+                      f"argsort, gather / scatter merge + unmerge, global level, Linear projections, SDPA) on "
+                      f"{torch.get_num_threads()} host threads, one site of each of the 4 kinds of the cfg-2 step in steady "
+                      f"state, {how}; {r['spent']:.1f} s measured -> {r['seconds_per_step']:.1f} s per 16-site step",
+            "seconds_per_step": round(r["seconds_per_step"], 2), "detail": r["detail"]}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,17 +289,26 @@ def main():
     vidtome_amd.apply_patch(unet, local_merge_ratio=LOCAL_RATIO, merge_global=not args.local_only,
                             global_merge_ratio=GLOBAL_RATIO, batch_size=BATCH, target_stride=4, global_rand=0.5)
     unet.set_size(LATENT)
+    total_passes = 1 + args.warmup + args.steps
+    ex = None
     if world > 1 and not args.local_only:
-        # north-star multi-GPU mode: every rank owns one chunk; per merging block the ranks all-gather their
-        # local merged tokens over RCCL/xGMI and merge against the previous rank's (chunk_parallel.py)
+        # every rank owns one chunk per pass; per merging block the global level takes its anchor tokens from the
+        # previous rank's chunk over RCCL / xGMI (chunk_parallel.py).  The whole run is ONE stream of chunks
+        # (chunk index = pass * world + rank), so the exchange knows which chunk is the last and leaves no send unmatched.
         from vidtome_amd import chunk_parallel as cp
-        cp.enable(unet, cp.AllGatherExchange())
+        ex = cp.AnchorExchange(args.exchange)
+        cp.enable(unet, ex)
+        ex.begin_step([FRAMES] * (total_passes * world))
     torch.manual_seed(123)           # the block generators fork this state (default.yaml seed)
     # each rank works on its own chunk of the video: different synthetic frames per rank
     hiddens = [sites.synthetic_hidden(s, BATCH, FRAMES, LATENT, torch.float16, dev, seed=1234 + 97 * rank + i)
                for i, s in enumerate(sites.sd15_sites())]
+    passes = [0]
 
     def step():
+        if ex is not None:
+            ex.begin_chunk(passes[0] * world + rank)
+        passes[0] += 1
         with torch.no_grad():
             return sites.run_segment_pass(unet, hiddens)
 
@@ -256,6 +329,8 @@ def main():
             step()
         fence()
         dt = time.perf_counter() - t0
+    if ex is not None:
+        ex.end_step()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -270,42 +345,75 @@ def main():
         att_tf = aflops / (ams * 1e-3) / 1e12 if ams > 0 else 0.0
         mat_tf = mflops / (mms * 1e-3) / 1e12 if mms > 0 else 0.0
         from vidtome_amd import merge as _merge
+        filtered = _merge.MATCH_MODE != "exact"
+        traffic, traffic_src = pmc_traffic()
+
+        def hbm(kind):
+            """algorithmic bytes / HIP-event time of one HBM-bound kernel: all launches, and the largest ones alone"""
+            by, ms, n = mt.summary(kind)
+            tb_, tms, tn = mt.largest(kind)
+            rate = lambda b_, m_: round(b_ / (m_ * 1e-3) / 1e9, 1) if m_ > 0 else 0.0
+            return {"launches": n, "ms_per_step": round(ms / args.steps, 3), "GBps": rate(by, ms),
+                    "largest": {"launches": tn, "MB": round(tb_ / 1e6, 1), "avg_us": round(tms * 1e3, 1),
+                                "GBps": rate(tb_, tms), "frac_of_hbm_peak": round(rate(tb_, tms) / HBM_PEAK_GBPS, 3)}}
+
+        par = f"chunk-parallel x{world}"
+        if ex is not None:
+            par += {"neighbour": ", anchor tokens = the previous rank's local merged tokens, point-to-point over RCCL/xGMI "
+                                 "per merging block",
+                    "allgather": ", RCCL all-gather of the anchor tokens per merging block",
+                    "ring": ", exact serial anchor chain (ring hand-off over RCCL/xGMI)"}[args.exchange]
         line = {
             "metric": "denoising steps/sec, 16-frame 512x512 SD-1.5 chunk, ratio=0.5",
             "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16 tokens / f32-exact matching / f16 MFMA attention",
+            "scaling": "weak", "vs_baseline": None,
+            # the arithmetic types of the path: tokens fp16; matching = fp16-MFMA candidate filter + fp32 exact
+            # refinement (result bit-identical to an all-fp32 matcher); attention = fp16 MFMA, fp32 accumulate / softmax
+            "dtype": "f16 tokens; matching f16-MFMA filter + f32 exact refine (f32-identical indices); attention f16 MFMA "
+                     "with f32 accumulate" if filtered else
+                     "f16 tokens; matching f32 MFMA (exact); attention f16 MFMA with f32 accumulate",
             "data": "synthetic",
             "config": {"workload": "SD-1.5 16 frames 512x512 (cfg-2): hot-path pass over the 16 transformer-block "
                                    "sites, batch 2 (CFG), local merge 0.5" +
                                    ("" if args.local_only else " + global merge 0.5 (steady state)"),
                        "sites": 16, "merged_sites": 10, "chunk_frames": FRAMES, "batch": BATCH,
-                       "matcher": _merge.MATCH_MODE,
-                       "parallelism": f"chunk-parallel x{world}" + (", RCCL all-gather of the anchor tokens per merging "
-                                                                     "block" if world > 1 else "")},
+                       "matcher": _merge.MATCH_MODE + (" (fp16-MFMA filter, fp32 refine; global-level index order inside "
+                                                       "groups of EXACTLY equal similarity is the stable one, the "
+                                                       "reference's is implementation-defined)" if filtered else ""),
+                       "parallelism": par},
             # dominant single kernel of the step: the merged-token self-attention (MFMA-bound)
             # `achieved` counts EXECUTED flops (4 B Mq Mk C per launch): with a global level the block only computes the
             # attention rows unmerge() reads, so the reference-algorithmic 4 B M^2 C would overstate the kernel
             "roofline": {"kernel": "attention_kernel<half,d> (flash attention over merged tokens, "
                                    "v_mfma_f32_32x32x16_f16; executed flops)",
                          "bound": "mfma", "achieved": round(att_tf, 1), "peak": FP16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(att_tf / FP16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                         "unit": "TFLOP/s", "frac": round(att_tf / FP16_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "launches": an, "avg_launch_ms": round(ams / max(an, 1), 4),
                          # the top-block launches alone (compare with attention_kernel<half,40> in profiles/*_kernel_stats.txt)
                          "top_block": {"launches": top_n, "avg_ms": round(top_ms, 4),
                                        "tflops": round(top_flops / (top_ms * 1e-3) / 1e12, 1) if top_ms > 0 else 0.0},
                          "attention_ms_per_step": round(ams / args.steps, 3)},
-            # the fused similarity + top-1 step (second largest): algorithmic fp32 FLOPs of the reference's
-            # `a @ b.T` + max over HIP-event time; the filtered matcher produces the fp32-exact result with
-            # fp16-MFMA filtering, so its algorithmic rate may exceed the fp32 peak it is quoted against
-            "matching": {"kernels": "filter_kernel + refine_kernel (vtm_match_filtered)" if _merge.MATCH_MODE != "exact"
+            # the fused similarity + top-1 step (second largest).  The filtered matcher executes the reference's
+            # 2 B Ns Nd C flops ONCE on the fp16 MFMA (one-product filter) and re-evaluates the few surviving pairs in
+            # fp32: its roof is the fp16 MFMA peak.  The exact fallback kernel runs on the fp32 MFMA (157.3 TFLOP/s).
+            "matching": {"kernels": "filter_kernel + survivors + refine_kernel (vtm_match_filtered)" if filtered
                                     else "match_kernel (vtm_match)",
-                         "algorithmic_tflops": round(mat_tf, 1), "fp32_peak": FP32_PEAK_TFLOPS,
-                         "frac_of_fp32_peak": round(mat_tf / FP32_PEAK_TFLOPS, 3), "calls": mn,
-                         "matching_ms_per_step": round(mms / args.steps, 3)},
+                         "executed_tflops": round(mat_tf, 1),
+                         "peak": FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS,
+                         "frac": round(mat_tf / (FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS), 4),
+                         "calls": mn, "matching_ms_per_step": round(mms / args.steps, 3)},
+            # the HBM-bound kernels of the path: algorithmic bytes (rows read + rows written) / HIP-event time.  The
+            # cfg-2 working sets (<= 212 MB) fit the 256 MB Infinity Cache, so `pmc` carries the counter-derived rates
+            # measured beyond it
+            "gather_path": {"hbm_peak_GBps": HBM_PEAK_GBPS, "layernorm": hbm("layernorm"),
+                            "gather_rows": hbm("gather_rows"), "unmerge_add": hbm("unmerge_add"),
+                            "pmc": pmc_gather_path()},
         }
         if not args.no_cpu_baseline and world == 1:           # reported on rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            line["cpu_baseline"] = (cpu_baseline_torch if args.cpu_baseline == "torch" else cpu_baseline_port)(
+                args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -258,3 +258,31 @@ def test_oracle_vs_reference_fuzz(oracle):
                 assert fuzz_hash(state["global_tokens"]) == want[1], (cfg, ck)
             assert fuzz_hash(u(merged)) == want[2], (cfg, ck)
 
+
+
+def test_torch_baseline_times_the_right_algorithm(oracle):
+    """oracle/torch_baseline.py (bench.py's `cpu_baseline.kind = "torch"` leg) is a plain-PyTorch restatement of the
+    same segment: on a small multi-chunk case (two local levels, global level, both coin outcomes over 7 chunks) its
+    block outputs, anchors and generator draws equal the pinned oracle's."""
+    import torch
+    from oracle import torch_baseline as tb
+    B, Fr, H, W, C, heads = 2, 8, 8, 8, 64, 2
+    args = {"batch_size": B, "max_downsample": 2, "target_stride": 4, "local_merge_ratio": 0.5, "merge_global": True,
+            "global_merge_ratio": 0.5, "align_batch": False, "global_rand": 0.5}
+    w = tb.random_weights(C, 1)
+    wn = {k: v.numpy() for k, v in w.items()}
+    g = torch.Generator().manual_seed(5)
+    gen_t, gen_o = torch.Generator().manual_seed(123), torch.Generator().manual_seed(123)
+    draws = oracle.RandomDraws.from_torch_generator(gen_o)
+    st_t, st_o = {}, {"global_tokens": None}
+    coins = set()
+    for ck in range(7):
+        x = torch.randn(B * Fr, H * W, C, generator=g)
+        yt = tb.segment(x, B, args, st_t, gen_t, w, heads)
+        yo, trace = oracle.patched_self_attention_segment(x.numpy(), (H, W), args, draws, st_o, wn, heads)
+        np.testing.assert_allclose(yt.numpy(), yo, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(st_t["global_tokens"].numpy(), st_o["global_tokens"], rtol=0, atol=1e-5)
+        assert torch.equal(gen_t.get_state(), gen_o.get_state())
+        if trace["global"] is not None:
+            coins.add(trace["global"]["local_chunk"])
+    assert coins == {0, 1}
