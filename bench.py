@@ -234,13 +234,12 @@ def cpu_baseline_port(target_seconds: float):
 
 def cpu_baseline_torch(budget_s: float):
     """The reference's PyTorch CPU path, restated (oracle/torch_baseline.py), TIMED on this host: one full site of
-    every kind of the cfg-2 step in steady state (anchors populated), fp32, all host threads; a step = sum over the 16
+    every kind of the cfg-2 step in steady state (anchors populated), fp32, torch's default intra-op threads (the physical cores); a step = sum over the 16
     sites.  Nothing is extrapolated from slices; if the top site's full batch would exceed the budget it is timed on
     one of the two batch samples and doubled (every operation of the path is independent per sample)."""
     from oracle import torch_baseline as tb
     from vidtome_amd import sites
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # torch's own default intra-op thread count (= the physical cores it detects): what the reference would run with
     args = {"max_downsample": 2, "target_stride": 4, "local_merge_ratio": LOCAL_RATIO, "merge_global": True,
             "global_merge_ratio": GLOBAL_RATIO, "global_rand": 0.5}
     r = tb.time_step(BATCH, FRAMES, LATENT, sites.sd15_sites(), args, budget_s)

@@ -155,22 +155,24 @@ def test_two_rank_exchange_gloo(oracle, mode):
         assert ok, f"rank {rank} failed: {err}"
 
 
-def test_three_fake_ranks_in_process(oracle):
-    """the single-process N-fake-rank replay -- three exchange endpoints on an in-memory transport,
-    the chunks executed in schedule order, equal the sequential run (ring) bit for bit."""
+@pytest.mark.parametrize("W", [1, 3])
+def test_fake_ranks_in_process(oracle, W):
+    """the single-process N-fake-rank replay -- W exchange endpoints on an in-memory transport,
+    the chunks executed in schedule order, equal the sequential run (ring) bit for bit; W = 1 is the degenerate
+    hand-over in place."""
     from vidtome_amd import chunk_parallel as cp
     steps = STEPS["ring"]
     for mode in ("ring", "neighbour"):
         ref, ref_end = _reference(oracle, mode, steps)
         tpf = HW[0] * HW[1]
-        fabric = cp.LocalTransport.fabric(3)
+        fabric = cp.LocalTransport.fabric(W)
         exs = [cp.AnchorExchange(mode, transport=t) for t in fabric]
-        mods = [[_Module(_fork()) for _ in range(NBLK)] for _ in range(3)]
+        mods = [[_Module(_fork()) for _ in range(NBLK)] for _ in range(W)]
         for s, frames in enumerate(steps):
             for ex in exs:
                 ex.begin_step(frames)
             for i, F in enumerate(frames):
-                ex, r = exs[i % 3], i % 3
+                ex, r = exs[i % W], i % W
                 ex.begin_chunk(i)
                 for blk in range(NBLK):
                     key, mod = f"b{blk}", mods[r][blk]
@@ -190,7 +192,7 @@ def test_three_fake_ranks_in_process(oracle):
                     assert np.array_equal(state["global_tokens"], ref[(s, i, blk)][1]), (mode, s, i, blk)
             for ex in exs:
                 ex.end_step()
-        for r in range(3):
+        for r in range(W):
             for blk in range(NBLK):
                 assert torch.equal(mods[r][blk].generator.get_state(), ref_end[blk])
 

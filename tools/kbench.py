@@ -4,6 +4,7 @@
     python tools/kbench.py match  [--shape top_l1|top_l2|top_g|mid_l1] [--iters 5]
     python tools/kbench.py attn   [--M 52224 --d 40 --heads 8 --B 2] [--iters 3]
     python tools/kbench.py sort   [--n 49152]
+    python tools/kbench.py gather|unmerge|layernorm [--B 4 --n 147456 --C 320]   (HBM-bound kernels beyond the MALL)
 """
 import argparse
 import os
@@ -45,6 +46,7 @@ def main():
     ap.add_argument("--B", type=int, default=2)
     ap.add_argument("--n", type=int, default=49152)
     ap.add_argument("--align", action="store_true")
+    ap.add_argument("--C", type=int, default=320)
     a = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
@@ -84,6 +86,30 @@ def main():
         keys = torch.randint(0, 2 ** 62, (a.B, a.n), generator=g, device=dev, dtype=torch.int64)
         med, best = timeit(lambda: _lib.sort_desc(keys), a.iters)
         print(f"sort rows={a.B} n={a.n}: median {med * 1e3:.1f} us, best {best * 1e3:.1f} us")
+    elif a.what in ("gather", "unmerge", "layernorm"):
+        # the HBM-bound kernels at a working set BEYOND the 256 MB Infinity Cache (run under rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE for counter-derived GB/s): cfg-5 top block (SD-2.1-768: L = 16 x 9216 tokens, C = 320)
+        # with --B 4, i.e. 377 MB per (B, L, C) fp16 tensor
+        B, L, C = a.B, a.n, a.C
+        M = int(L * 0.53) // 8 * 8
+        x = torch.randn(B, L, C, generator=g, device=dev, dtype=torch.float16)
+        if a.what == "layernorm":
+            w = torch.ones(C, device=dev, dtype=torch.float16)
+            bb = torch.zeros(C, device=dev, dtype=torch.float16)
+            med, best = timeit(lambda: _lib.layernorm(x, w, bb, 1e-5), a.iters)
+            nbytes = 2.0 * B * L * C * 2
+        elif a.what == "gather":
+            idx = torch.stack([torch.randperm(L, generator=g, device=dev)[:M] for _ in range(B)]).to(torch.int32)
+            idx = idx.sort(dim=1).values.contiguous()       # merged rows are mostly ascending runs of pool rows
+            med, best = timeit(lambda: _lib.gather_rows(x, None, idx), a.iters)
+            nbytes = 2.0 * B * M * C * 2
+        else:
+            y = torch.randn(B, M, C, generator=g, device=dev, dtype=torch.float16)
+            inv = torch.randint(0, M, (B, L), generator=g, device=dev, dtype=torch.int32)
+            med, best = timeit(lambda: _lib.unmerge_add(y, inv, x), a.iters)
+            nbytes = (B * M + 2.0 * B * L) * C * 2
+        print(f"{a.what} B={B} L={L} M={M} C={C}: {nbytes / 1e6:.1f} MB algorithmic, median {med * 1e3:.1f} us "
+              f"({nbytes / med / 1e6:.0f} GB/s), best {best * 1e3:.1f} us ({nbytes / best / 1e6:.0f} GB/s)")
     else:
         raise SystemExit("unknown benchmark")
 

@@ -320,11 +320,11 @@ class AnchorExchange:
         if self.mode == "neighbour":
             if i + 1 < n:
                 self._send(local, self._owner(i + 1), st)
+            if self.world == 1:                            # the predecessor ran here: hand over in place
+                got, st.carry = st.carry, local
+                return got if i > 0 else None
             if i == 0:
                 return None
-            if st.recv is None:
-                got, st.carry = st.carry, local            # world == 1
-                return got
             got, st.recv = st.recv.wait(), None
             self.bytes_received += got.numel() * got.element_size()
             return got
