@@ -94,12 +94,14 @@ int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd,
  * the residual lo terms are a build-time option) collects for every src row the dst rows whose approximate score lies within a
  * rigorous error window of the row's running maximum, and an fp32 refine pass evaluates the canonical
  * fmaf chain on those candidates only.  A row with more than 64 candidates (massively duplicated dst
- * rows) is recomputed exactly on its own; any non-finite normalised component (zero token) raises a
- * device flag that makes a gated launch of the plain fp32 kernel recompute the whole call (exact, no host
- * round trip).  C > 1280 is rejected (the error budget is derived for C <= 1280; use vtm_match).
+ * rows) is recomputed exactly on its own; a row without a finite positive norm (zero token -> NaN xhat,
+ * merge.py:84 has no eps) raises a device flag that makes the refine pass recompute EVERY row of the call
+ * exactly (no host round trip).  Four launches per call: operand preparation (canonical norms + fp16 panels),
+ * filter, survivor compaction, refine.  C > 1280 is rejected (the error budget is derived for C <= 1280; use
+ * vtm_match).
  * Inputs are the token pool (x0 | x1, as vtm_normalize_gather) and the gathered pool ids a_rows (B, Ns),
  * b_rows (B, Nd).  ws: >= vtm_match_filtered_ws_bytes(...) bytes.  flags_out (optional, 4 int32,
- * device): [0] = [1] = 1 if the whole-call exact fallback ran (non-finite component), [2] = number of
+ * device): [0] = [1] = 1 if every row was recomputed exactly (non-finite component), [2] = number of
  * rows recomputed exactly because their candidate list overflowed, [3] = number of (row, dst) pairs the
  * refine pass evaluated.  Derivation of the window: vidtome_amd/csrc/match_filter.hip.
  * ---------------------------------------------------------------------------------------------- */

@@ -154,7 +154,7 @@ def test_match_filtered_hard_cases(L):
     xf[:, Ns + 2] = xf[:, Ns] + 3e-7 * torch.randn(B, C, generator=g)
     xf[:, 0] = xf[:, Ns] + 1e-3 * torch.randn(B, C, generator=g)
     _filtered_vs_exact(L, xf.to(DEV), Ns, Nd, False, expect_flag=0)
-    # (4) zero token -> NaN row -> device flag -> gated exact kernel
+    # (4) zero token -> NaN row -> device flag -> every row recomputed by refine_kernel's exact row pass
     x = torch.randn(B, Ns + Nd, C, generator=g).half()
     x[0, 3] = 0
     x[1, Ns + 50] = 0
@@ -170,6 +170,41 @@ def test_match_filtered_hard_cases(L):
         _filtered_vs_exact(L, x.to(DEV), Ns, Nd, align, expect_flag=0)
         _, flag = L.match_filtered(x.to(DEV), None, ra, rb, align, want_flag=True)
         assert int(flag[2].item()) == (Ns if align else B * Ns)
+
+
+@pytest.mark.parametrize("C", [64, 256, 1024])
+def test_match_filtered_adversarial_window(L, C):
+    """The filter drops the fp16 residuals (`lo`) of both operands; its window budget (match_filter.hip, EPS) assumes
+    the worst case sum |a_k b_k| = 1 with every dropped half-ulp pulling the same way.  Build exactly that: rows whose
+    normalised components all sit a hair under the rounding midpoint above a power of two (1024 * xhat = 2^e * (1 +
+    0.96 * 2^-11): hi = 2^e, lo = +0.96 half-ulp -- the largest relative residual fp16 allows), all products positive,
+    cosine ~1 between all of them, and true scores that differ only at the 1e-6 level while the filter errs by up to
+    ~9.6e-4 in one direction for some pairs and not for others.  filtered must still equal exact, bit for bit."""
+    g = torch.Generator().manual_seed(C)
+    B, Ns, Nd = 2, 300, 500
+    h = 1024.0 / C ** 0.5                           # 1024 * xhat of a flat unit vector: a power of two for these C
+    assert 2 ** round(np.log2(h)) == h
+    up = h * (1 + 0.96 * 2.0 ** -11) / 1024.0       # rounds DOWN to h: lo = +0.96 half-ulp (relative 4.7e-4)
+    dn = h * (1 - 0.96 * 2.0 ** -12) / 1024.0       # rounds UP to h:   lo = -0.96 half-ulp of the binade below
+    flat = h / 1024.0
+
+    def rows(n, kinds):
+        r = torch.empty(B, n, C, dtype=torch.float64)
+        for i in range(n):
+            v = kinds[i % len(kinds)]
+            r[:, i] = v
+            r[:, i, (7 * i) % C] = (1.0 - (C - 1) * v * v) ** 0.5     # one component absorbs the rest of the unit norm
+        r *= 1 + 2e-6 * torch.randn(B, n, C, generator=g, dtype=torch.float64)      # decides the TRUE order
+        return r
+    # src rows of both signs of residual; dst rows of both signs plus exactly representable ones
+    x = torch.cat([rows(Ns, [up, dn]), rows(Nd, [up, dn, flat, up])], dim=1).float()
+    flag = _filtered_vs_exact(L, x.to(DEV), Ns, Nd, False)
+    _filtered_vs_exact(L, x.to(DEV), Ns, Nd, True)
+    assert flag == 0
+    # the construction does what it says: the hi-only products of an (up, up) pair underestimate by ~2u
+    xh = x[0, :1].double() / x[0, :1].double().norm()
+    hi = (xh * 1024).half().double()
+    assert 8e-4 < float(1.0 - (hi * hi).sum() / 1024 ** 2) < 9.9e-4
 
 
 def test_match_filtered_full_size(L):

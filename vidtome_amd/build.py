@@ -41,17 +41,22 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(LIBDIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, defines=(), tag: str = "") -> str:
+    """Build the library.  `defines` / `tag` produce an experiment variant next to the shipped one
+    (lib/variants/<tag>/libvidtome_hip.so, selected with VIDTOME_HIP_LIB; used by tools/kbench.py comparisons)."""
+    libdir = os.path.join(LIBDIR, "variants", tag) if tag else LIBDIR
+    lib = os.path.join(libdir, "libvidtome_hip.so")
+    os.makedirs(libdir, exist_ok=True)
     cc = hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "vidtome_hip.h")]
     objs, jobs = [], []
+    flags = FLAGS + ["-D" + d for d in defines]
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(libdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([cc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([cc, *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -65,10 +70,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         for out in ex.map(run, jobs):
             if verbose and out.strip():
                 print(out)
-    if force or jobs or _stale(LIB, objs):
-        run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m vidtome_amd.build [--force] [--tag NAME -DMACRO ...]
+    argv = sys.argv[1:]
+    tag = argv[argv.index("--tag") + 1] if "--tag" in argv else ""
+    print(build(force="--force" in argv, verbose=True, defines=[a[2:] for a in argv if a.startswith("-D")], tag=tag))

@@ -319,9 +319,11 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     }
 
     // hoisted staging addresses: chunk c = tid + 256 i ; K: (row c / DCH, 16-byte piece c % DCH);
-    // V^T: (channel row c / 8, key piece c % 8).  The tile bases are wave-uniform (scalar) pointers that
-    // advance by 64 rows / 64 keys per tile; the per-thread parts are 32-bit element offsets computed once.
-    int kgo[K_PER_T], vgo[V_PER_T];      // global element offsets relative to the tile base
+    // V^T: (channel row c / 8, key piece c % 8).  Tiles are fetched with buffer loads: a wave-uniform descriptor of
+    // the (sample, head) slice, a per-thread 32-bit byte offset computed once, and a scalar tile offset that advances by
+    // 64 rows / 64 keys per tile -- no vector address arithmetic inside the loop (the kernel is VALU-bound at d = 40).
+    // The descriptors carry no real bound (ragged tiles are masked explicitly below).
+    uint32_t kgo[K_PER_T], vgo[V_PER_T];   // byte offsets relative to the tile base
     int koff[K_PER_T], voff[V_PER_T], krow[K_PER_T], vkey[V_PER_T];
     bool kok[K_PER_T], vok[V_PER_T];
 #pragma unroll
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
         const int c = tid + i * NT;
         kok[i] = c < K_CHUNKS;
         krow[i] = c / DCH;
-        kgo[i] = kok[i] ? krow[i] * (int)ldk + (c % DCH) * 8 : 0;
+        kgo[i] = kok[i] ? (uint32_t)(krow[i] * (int)ldk + (c % DCH) * 8) * 2u : 0u;
         koff[i] = krow[i] * K_STRIDE + (c % DCH) * 8;
     }
 #pragma unroll
@@ -337,31 +339,35 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
         const int c = tid + i * NT;
         vok[i] = c < V_CHUNKS;
         vkey[i] = (c % (KV / 8)) * 8;
-        vgo[i] = vok[i] ? (c / (KV / 8)) * (int)ldvt + vkey[i] : 0;
+        vgo[i] = vok[i] ? (uint32_t)((c / (KV / 8)) * (int)ldvt + vkey[i]) * 2u : 0u;
         // inside every 16-key group the tile is stored as [k0-3 | k8-11 | k4-7 | k12-15]: the 8 keys one lane
         // feeds to a PV k-step (4 hi + {0..3} and 8 + 4 hi + {0..3}) are then one contiguous 16-byte read
         voff[i] = (c / (KV / 8)) * VT_STRIDE + (vkey[i] & ~15) + ((vkey[i] >> 3) & 1) * 4;
     }
-    const T *ktile = k + bq * Mkp * ldk + h * D;          // uniform
-    const T *vtile = vt + (b * C + h * D) * ldvt;        // uniform
-    const int64_t kstep = (int64_t)KV * ldk;
+    const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(k + bq * Mkp * ldk + h * D), 0, 0x7fffffff, 0x00020000);
+    const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(vt + (b * C + h * D) * ldvt), 0, 0x7fffffff, 0x00020000);
+    const uint32_t kstep = (uint32_t)(KV * ldk) * 2u, vstep = (uint32_t)KV * 2u;   // bytes per tile
+    uint32_t so_k = 0, so_v = 0;                                                    // scalar tile offsets (bytes)
+    auto fetch = [](const auto &rsrc, uint32_t voff_, uint32_t soff_) {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_, soff_, 0));
+    };
 
     uint4 rk[K_PER_T], rv[V_PER_T];
     auto issue_full = [&]() {   // tile completely inside [0, M): no bounds logic
         // unconditional: surplus threads re-read chunk 0 (their kgo / vgo is 0) and simply do not store it --
         // a load inside a divergent branch makes the compiler wait for ALL outstanding loads right after it
 #pragma unroll
-        for (int i = 0; i < K_PER_T; ++i) rk[i] = *reinterpret_cast<const uint4 *>(ktile + kgo[i]);
+        for (int i = 0; i < K_PER_T; ++i) rk[i] = fetch(rsrc_k, kgo[i], so_k);
 #pragma unroll
-        for (int i = 0; i < V_PER_T; ++i) rv[i] = *reinterpret_cast<const uint4 *>(vtile + vgo[i]);
-        ktile += kstep;
-        vtile += KV;
+        for (int i = 0; i < V_PER_T; ++i) rv[i] = fetch(rsrc_v, vgo[i], so_v);
+        so_k += kstep;
+        so_v += vstep;
     };
     auto issue_tail = [&](int64_t key0) {   // ragged last tile: rows / keys >= M read as zero
 #pragma unroll
         for (int i = 0; i < K_PER_T; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (kok[i] && key0 + krow[i] < Mk) v = *reinterpret_cast<const uint4 *>(ktile + kgo[i]);
+            if (kok[i] && key0 + krow[i] < Mk) v = fetch(rsrc_k, kgo[i], so_k);
             rk[i] = v;
         }
 #pragma unroll
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             uint4 v = make_uint4(0, 0, 0, 0);
             const int64_t key = key0 + vkey[i];
             if (vok[i] && key < Mk) {   // ldvt >= Mk rounded up to 8: the 16-byte piece is inside the row
-                v = *reinterpret_cast<const uint4 *>(vtile + vgo[i]);
+                v = fetch(rsrc_v, vgo[i], so_v);
                 mask_keys(v, (int)(Mk - key));   // p is 0 there, but 0 * garbage may be NaN
             }
             rv[i] = v;
@@ -580,36 +586,41 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     using std::false_type;
     using std::true_type;
 
-    const int64_t ntiles = (Mk + KV - 1) / KV, nfull = Mk / KV;
-    const int64_t tps = (ntiles + nsplit - 1) / nsplit;                     // key tiles per split
-    const int64_t tb = split * tps, te = tb + tps < ntiles ? tb + tps : ntiles;
-    const int64_t fe = te < nfull ? te : nfull;                             // end of the full tiles of this range
-    ktile += tb * kstep;
-    vtile += tb * KV;
-    if (tb < fe) issue_full(); else issue_tail(tb * KV);
+    const int ntiles = (int)((Mk + KV - 1) / KV), nfull = (int)(Mk / KV);
+    const int tps = (ntiles + nsplit - 1) / nsplit;                         // key tiles per split
+    const int tb = split * tps, te = tb + tps < ntiles ? tb + tps : ntiles;
+    const int fe = te < nfull ? te : nfull;                                 // end of the full tiles of this range
+    so_k = (uint32_t)tb * kstep;
+    so_v = (uint32_t)tb * vstep;
+    if (tb < fe) issue_full(); else issue_tail((int64_t)tb * KV);
     write_lds(0);
     __syncthreads();
+#ifdef VTM_ATT_PRIO
+    // static priority for the second-dispatched half of an 8-wave workgroup (it loses VALU arbitration to the older
+    // half on every phase otherwise): one s_setprio before the loop, no flips inside
+    if (WAVES == 8 && __builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // hot loop: full tiles whose successor is full too -- no bounds logic of any kind inside
-    int64_t t = tb;
+    int t = tb;
     int buf = 0;
     for (; t + 1 < fe; ++t) {
         issue_full();
-        tile(false_type{}, buf, t * KV);
+        tile(false_type{}, buf, (int64_t)t * KV);
         write_lds(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
     if (t < fe) {               // last full tile; prefetches the ragged tile if it belongs to this range
         const bool ragged_next = te > fe;
-        if (ragged_next) issue_tail(fe * KV);
-        tile(false_type{}, buf, t * KV);
+        if (ragged_next) issue_tail((int64_t)fe * KV);
+        tile(false_type{}, buf, (int64_t)t * KV);
         if (ragged_next) write_lds(buf ^ 1);
         __syncthreads();
         ++t;
         buf ^= 1;
     }
-    if (t < te) tile(true_type{}, buf, t * KV);
+    if (t < te) tile(true_type{}, buf, (int64_t)t * KV);
 
     if (partial) {   // split workgroup: hand the raw state to attention_combine_kernel
         constexpr int NA = acc_floats(D), NM = max_floats(D);

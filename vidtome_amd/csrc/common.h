@@ -55,19 +55,6 @@ inline int device_cus() {
     return n;
 }
 
-// internal cross-file launchers (not part of the C ABI)
-int launch_row_norms(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B, int64_t C,
-                     const int32_t *rows, int64_t n, float *norms, hipStream_t s, const int32_t *rows2 = nullptr,
-                     int64_t n2 = 0, float *norms2 = nullptr, void *zero = nullptr, size_t zero_bytes = 0);
-int launch_write_operand(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
-                         int64_t C, const int32_t *rows, int64_t n, const float *norms, float *out,
-                         int64_t n_pad, int64_t C_pad, const int *gate, hipStream_t s,
-                         const int32_t *rows2 = nullptr, int64_t n2 = 0, const float *norms2 = nullptr,
-                         float *out2 = nullptr, int64_t n_pad2 = 0);
-int launch_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd, int64_t Ns_pad,
-                 int64_t Nd_pad, int64_t C_pad, int align, uint64_t *best, const int *gate, bool zero_best,
-                 hipStream_t s);
-
 }  // namespace vtm
 
 #define VTM_REQUIRE(cond, ...)                                   \

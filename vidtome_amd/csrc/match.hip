@@ -50,9 +50,7 @@ __device__ __forceinline__ uint32_t orderable(float f) {
 __global__ __launch_bounds__(THREADS, 2) void match_kernel(
     const float *__restrict__ a, const float *__restrict__ b, int64_t Ns, int64_t Nd, int64_t Ns_pad,
     int64_t Nd_pad, int64_t C_pad, int align, int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split,
-    unsigned long long *__restrict__ best, const int *__restrict__ gate) {
-    // gate != NULL: this launch is the exact fallback of the filtered matcher and only runs when flagged
-    if (gate && *gate == 0) return;
+    unsigned long long *__restrict__ best) {
     // dst tile of one K-step as 8 panels [g][kh][128 rows][4 floats], double-buffered (2 x 16 KiB)
     __shared__ __attribute__((aligned(16))) float sA[2][8 * BD * 4];
 
@@ -183,32 +181,25 @@ __global__ __launch_bounds__(THREADS, 2) void match_kernel(
 
 }  // namespace
 
-namespace vtm {
-// Shared launcher: `gate` (device int, may be NULL) turns the launch into a no-op unless *gate != 0;
-// `zero_best` clears the packed result first (the fallback path accumulates on top of the refine pass).
-int launch_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd, int64_t Ns_pad,
-                 int64_t Nd_pad, int64_t C_pad, int align, uint64_t *best, const int *gate, bool zero_best,
-                 hipStream_t s) {
-    if (zero_best) {
-        const int64_t out_rows = align ? Ns : B * Ns;
-        hipError_t e = hipMemsetAsync(best, 0, (size_t)out_rows * sizeof(uint64_t), s);
-        if (e != hipSuccess) return fail(VTM_ELAUNCH, "vtm_match: memset: %s", hipGetErrorString(e));
-    }
+static int launch_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd, int64_t Ns_pad,
+                        int64_t Nd_pad, int64_t C_pad, int align, uint64_t *best, hipStream_t s) {
+    const int64_t out_rows = align ? Ns : B * Ns;
+    hipError_t e = hipMemsetAsync(best, 0, (size_t)out_rows * sizeof(uint64_t), s);
+    if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match: memset: %s", hipGetErrorString(e));
     const int ns_tiles = (int)(Ns_pad / BS), nd_tiles = (int)(Nd_pad / BD);
     // enough workgroups to fill 256 CUs x 2 resident blocks a few times over, but keep >= 4 dst tiles
     // per block so the running-max epilogue and the atomics stay amortised
-    int64_t want = cdiv(1536, (int64_t)ns_tiles * B);
+    int64_t want = vtm::cdiv(1536, (int64_t)ns_tiles * B);
     int nsplit = (int)(want < 1 ? 1 : want);
     if (nsplit > nd_tiles / 4) nsplit = nd_tiles / 4 > 0 ? nd_tiles / 4 : 1;
-    const int tiles_per_split = (int)cdiv(nd_tiles, nsplit);
-    nsplit = (int)cdiv(nd_tiles, tiles_per_split);
+    const int tiles_per_split = (int)vtm::cdiv(nd_tiles, nsplit);
+    nsplit = (int)vtm::cdiv(nd_tiles, tiles_per_split);
     const int64_t grid = (int64_t)B * ns_tiles * nsplit;
     hipLaunchKernelGGL(match_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, a, b, Ns, Nd, Ns_pad, Nd_pad,
                        C_pad, align, ns_tiles, nd_tiles, nsplit, tiles_per_split,
-                       reinterpret_cast<unsigned long long *>(best), gate);
-    return launch_status("vtm_match");
+                       reinterpret_cast<unsigned long long *>(best));
+    return vtm::launch_status("vtm_match");
 }
-}  // namespace vtm
 
 VTM_EXPORT int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd,
                          int64_t Ns_pad, int64_t Nd_pad, int64_t C_pad, int align, uint64_t *best,
@@ -219,6 +210,5 @@ VTM_EXPORT int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, 
                 "vtm_match: rows must be padded to a multiple of %d", VTM_MATCH_ROW_PAD);
     VTM_REQUIRE(C_pad > 0 && C_pad % BK == 0, "vtm_match: C_pad must be a multiple of %d", BK);
     VTM_REQUIRE(B * Nd < (1ll << 32) - 1, "vtm_match: index space overflow");
-    return vtm::launch_match(a, b, B, Ns, Nd, Ns_pad, Nd_pad, C_pad, align, best, nullptr, true,
-                             vtm::as_stream(stream));
+    return launch_match(a, b, B, Ns, Nd, Ns_pad, Nd_pad, C_pad, align, best, vtm::as_stream(stream));
 }

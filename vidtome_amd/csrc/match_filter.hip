@@ -18,9 +18,10 @@
 // rounded with an absolute error <= 3e-11, far inside EPS even summed over 1280 channels).
 //
 // Escapes (all exact, no host round trip): a row whose candidate list overflows CAP (massively duplicated
-// dst rows) is recomputed exactly by the exact-row pass at the end of refine_kernel (all Nd chains of that row); any non-finite xhat
-// component (zero token -> 0/0, merge.py:84 has no eps) raises a device flag that turns a *gated* launch of
-// the ordinary fp32 kernel (match.hip) from a no-op into a full recomputation of the call.
+// dst rows) is recomputed exactly by the exact-row pass at the end of refine_kernel (all Nd chains of that row); any
+// row without a finite positive norm (zero token -> 0/0, merge.py:84 has no eps) raises a device flag
+// (survivors_kernel) that makes that same pass recompute EVERY row of the call -- slow, exact, and only ever
+// taken by degenerate inputs.
 #include "common.h"
 
 #include <cstdlib>
@@ -104,57 +105,78 @@ __device__ __forceinline__ float from_orderable(uint32_t o) {   // 0 (never writ
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-// ---- operand writer: hi / lo fp16 panels [b][g = k/8][row][8], one thread per (g, row), rows fastest ----
-struct SplitArgs {   // one operand: gathered rows, their norms, the panel outputs
+// ---- operand preparation: canonical row norms + hi / lo fp16 panels [b][g = k/8][row][8], ONE launch ----
+// One thread per gathered row (both operands of the match in the same launch): the canonical k-ascending fmaf chain
+// (the order is part of the bit-exact contract, so it is not tree-reduced -- same bits as row_norms in normalize.hip),
+// then a second walk over the row (L1 / L2-resident) divides, scales, splits and stores the panels: lanes are
+// consecutive rows, so every panel store of a wave is one contiguous 1 KiB segment.  The launch also clears the
+// call's counters and zero-fills `best` (nothing in this kernel reads them: no ordering needed).
+// A row whose norm is not a finite positive number (zero token -> 0/0, merge.py:84 has no eps; inf / NaN inputs) has
+// non-finite xhat components; survivors_kernel recognises it by the stored norm.
+struct SplitArgs {   // one operand: gathered rows, their norms (out), the panel outputs
     const int32_t *rows;
     int64_t n;
-    const float *norms;
+    float *norms;
     uint4 *out_hi, *out_lo;
     int64_t n_pad;
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void split_operand(const T *__restrict__ x0, int64_t P0,
-                                                     const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
-                                                     SplitArgs A0, SplitArgs A1, int64_t C_pad,
-                                                     int *__restrict__ flags,
-                                                     unsigned long long *__restrict__ best, int64_t nbest) {
-    // one launch writes both operands of a match: threads beyond the first operand's range take the second
+__global__ __launch_bounds__(256) void prep_operand(const T *__restrict__ x0, int64_t P0,
+                                                    const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
+                                                    SplitArgs A0, SplitArgs A1, int64_t C_pad,
+                                                    uint32_t *__restrict__ zero, int64_t zero_words,
+                                                    unsigned long long *__restrict__ best, int64_t nbest) {
     const int64_t G = C_pad / 8;
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < nbest) best[idx] = 0ull;   // the packed results start from "nothing found" (saves a memset launch)
-    const bool second = idx >= B * A0.n_pad * G;
-    if (second) idx -= B * A0.n_pad * G;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t w = gid; w < zero_words; w += gsz) zero[w] = 0u;      // amax, cnt, flags
+    for (int64_t w = gid; w < nbest; w += gsz) best[w] = 0ull;         // packed results start from "nothing found"
+    int64_t idx = gid;
+    const bool second = idx >= B * A0.n_pad;
+    if (second) idx -= B * A0.n_pad;
     const SplitArgs &A = second ? A1 : A0;
-    const int32_t *__restrict__ rows = A.rows;
-    const float *__restrict__ norms = A.norms;
-    uint4 *__restrict__ out_hi = A.out_hi, *__restrict__ out_lo = A.out_lo;
     const int64_t n = A.n, n_pad = A.n_pad;
-    if (idx >= B * n_pad * G) return;
-    const int64_t i = idx % n_pad;
-    const int64_t bg = idx / n_pad;
-    const int64_t g = bg % G, b = bg / G;
-    uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
-    if (i < n && g * 8 < C) {
-        const T *src = pool_row(x0, P0, x1, P1, b, rows[b * n + i], C) + g * 8;
-        const float nrm = norms[b * n + i];
-        float f[8];
-        load8(src, f);
-        _Float16 *ph = reinterpret_cast<_Float16 *>(&vh), *pl = reinterpret_cast<_Float16 *>(&vl);
-        bool special = false;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = f[j] / nrm;                 // the canonical xhat (IEEE divide)
-            special |= !(__builtin_fabsf(xh) <= 3.0e38f);   // NaN or inf
-            const float sc = xh * SCALE;
-            const _Float16 h = (_Float16)sc;
-            ph[j] = h;
-            pl[j] = (_Float16)(sc - (float)h);            // exact difference, rounded once
+    if (idx >= B * n_pad) return;
+    const int64_t i = idx % n_pad, b = idx / n_pad;
+    uint4 *__restrict__ out_hi = A.out_hi + (b * G) * n_pad + i;
+    uint4 *__restrict__ out_lo = A.out_lo ? A.out_lo + (b * G) * n_pad + i : nullptr;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if (i >= n) {                                                       // padding rows: all-zero operands
+        for (int64_t g = 0; g < G; ++g) {
+            out_hi[g * n_pad] = z;
+            if (out_lo) out_lo[g * n_pad] = z;
         }
-        if (special) { flags[0] = 1; flags[1] = 1; }
+        return;
     }
-    out_hi[bg * n_pad + i] = vh;
-    if (out_lo) out_lo[bg * n_pad + i] = vl;
+    const T *src = pool_row(x0, P0, x1, P1, b, A.rows[b * n + i], C);
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int64_t k = 0; k < C; k += 8) {
+        float f[8];
+        load8(src + k, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(f[e], f[e], acc);
+    }
+    const float nrm = __builtin_sqrtf(acc);
+    A.norms[b * n + i] = nrm;
+#pragma unroll 2
+    for (int64_t g = 0; g < G; ++g) {
+        uint4 vh = z, vl = z;
+        if (g * 8 < C) {
+            float f[8];
+            load8(src + g * 8, f);
+            _Float16 *ph = reinterpret_cast<_Float16 *>(&vh), *pl = reinterpret_cast<_Float16 *>(&vl);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sc = (f[e] / nrm) * SCALE;                 // the canonical xhat (IEEE divide), scaled
+                const _Float16 h = (_Float16)sc;
+                ph[e] = h;
+                pl[e] = (_Float16)(sc - (float)h);                     // exact difference, rounded once
+            }
+        }
+        out_hi[g * n_pad] = vh;
+        if (out_lo) out_lo[g * n_pad] = vl;
+    }
 }
 
 // ---- filter: approximate scores on the fp16 MFMA, candidate collection ----
@@ -485,8 +507,19 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
 __global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const unsigned int *__restrict__ amax,
                                                         const int *__restrict__ cnt, const uint2 *__restrict__ cand,
                                                         int *__restrict__ flags, int *__restrict__ ovf_rows,
-                                                        uint2 *__restrict__ pairs) {
+                                                        uint2 *__restrict__ pairs, const float *__restrict__ na,
+                                                        int64_t n_na, const float *__restrict__ nb, int64_t n_nb) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // any row of either operand without a finite positive norm (zero token -> NaN xhat, merge.py:84): the filter's
+    // error window means nothing for this call -> refine_kernel recomputes EVERY row exactly (flags[0]).  The scan
+    // rides on this launch (a kernel boundary separates it from the reader).
+    {
+        const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+        bool bad = false;
+        for (int64_t t = row; t < n_na; t += gsz) bad |= !(na[t] > 0.0f && na[t] < INFINITY);
+        for (int64_t t = row; t < n_nb; t += gsz) bad |= !(nb[t] > 0.0f && nb[t] < INFINITY);
+        if (bad) { flags[0] = 1; flags[1] = 1; }
+    }
     if (row >= rows_out) return;
     const int n = cnt[row];
     if (n > CAP) {   // candidate list overflowed: the row is recomputed exactly by refine_kernel's row pass
@@ -516,7 +549,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
                                                      const float *__restrict__ na, const float *__restrict__ nb,
                                                      int align, const int *__restrict__ flags,
                                                      const uint2 *__restrict__ pairs, const int *__restrict__ ovf_rows,
-                                                     unsigned long long *__restrict__ best) {
+                                                     unsigned long long *__restrict__ best, int64_t rows_out) {
     extern __shared__ float sa[];   // exact-row pass: the normalised src row (C floats)
     const int npairs = flags[3];
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (int64_t)gridDim.x * blockDim.x) {
@@ -540,12 +573,14 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
         atomicMax(&best[row], ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col));
     }
 
-    // ---- exact pass for the (rare) rows whose candidate list overflowed: all Nd canonical chains of the row,
-    // one workgroup per row (same launch: the list is almost always empty and a launch of its own costs more
-    // than the check)
-    const int nrows = flags[2];
-    for (int it = blockIdx.x; it < nrows; it += gridDim.x) {
-        const int64_t row = ovf_rows[it];
+    // ---- exact pass for the (rare) rows whose candidate list overflowed -- or for every row of a call with
+    // non-finite operands: all Nd canonical chains of the row, one workgroup per row (same launch: the list is
+    // almost always empty and a launch of its own costs more than the check).  NaN scores order like torch.max:
+    // the packed key puts NaN on top and the first column first.
+    const bool all_rows = flags[0] != 0;             // a non-finite xhat somewhere: every row, see survivors_kernel
+    const int64_t nrows = all_rows ? rows_out : (int64_t)flags[2];
+    for (int64_t it = blockIdx.x; it < nrows; it += gridDim.x) {
+        const int64_t row = all_rows ? it : (int64_t)ovf_rows[it];
         const int64_t i = align ? row : row % Ns;
         unsigned long long bestkey = 0;
         const int64_t b0 = align ? 0 : row / Ns, b1 = align ? B : b0 + 1;
@@ -577,8 +612,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf, pairs, aop, bop, total;
-    int64_t Ns_pad, Nd_pad, C64, C32;
+    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf, pairs, total;
+    int64_t Ns_pad, Nd_pad, C64;
 };
 
 Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
@@ -586,24 +621,21 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     L.Ns_pad = vtm::cdiv(Ns, FBS) * FBS;
     L.Nd_pad = vtm::cdiv(Nd, FBS) * FBS;
     L.C64 = vtm::cdiv(C, 64) * 64;
-    L.C32 = vtm::cdiv(C, 32) * 32;
     const int64_t rows_out = align ? Ns : B * Ns;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes); return at; };
     L.na = take((size_t)B * Ns * 4);
     L.nb = take((size_t)B * Nd * 4);
     L.ah = take((size_t)B * L.C64 * L.Ns_pad * 2);
-    L.al = take((size_t)B * L.C64 * L.Ns_pad * 2);
+    L.al = take(SRC_LO ? (size_t)B * L.C64 * L.Ns_pad * 2 : 0);
     L.bh = take((size_t)B * L.C64 * L.Nd_pad * 2);
-    L.bl = take((size_t)B * L.C64 * L.Nd_pad * 2);
+    L.bl = take(DST_LO ? (size_t)B * L.C64 * L.Nd_pad * 2 : 0);
     L.amax = take((size_t)rows_out * 4);      // amax, cnt and flags are contiguous: cleared together
     L.cnt = take((size_t)rows_out * 4);
     L.flags = take(256);
     L.cand = take((size_t)rows_out * CAP * 8);
     L.ovf = take((size_t)rows_out * 4);
     L.pairs = take((size_t)rows_out * MAX_SURVIVORS * 8);
-    L.aop = take((size_t)B * L.C32 * L.Ns_pad * 4);
-    L.bop = take((size_t)B * L.C32 * L.Nd_pad * 4);
     L.total = o;
     return L;
 }
@@ -637,33 +669,31 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     uint2 *cand = (uint2 *)(w + L.cand);
     int *ovf_rows = (int *)(w + L.ovf);
     uint2 *pairs = (uint2 *)(w + L.pairs);
-    float *aop = (float *)(w + L.aop), *bop = (float *)(w + L.bop);
     const int64_t rows_out = align ? Ns : B * Ns;
-
-    // amax, cnt and flags start from zero (cleared by the row-norm launch); `best` is zeroed by split_operand
-    if (int rc = vtm::launch_row_norms(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, s, b_rows, Nd, nb, w + L.amax,
-                                       L.cand - L.amax))
-        return rc;
 
     VTM_REQUIRE(dtype == VTM_F32 || dtype == VTM_F16 || dtype == VTM_BF16, "vtm_match_filtered: bad dtype");
     {
+        // one launch: canonical norms + fp16 panels of both operands; it also clears amax / cnt / flags (contiguous)
+        // and zero-fills `best`
         const SplitArgs A0{a_rows, Ns, na, ah, SRC_LO ? al : nullptr, L.Ns_pad};
         const SplitArgs A1{b_rows, Nd, nb, bh, DST_LO ? bl : nullptr, L.Nd_pad};
-        const int64_t total = B * (L.Ns_pad + L.Nd_pad) * (L.C64 / 8);   // >= rows_out by construction
+        const int64_t total = B * (L.Ns_pad + L.Nd_pad);
         unsigned long long *bp0 = reinterpret_cast<unsigned long long *>(best);
+        uint32_t *zp = reinterpret_cast<uint32_t *>(w + L.amax);
+        const int64_t zw = (int64_t)((L.cand - L.amax) / 4);
         const dim3 grid((unsigned)vtm::cdiv(total, 256)), block(256);
         switch (dtype) {
             case VTM_F32:
-                hipLaunchKernelGGL(split_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, A0, A1, L.C64, flags, bp0, rows_out);
+                hipLaunchKernelGGL(prep_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
+                                   B, C, A0, A1, L.C64, zp, zw, bp0, rows_out);
                 break;
             case VTM_F16:
-                hipLaunchKernelGGL(split_operand<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, A0, A1, L.C64, flags, bp0, rows_out);
+                hipLaunchKernelGGL(prep_operand<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
+                                   P1, B, C, A0, A1, L.C64, zp, zw, bp0, rows_out);
                 break;
             default:
-                hipLaunchKernelGGL(split_operand<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, A0, A1, L.C64, flags, bp0, rows_out);
+                hipLaunchKernelGGL(prep_operand<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
+                                   (const vtm_bf16 *)x1, P1, B, C, A0, A1, L.C64, zp, zw, bp0, rows_out);
         }
     }
 
@@ -714,7 +744,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     }
     {
         hipLaunchKernelGGL(survivors_kernel, dim3((unsigned)vtm::cdiv(rows_out, 256)), dim3(256), 0, s, rows_out, amax, cnt,
-                           cand, flags, ovf_rows, pairs);
+                           cand, flags, ovf_rows, pairs, (const float *)na, B * Ns, (const float *)nb, B * Nd);
         // one thread per surviving pair; the count lives on the device, so a fixed grid strides over the list
         const dim3 grid((unsigned)std::min<int64_t>(vtm::cdiv(rows_out * 2, 256), 4096)), block(256);
         unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
@@ -722,25 +752,19 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(refine_kernel<float>, grid, block, lds, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp);
+                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp, rows_out);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(refine_kernel<__half>, grid, block, lds, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp);
+                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp, rows_out);
                 break;
             default:
                 hipLaunchKernelGGL(refine_kernel<vtm_bf16>, grid, block, lds, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp);
+                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp, rows_out);
         }
     }
     if (int rc = vtm::launch_status("vtm_match_filtered")) return rc;
 
-    // gated exact fallback (no-ops unless flags[0] != 0)
-    if (int rc = vtm::launch_write_operand(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, na, aop, L.Ns_pad, L.C32, flags, s,
-                                           b_rows, Nd, nb, bop, L.Nd_pad))
-        return rc;
-    if (int rc = vtm::launch_match(aop, bop, B, Ns, Nd, L.Ns_pad, L.Nd_pad, L.C32, align, best, flags, false, s))
-        return rc;
     if (flags_out) {
         const hipError_t e = hipMemcpyAsync(flags_out, flags, 4 * sizeof(int), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: copy: %s", hipGetErrorString(e));

@@ -27,21 +27,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void row_norms(const T *__restrict__ x0, int64_t P0,
                                                  const T *__restrict__ x1, int64_t P1, int64_t B,
                                                  int64_t C, const int32_t *__restrict__ rows,
-                                                 int64_t n, float *__restrict__ norms,
-                                                 const int32_t *__restrict__ rows2, int64_t n2,
-                                                 float *__restrict__ norms2, uint32_t *__restrict__ zero,
-                                                 int64_t zero_words) {
-    // one launch may serve two row lists (the src and the dst rows of a match): threads >= B*n take the second
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // ... and clear a scratch region of the caller (the filtered matcher's counters: saves a memset launch)
-    for (int64_t w = idx; w < zero_words; w += (int64_t)gridDim.x * blockDim.x) zero[w] = 0u;
-    if (idx >= B * n) {
-        idx -= B * n;
-        rows = rows2;
-        n = n2;
-        norms = norms2;
-        if (idx >= B * n) return;
-    }
+                                                 int64_t n, float *__restrict__ norms) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n) return;
     const int64_t b = idx / n;
     const T *src = pool_row(x0, P0, x1, P1, b, rows[idx], C);
     constexpr int N = Vec16<T>::N;
@@ -65,25 +53,12 @@ __global__ __launch_bounds__(256) void write_operand(const T *__restrict__ x0, i
                                                      int64_t C, const int32_t *__restrict__ rows,
                                                      int64_t n, const float *__restrict__ norms,
                                                      float *__restrict__ out, int64_t n_pad,
-                                                     int64_t C_pad, const int *__restrict__ gate,
-                                                     const int32_t *__restrict__ rows2, int64_t n2,
-                                                     const float *__restrict__ norms2, float *__restrict__ out2,
-                                                     int64_t n_pad2) {
-    if (gate && *gate == 0) return;   // exact-fallback operands are only materialised when flagged
+                                                     int64_t C_pad) {
     // one thread per (8-channel group g, row i), rows fastest -> the two 16-byte panel stores of a wave are
     // contiguous 1 KiB segments.  Panel layout: out[b][g][kh][i][e] = xhat[b, i, 8g + 2e + kh].
-    // A launch may write two operands (threads beyond the first one's range take the second).
     const int64_t G = C_pad / 8;
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * n_pad * G) {
-        idx -= B * n_pad * G;
-        rows = rows2;
-        n = n2;
-        norms = norms2;
-        out = out2;
-        n_pad = n_pad2;
-        if (idx >= B * n_pad * G) return;
-    }
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n_pad * G) return;
     const int64_t i = idx % n_pad;
     const int64_t bg = idx / n_pad;  // b * G + g
     const int64_t g = bg % G, b = bg / G;
@@ -120,72 +95,17 @@ int run(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, int64
     if (B * n > 0) {
         const int64_t blocks = vtm::cdiv(B * n, 256);
         hipLaunchKernelGGL(row_norms<T>, dim3((unsigned)blocks), dim3(256), 0, s, (const T *)x0, P0,
-                           (const T *)x1, P1, B, C, rows, n, norms, (const int32_t *)nullptr, (int64_t)0, (float *)nullptr,
-                           (uint32_t *)nullptr, (int64_t)0);
+                           (const T *)x1, P1, B, C, rows, n, norms);
     }
     const int64_t total = B * n_pad * (C_pad / 8);
     if (total > 0) {
         hipLaunchKernelGGL(write_operand<T>, dim3((unsigned)vtm::cdiv(total, 256)), dim3(256), 0, s,
-                           (const T *)x0, P0, (const T *)x1, P1, B, C, rows, n, norms, out, n_pad,
-                           C_pad, (const int *)nullptr, (const int32_t *)nullptr, (int64_t)0, (const float *)nullptr,
-                           (float *)nullptr, (int64_t)0);
+                           (const T *)x0, P0, (const T *)x1, P1, B, C, rows, n, norms, out, n_pad, C_pad);
     }
     return vtm::launch_status("vtm_normalize_gather");
 }
 
 }  // namespace
-
-namespace vtm {
-// shared with match_filter.hip: the canonical row norms of gathered pool rows (same kernel, same bits)
-int launch_row_norms(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B, int64_t C,
-                     const int32_t *rows, int64_t n, float *norms, hipStream_t s, const int32_t *rows2, int64_t n2,
-                     float *norms2, void *zero, size_t zero_bytes) {
-    uint32_t *zp = static_cast<uint32_t *>(zero);
-    const int64_t zw = (int64_t)(zero_bytes / 4);   // callers pass 4-byte multiples
-    if (B * (n + n2) <= 0) return VTM_OK;
-    const dim3 grid((unsigned)cdiv(B * (n + n2), 256)), block(256);
-    switch (dtype) {
-        case VTM_F32:
-            hipLaunchKernelGGL(row_norms<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1, B,
-                               C, rows, n, norms, rows2, n2, norms2, zp, zw);
-            break;
-        case VTM_F16:
-            hipLaunchKernelGGL(row_norms<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1, P1,
-                               B, C, rows, n, norms, rows2, n2, norms2, zp, zw);
-            break;
-        case VTM_BF16:
-            hipLaunchKernelGGL(row_norms<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0, (const vtm_bf16 *)x1,
-                               P1, B, C, rows, n, norms, rows2, n2, norms2, zp, zw);
-            break;
-        default: return fail(VTM_EINVAL, "unsupported dtype %d", dtype);
-    }
-    return launch_status("row_norms");
-}
-int launch_write_operand(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
-                         int64_t C, const int32_t *rows, int64_t n, const float *norms, float *out,
-                         int64_t n_pad, int64_t C_pad, const int *gate, hipStream_t s, const int32_t *rows2,
-                         int64_t n2, const float *norms2, float *out2, int64_t n_pad2) {
-    const int64_t total = B * (n_pad + n_pad2) * (C_pad / 8);
-    if (total <= 0) return VTM_OK;
-    const dim3 grid((unsigned)cdiv(total, 256)), block(256);
-    switch (dtype) {
-        case VTM_F32:
-            hipLaunchKernelGGL(write_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                               B, C, rows, n, norms, out, n_pad, C_pad, gate, rows2, n2, norms2, out2, n_pad2);
-            break;
-        case VTM_F16:
-            hipLaunchKernelGGL(write_operand<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                               P1, B, C, rows, n, norms, out, n_pad, C_pad, gate, rows2, n2, norms2, out2, n_pad2);
-            break;
-        case VTM_BF16:
-            hipLaunchKernelGGL(write_operand<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
-                               (const vtm_bf16 *)x1, P1, B, C, rows, n, norms, out, n_pad, C_pad, gate, rows2, n2, norms2, out2, n_pad2);
-            break;
-        default: return fail(VTM_EINVAL, "unsupported dtype %d", dtype);
-    }
-    return launch_status("write_operand");
-}
-}  // namespace vtm
 
 VTM_EXPORT int vtm_normalize_gather(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype,
                                     int64_t B, int64_t C, const int32_t *rows, int64_t n, float *norms,
