@@ -72,7 +72,8 @@ class KernelTimer:
     def __init__(self, lib_mod):
         self.lib_mod = lib_mod
         self.orig = {}
-        self.records = {"attention": [], "matching": [], "layernorm": [], "gather_rows": [], "unmerge_add": []}
+        self.records = {"attention": [], "matching": [], "layernorm": [], "gather_rows": [], "unmerge_add": [],
+                        "projections": []}
         self.enabled = False
 
     def _wrap(self, name, kind, flops_of):
@@ -104,6 +105,10 @@ class KernelTimer:
         self._wrap("layernorm", "layernorm", lambda x, w, b, eps: 2.0 * x.numel() * esz(x))
         self._wrap("gather_rows", "gather_rows",
                    lambda x0, x1, idx, pad_to=1: 2.0 * idx.numel() * x0.shape[2] * esz(x0))
+        # linear_rows(x0, x1, rows, rows2, n, weight, bias, ...): 2 B n K N flops (the gather-fused projection GEMMs)
+        self._wrap("linear_rows", "projections",
+                   lambda x0, x1, rows, rows2, n, weight, bias=None, transposed=False, pad_to=8, out=None:
+                   2.0 * x0.shape[0] * n * weight.shape[0] * weight.shape[1])
         self._wrap("unmerge_add", "unmerge_add",
                    lambda y, inv, resid: (2.0 + (resid is not None)) * inv.numel() * y.shape[2] * esz(y))
         return self
@@ -406,6 +411,11 @@ def main():
             # the HBM-bound kernels of the path: algorithmic bytes (rows read + rows written) / HIP-event time.  The
             # cfg-2 working sets (<= 212 MB) fit the 256 MB Infinity Cache, so `pmc` carries the counter-derived rates
             # measured beyond it
+            # q / k / v^T / out projections: GEMMs whose A rows are gathered through the composed merge map
+            "projections": (lambda f, ms, n: {"kernel": "linear_rows_kernel (vtm_linear_rows, fp16 MFMA)", "launches": n,
+                                              "ms_per_step": round(ms / args.steps, 3),
+                                              "tflops": round(f / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0})(
+                *mt.summary("projections")),
             "gather_path": {"hbm_peak_GBps": HBM_PEAK_GBPS, "layernorm": hbm("layernorm"),
                             "gather_rows": hbm("gather_rows"), "unmerge_add": hbm("unmerge_add"),
                             "pmc": pmc_gather_path()},

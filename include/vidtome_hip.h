@@ -254,6 +254,24 @@ int vtm_layernorm(const void *x, const void *gamma, const void *beta, int dtype,
  * ---------------------------------------------------------------------------------------------- */
 int vtm_geglu(const void *x, int dtype, int64_t rows, int64_t D, void *out, vtm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * vtm_linear_rows -- `Linear(gather(tokens))`: the attention projections of the patched block
+ * (`self.attn1(...)`, vidtome/patch.py:157-162; to_q / to_k / to_v / to_out[0] as in utils/pnp_utils.py:47-95)
+ * fed by the composed merge map instead of a materialised merged tensor (the reference's
+ * merge closure `cat([gather(src, unm_idx), dst])`, merge.py:119-133 / 423-437, followed by nn.Linear).
+ *   out[b, i, :] = pool[b, p(i), :] @ W^T (+ bias),   p(i) = rows[b, rows2[b, i]]   (either map may be NULL:
+ *   rows2 NULL -> p(i) = rows[b, i];  rows NULL -> p(i) = rows2[b, i] or i)
+ * pool = x0 (B, P0, K) | x1 (B, P1, K) as in vtm_gather_rows; rows: (B, rows_ld) int32 pool ids (the composed merge
+ * map); rows2: (B, n) int32 positions in the merged sequence (the live-query rows of a global level).
+ * W: (N, K) row-major like torch.nn.Linear.weight, bias: (N) or NULL; fp16 / bf16, fp32 accumulation.
+ * transposed == 0: out is (B, >= n, ldo >= N) token-major; transposed != 0: out is (B, N, ldo >= n) channel-major
+ * (V^T for vtm_attention).  out_batch_stride in elements.  K % 32 == 0.  Rows >= n of out are not written.
+ * ---------------------------------------------------------------------------------------------- */
+int vtm_linear_rows(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B, int64_t K,
+                    const int32_t *rows, int64_t rows_ld, const int32_t *rows2, int64_t n, const void *W,
+                    const void *bias, int64_t N, void *out, int64_t ldo, int64_t out_batch_stride,
+                    int transposed, vtm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

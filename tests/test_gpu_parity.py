@@ -542,6 +542,53 @@ def test_geglu_vs_torch_fp32(L, dtype):
     assert (y - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,P0,P1,K,N,n", [(2, 300, 100, 64, 96, 257), (1, 128, 0, 32, 128, 128), (3, 50, 77, 320, 320, 91),
+                                            (2, 4096, 1000, 640, 640, 3000)])
+def test_linear_rows_vs_torch_fp32(L, dtype, B, P0, P1, K, N, n):
+    """vtm_linear_rows = Linear(gather(pool, rows)): both output layouts, one- and two-level maps, bias, ragged tiles."""
+    g = torch.Generator().manual_seed(K + n)
+    x0 = torch.randn(B, P0, K, generator=g).to(dtype).to(DEV)
+    x1 = torch.randn(B, P1, K, generator=g).to(dtype).to(DEV) if P1 else None
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype).to(DEV)
+    bias = torch.randn(N, generator=g).to(dtype).to(DEV)
+    pool = x0 if x1 is None else torch.cat([x0, x1], dim=1)
+    Mfull = max(n, (P0 + P1) // 2)
+    rows = torch.randint(0, P0 + P1, (B, Mfull), generator=g).to(torch.int32).to(DEV)
+    rows2 = torch.randint(0, Mfull, (B, n), generator=g).to(torch.int32).to(DEV)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+
+    def ref(idx, b_):
+        a = torch.gather(pool.float(), 1, idx.long().unsqueeze(-1).expand(-1, -1, K))
+        y = a @ w.float().t()
+        return y + b_.float() if b_ is not None else y
+
+    def check(got, want):
+        err = (got.float() - want).abs().max().item()
+        assert err < tol * max(1.0, want.abs().max().item()), err
+
+    n_pad = (n + 7) // 8 * 8
+    # one-level map, token-major, with and without bias
+    for b_ in (None, bias):
+        out = L.linear_rows(x0, x1, rows[:, :n].contiguous(), None, n, w, b_)
+        assert out.shape == (B, n_pad, N)
+        check(out[:, :n], ref(rows[:, :n], b_))
+    # two-level map (live-query rows), channel-major (V^T layout)
+    comp = torch.gather(rows.long(), 1, rows2.long())
+    out_t = L.linear_rows(x0, x1, rows, rows2, n, w, bias, transposed=True)
+    assert out_t.shape == (B, N, n_pad)
+    check(out_t[:, :, :n].transpose(1, 2), ref(comp, bias))
+    # identity rows over x0 (the to_out projection of the attention output), written into a strided view
+    m = min(n, P0)
+    buf = torch.zeros(B, (m + 7) // 8 * 8, 2 * N, dtype=dtype, device=DEV)
+    L.linear_rows(x0, None, None, None, m, w, None, out=buf[:, :, N:])
+    check(buf[:, :m, N:], x0[:, :m].float() @ w.float().t())
+    assert (buf[:, :, :N] == 0).all()
+    # pool ids through rows2 alone
+    out2 = L.linear_rows(x0, x1, None, comp.to(torch.int32).contiguous(), n, w, None)
+    check(out2[:, :n], ref(comp, None))
+
+
 @pytest.mark.parametrize("B,N,Mk,C,heads", [(4, 256, 77, 320, 8), (2, 100, 77, 640, 8), (3, 64, 10, 160, 2)])
 def test_cross_attention_and_ff_vs_torch_fp32(L, B, N, Mk, C, heads):
     """attn2 / ff of the patched block (patch.py:171-199) against plain PyTorch fp32 on the same rounded inputs."""
@@ -690,8 +737,9 @@ def test_attention_full_size_vs_oracle(L, oracle, name, B, h, d, Mq, Mk):
                                vt[:, :, :Mk].transpose(1, 2).float().cpu().numpy(), h, d ** -0.5)
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max())
-    assert scale > 0.2, "the comparison should not be about zeros"
-    assert err < 1e-3 * max(1.0, scale), (name, err, scale)
+    assert scale > 0.05, "the comparison should not be about zeros"
+    assert err < 1e-3 * max(1.0, scale), (name, err, scale)      # north_star's bound
+    assert err < 5e-3 * scale, (name, err, scale)                # and well inside it relative to the outputs themselves
     assert torch.isfinite(out[:, :Mq]).all()
     if Mqp != Mq:
         assert (out[:, Mq:] == 0).all()
@@ -799,6 +847,38 @@ def test_live_queries_equal_full_attention(L, F, global_rand):
         for a, b in zip(a_chunk, b_chunk):
             assert a.shape == b.shape and torch.isfinite(a).all()
             assert (a - b).abs().max() <= 2e-3 * max(1.0, float(b.abs().max()))
+
+
+def test_projection_paths_agree(L):
+    """The patched segment with its projections fed through the composed merge map (vtm_linear_rows, the default) equals
+    the same segment over materialised merged tokens with library GEMMs (VIDTOME_PROJ=blas) -- two chunks, local + global
+    levels, live queries, merged and un-merged sites."""
+    import vidtome_amd
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import sites
+    sl = [sites.Site("top", 1, 320, 8), sites.Site("mid", 2, 640, 8), sites.Site("low", 4, 1280, 8)]
+    B, F, latent = 2, 4, (16, 16)
+    outs = {}
+    for mode in (True, False):
+        vpatch.FUSED_PROJ = mode
+        try:
+            unet = sites.SiteUNet(sl, seed=0).to(device=DEV, dtype=torch.float16)
+            vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B)
+            unet.set_size(latent)
+            torch.manual_seed(123)
+            res = []
+            with torch.no_grad():
+                for ck in range(2):
+                    hs = [sites.synthetic_hidden(s_, B, F, latent, torch.float16, DEV, seed=10 * ck + i)
+                          for i, s_ in enumerate(sl)]
+                    res.append([o.float() for o in sites.run_segment_pass(unet, hs)])
+            outs[mode] = res
+        finally:
+            vpatch.FUSED_PROJ = True
+    for a, b in zip(outs[True], outs[False]):
+        for x, y in zip(a, b):
+            assert torch.isfinite(x).all()
+            assert (x - y).abs().max().item() < 4e-3 * max(1.0, y.abs().max().item())
 
 
 def test_cfg5_sd21_768_full_size(L):

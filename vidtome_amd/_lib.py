@@ -56,6 +56,8 @@ _SIGNATURES = {
     "vtm_cfg_ddim": ([_vp, _vp, _vp, _int, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp], _int),
     "vtm_layernorm": ([_vp, _vp, _vp, _int, _i64, _i64, _f32, _vp, _vp], _int),
     "vtm_geglu": ([_vp, _int, _i64, _i64, _vp, _vp], _int),
+    "vtm_linear_rows": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64,
+                         _int, _vp], _int),
 }
 
 
@@ -381,4 +383,33 @@ def geglu(x: torch.Tensor) -> torch.Tensor:
     xc = x.contiguous()
     out = torch.empty(xc.shape[:-1] + (D,), dtype=x.dtype, device=x.device)
     _check(lib().vtm_geglu(_ptr(xc), dtype_code(xc), xc.numel() // (2 * D), D, _ptr(out), _stream()), "vtm_geglu")
+    return out
+
+
+@_on_device
+def linear_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], rows: Optional[torch.Tensor],
+                rows2: Optional[torch.Tensor], n: int, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                transposed: bool = False, pad_to: int = 8, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b, i] = pool[b, rows[b, rows2[b, i]]] @ weight^T (+ bias) for i < n (either map may be None = identity).
+    Returns (B, n_pad, N) token-major, or (B, N, n_pad) channel-major when ``transposed`` (n_pad = n rounded up to
+    ``pad_to``; the padding is NOT written).  ``out`` may be a preallocated view (last axis contiguous)."""
+    _req(x0, "x0"), _req(weight, "weight")
+    B, P0, K = x0.shape
+    P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
+    N = weight.shape[0]
+    if weight.shape[1] != K or weight.dtype != x0.dtype:
+        raise RuntimeError("linear_rows: weight must be (N, K) in the token dtype")
+    if rows is not None:
+        _req(rows, "rows")
+    if rows2 is not None:
+        _req(rows2, "rows2")
+    n_pad = (n + pad_to - 1) // pad_to * pad_to
+    if out is None:
+        out = torch.empty((B, N, n_pad) if transposed else (B, n_pad, N), dtype=x0.dtype, device=x0.device)
+    if out.stride(2) != 1:
+        raise RuntimeError("linear_rows: out must be contiguous along its last axis")
+    _check(lib().vtm_linear_rows(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, K, _ptr(rows),
+                                 0 if rows is None else rows.shape[1], _ptr(rows2), n, _ptr(weight),
+                                 _ptr(bias.contiguous() if bias is not None else None), N, out.data_ptr(), out.stride(1),
+                                 out.stride(0), int(transposed), _stream()), "vtm_linear_rows")
     return out

@@ -149,17 +149,26 @@ __global__ __launch_bounds__(256) void prep_operand(const T *__restrict__ x0, in
         return;
     }
     const T *src = pool_row(x0, P0, x1, P1, b, A.rows[b * n + i], C);
+    // one thread walks one row twice (a wave keeps only 64 rows in flight): the loads are issued 8 pieces ahead of
+    // the serial chain / the divides so that each thread has 128 bytes outstanding
+    constexpr int AHEAD = 8;
+    const int64_t CG = C / 8;                      // 8-channel pieces of the row (C % 8 == 0)
     float acc = 0.0f;
-#pragma unroll 4
-    for (int64_t k = 0; k < C; k += 8) {
-        float f[8];
-        load8(src + k, f);
+    for (int64_t g0 = 0; g0 < CG; g0 += AHEAD) {
+        float f[AHEAD][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(f[e], f[e], acc);
+        for (int u = 0; u < AHEAD; ++u)
+            if (g0 + u < CG) load8(src + (g0 + u) * 8, f[u]);
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u)
+            if (g0 + u < CG) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(f[u][e], f[u][e], acc);
+            }
     }
     const float nrm = __builtin_sqrtf(acc);
     A.norms[b * n + i] = nrm;
-#pragma unroll 2
+#pragma unroll 4
     for (int64_t g = 0; g < G; ++g) {
         uint4 vh = z, vl = z;
         if (g * 8 < C) {

@@ -43,8 +43,8 @@ LIVE_QUERIES = os.environ.get("VIDTOME_LIVE_QUERIES", "1") != "0"
 class MergePlan:
     """What ``compute_merge`` produces for one block call: composed maps + the merged tokens."""
 
-    __slots__ = ("fsize", "L", "M", "gather_map", "inv", "merged", "levels", "global_level", "local_chunk",
-                 "x_joined", "anchors_in", "q_rows", "inv_q")
+    __slots__ = ("fsize", "L", "M", "gather_map", "inv", "_merged", "levels", "global_level", "local_chunk",
+                 "x_joined", "anchors_in", "q_rows", "inv_q", "pad_to")
 
     def __init__(self):
         self.levels = []
@@ -60,6 +60,18 @@ class MergePlan:
         # the q_rows queries only -- a third fewer at global_merge_ratio 0.5, same block output.
         self.q_rows = None
         self.inv_q = None
+        self._merged = None
+        self.pad_to = 8
+
+    @property
+    def merged(self) -> torch.Tensor:
+        """The merged tokens (B, Mp, C) -- what the reference's composed merge closure returns (patch.py:84).  The
+        patched block itself does not need them (its projections read the pool through `gather_map`), so they are
+        materialised on first use."""
+        if self._merged is None:
+            self._merged = self.x_joined if self.gather_map is None else \
+                _lib.gather_rows(self.x_joined, self.anchors_in, self.gather_map, pad_to=self.pad_to)
+        return self._merged
 
 
 def _draw_coin(generator: torch.Generator) -> float:
@@ -68,11 +80,13 @@ def _draw_coin(generator: torch.Generator) -> float:
 
 
 def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str, Any],
-                  pad_to: int = 8, want_indices: bool = False
+                  pad_to: int = 8, want_indices: bool = False, materialize: bool = True
                   ) -> Tuple[Callable, Callable, torch.Tensor]:
     """vidtome/patch.py:14-91.  Returns ``(m, u, merged_tokens)``; ``u`` accepts ``resid=`` to fuse the
     residual add of patch.py:169 into the unmerge gather.  ``merged_tokens`` is (B, Mp, C) with
-    Mp = M rounded up to ``pad_to`` rows (zero rows); ``m.plan`` exposes the MergePlan."""
+    Mp = M rounded up to ``pad_to`` rows (zero rows); ``m.plan`` exposes the MergePlan.  With ``materialize=False``
+    (the patched block's own call: its projections gather through the map) the third value is None and
+    ``m.plan.merged`` materialises the tokens on demand."""
     original_h, original_w = tome_info["size"]
     original_tokens = original_h * original_w
     downsample = int(math.ceil(math.sqrt(original_tokens // x.shape[1])))        # patch.py:17
@@ -147,18 +161,16 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 n_cur = cur.shape[1]
 
         plan.M = n_cur
-        plan.gather_map, plan.inv = cur, inv
-        if cur is None:
-            merged = xj                                                            # F == 1, nothing merged
-        else:
-            merged = _lib.gather_rows(xj, plan.anchors_in, cur, pad_to=pad_to)
-        plan.merged = merged
+        plan.gather_map, plan.inv, plan.pad_to = cur, inv, pad_to
+        merged = plan.merged if (materialize or cur is None) else None             # cur None: F == 1, a view
         if args["merge_global"]:
             if anchors_out is not None:
                 module.global_tokens = anchors_out
             elif plan.global_level is None:
                 # patch.py:82: first chunk of a step stores its local tokens (device-resident, shared
                 # with `merged`, which nothing mutates)
+                if merged is None:
+                    merged = plan.merged
                 module.global_tokens = merged[:, :Ml] if merged.shape[1] != Ml else merged
             if exchange is not None:
                 exchange.publish(xkey, module.global_tokens)
@@ -291,10 +303,61 @@ def fused_attention_ok(attn: torch.nn.Module, x: torch.Tensor, self_attn: bool =
     return True
 
 
+# VIDTOME_PROJ=blas keeps the projections on library GEMMs (torch -> hipBLASLt) over materialised merged tokens;
+# the default feeds them through the composed merge map (vtm_linear_rows), so the C ABI covers attn1 end to end.
+FUSED_PROJ = os.environ.get("VIDTOME_PROJ", "rows") != "blas"
+
+
+def fused_projections_ok(attn: torch.nn.Module, x: torch.Tensor) -> bool:
+    """The gather-fused projection GEMM (vtm_linear_rows) takes fp16 / bf16 tokens with C % 32 == 0."""
+    return FUSED_PROJ and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 32 == 0 \
+        and attn.to_q.weight.dtype == x.dtype
+
+
+def _weight(m: torch.nn.Module, dtype) -> torch.Tensor:
+    w = m.weight
+    return w if (w.dtype == dtype and w.is_contiguous()) else w.to(dtype).contiguous()
+
+
+def self_attention_rows(attn: torch.nn.Module, x0: torch.Tensor, x1: Optional[torch.Tensor],
+                        rows: Optional[torch.Tensor], q_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``attn1(merged)`` (patch.py:157-162; arithmetic of pnp_utils.py:47-95) with ``merged[b, i] = pool[b, rows[b, i]]``
+    never materialised: every projection is a vtm_linear_rows GEMM that fetches its A rows through the composed merge
+    map (pool = x0 | x1, ``rows`` None = the rows of x0 as they are), k and v for all M rows (v channel-major, what the
+    PV contraction reads), q -- and the output projection -- only for the ``q_rows`` positions when given (the rows
+    unmerge() reads).  Returns (B, Mq rounded up to 8, C); rows >= Mq are not meaningful."""
+    B, _, C = x0.shape
+    M = x0.shape[1] if rows is None else rows.shape[1]
+    Mp = (M + 7) // 8 * 8
+    heads = attn.heads
+    scale = getattr(attn, "scale", None) or (C // heads) ** -0.5
+    share = _pnp_share_groups(attn)
+    if q_rows is not None and share != 1:
+        raise RuntimeError("q_rows cannot be combined with the PnP shared-probability mode")
+    dt = x0.dtype
+    wqk, bqk = _fused_weights(attn, dt, x0.device)
+    bv = getattr(attn.to_v, "bias", None)
+    vt = _lib.linear_rows(x0, x1, rows, None, M, _weight(attn.to_v, dt), None if bv is None else bv.to(dt),
+                          transposed=True)                                                       # (B, C, Mp)
+    if q_rows is None:
+        qk = _lib.linear_rows(x0, x1, rows, None, M, wqk, bqk)                                   # (B, Mp, 2C): q | k
+        o = _lib.attention(qk[:, :, :C], qk[:, :, C:], vt, heads, M, scale, share)
+        Mq = M
+    else:
+        Mq = q_rows.shape[1]
+        k_op = _lib.linear_rows(x0, x1, rows, None, M, wqk[C:], None if bqk is None else bqk[C:])
+        q_op = _lib.linear_rows(x0, x1, rows, q_rows, Mq, wqk[:C], None if bqk is None else bqk[:C])
+        o = _lib.attention_kv(q_op, k_op, vt, heads, Mq, M, scale)
+    to_out = _out_linear(attn)
+    return _lib.linear_rows(o, None, None, None, Mq, _weight(to_out, dt), None if to_out.bias is None else to_out.bias.to(dt))
+
+
 def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = None,
                    q_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``attn1(x)`` for self-attention without mask (patch.py:157-162), arithmetic of pnp_utils.py:47-95:
-    q,k,v projections -> softmax(q k^T * scale) v per head -> to_out[0] (+ dropout(0)).
+    q,k,v projections -> softmax(q k^T * scale) v per head -> to_out[0] (+ dropout(0)), on MATERIALISED tokens with
+    library GEMMs (torch -> hipBLASLt) for the projections: the path of fp32 models, of channel counts the
+    gather-fused GEMM does not take, and of VIDTOME_PROJ=blas (see self_attention_rows for the default).
     x is (B, Mp, C) whose first M rows per sample are the sequence.  With ``q_rows`` (B, Mq) only those rows act
     as queries (every row stays a key / value) and the result is (B, Mq rounded up to 8, C) in q_rows order.
     The caller has checked ``fused_attention_ok(attn, x)``.
@@ -394,11 +457,14 @@ def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.
                                    attention_mask=None, cross_attention_kwargs=None, gate_msa=None
                                    ) -> torch.Tensor:
     """patch.py:148-169: compute_merge -> attn1(merged) -> unmerge -> + residual."""
-    m_a, u_a, merged = compute_merge(block, norm_hidden_states, block._tome_info)
     cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
-    plan = getattr(m_a, "plan", None)
     custom = encoder_hidden_states is not None and block.only_cross_attention
-    if custom or attention_mask is not None or cross_attention_kwargs or not fused_attention_ok(block.attn1, merged):
+    fused = not (custom or attention_mask is not None or cross_attention_kwargs) \
+        and fused_attention_ok(block.attn1, norm_hidden_states)
+    by_rows = fused and fused_projections_ok(block.attn1, norm_hidden_states)
+    m_a, u_a, merged = compute_merge(block, norm_hidden_states, block._tome_info, materialize=not by_rows)
+    plan = getattr(m_a, "plan", None)
+    if not fused:
         # not the hot path (SD never masks self-attention nor makes attn1 a cross-attention; LoRA'd / custom
         # attention modules are not the plain arithmetic): run the module's own attention on the merged tokens
         # exactly as the reference does
@@ -410,8 +476,14 @@ def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.
         # (PnP injection reads the source sample's q for every group: it keeps the full, aligned layout)
         live = (plan is not None and plan.q_rows is not None and gate_msa is None and LIVE_QUERIES
                 and _pnp_share_groups(block.attn1) == 1)
-        attn_output = self_attention(block.attn1, merged, plan.M if plan is not None else None,
-                                     plan.q_rows if live else None)
+        q_rows = plan.q_rows if live else None
+        if by_rows:
+            if plan is None:                                              # block does not merge: per-frame attention
+                attn_output = self_attention_rows(block.attn1, norm_hidden_states.contiguous(), None, None)
+            else:
+                attn_output = self_attention_rows(block.attn1, plan.x_joined, plan.anchors_in, plan.gather_map, q_rows)
+        else:
+            attn_output = self_attention(block.attn1, merged, plan.M if plan is not None else None, q_rows)
         if live:
             # rows are the chunk's local merged tokens: unmerge with the local levels' map alone
             # (= the global level's unmerge, merge.py:439-460, folded into the choice of queries)
