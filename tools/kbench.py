@@ -110,6 +110,24 @@ def main():
             nbytes = (B * M + 2.0 * B * L) * C * 2
         print(f"{a.what} B={B} L={L} M={M} C={C}: {nbytes / 1e6:.1f} MB algorithmic, median {med * 1e3:.1f} us "
               f"({nbytes / med / 1e6:.0f} GB/s), best {best * 1e3:.1f} us ({nbytes / best / 1e6:.0f} GB/s)")
+    elif a.what == "linear":
+        # the block's projection GEMMs at a merged site: K/V^T over all M rows through the merge map, Q over the live
+        # rows, out over the attention output -- vtm_linear_rows vs gather + library GEMM (torch -> hipBLASLt)
+        import torch.nn.functional as F
+        B, L, C, M, Mq = a.B, a.n, a.C, a.M, (a.Mq or a.M)
+        x = torch.randn(B, L, C, generator=g, device=dev, dtype=torch.float16)
+        idx = torch.stack([torch.randperm(L, generator=g, device=dev)[:M] for _ in range(B)]).to(torch.int32)
+        idx = idx.sort(dim=1).values.contiguous()
+        q_rows = torch.stack([torch.randperm(M, generator=g, device=dev)[:Mq] for _ in range(B)]).to(torch.int32).contiguous()
+        w = (torch.randn(C, C, generator=g, device=dev) * C ** -0.5).half()
+        for name, fn, fl in (
+                ("k   rows", lambda: _lib.linear_rows(x, None, idx, None, M, w, None), 2.0 * B * M * C * C),
+                ("v^T rows", lambda: _lib.linear_rows(x, None, idx, None, M, w, None, transposed=True), 2.0 * B * M * C * C),
+                ("q   rows", lambda: _lib.linear_rows(x, None, idx, q_rows, Mq, w, None), 2.0 * B * Mq * C * C),
+                ("k   blas", lambda: F.linear(_lib.gather_rows(x, None, idx), w), 2.0 * B * M * C * C),
+                ("v^T blas", lambda: torch.matmul(w, _lib.gather_rows(x, None, idx).transpose(1, 2)), 2.0 * B * M * C * C)):
+            med, best = timeit(fn, a.iters)
+            print(f"linear {name} B={B} M={M} Mq={Mq} C={C}: median {med * 1e3:.1f} us ({fl / med / 1e9:.1f} TFLOP/s), best {best * 1e3:.1f} us")
     else:
         raise SystemExit("unknown benchmark")
 

@@ -8,15 +8,19 @@
 // (row = rows[rows2[i]]).  V can be produced TRANSPOSED (channel-major), which is what the attention kernel's PV
 // contraction reads -- no transpose pass.
 //
-// GEMM: fp16 / bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16), one rounding at the store.  Workgroup tile
-// 128 tokens x 128 output channels, 4 waves of 64 x 64 (2 x 2 accumulator blocks), K walked in steps of 32 through
-// a double-buffered LDS ring (register-staged: the loads of step s + 1 are in flight while step s runs on the MFMA).
-// Both operands are k-contiguous (token rows, and nn.Linear's (out, in) weight rows), so the same LDS tiles serve
-// either MFMA operand slot: the row-major outputs put the WEIGHT rows on the M axis (every lane then owns one token and
-// 4 consecutive channels per accumulator group: 8-byte stores along a token row), the transposed output puts the TOKEN
-// rows there (a lane owns one channel and 4 consecutive tokens).  K = C is 320 / 640 / 1280: the GEMM is short and
-// wide, bound by the A-row gather and the output stream (about one pass over the tokens per 128 output channels, served
-// by L2 / MALL), not by the matrix pipe.
+// GEMM: fp16 / bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16), one rounding at the store.  K = C is only
+// 320 / 640 / 1280: short and wide, so the shape of the kernel is set by getting BYTES IN FLIGHT, not by the matrix pipe:
+//   * a wave owns 32 token rows and fetches THEIR operand fragments straight from global memory into registers, in the
+//     MFMA layout (lane = (row, k-half): 16 bytes per k-step), a whole K-chunk (160 channels = 10 k-steps = 40 VGPRs)
+//     at a time and one chunk ahead -- a workgroup keeps 80 KB of token reads outstanding, no LDS round trip, and the
+//     gather through the row map costs nothing extra (a lane's row pointer is computed once);
+//   * the weight tile (128 output channels x 80 channels of K per step) is the operand all 4 waves share: staged
+//     through a double-buffered LDS ring (register-staged, L2-resident source), 20 MFMAs per wave and barrier;
+//   * both operands are k-contiguous (token rows, and nn.Linear's (out, in) weight rows), so either can take either
+//     MFMA slot: the token-major outputs put the WEIGHT rows on the M axis (a lane then owns one token and 4
+//     consecutive channels per accumulator group: 8-byte stores along a token row), the channel-major output puts the
+//     TOKEN rows there (a lane owns one channel and 4 consecutive tokens).
+// Workgroup tile: 128 tokens x 128 output channels, accumulators 4 x 16 registers per lane.
 #include "common.h"
 
 namespace {
@@ -24,9 +28,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM = 128, TN = 128, TK = 32, NT = 256;
-constexpr int LDK = TK + 8;   // 80-byte rows: 16-byte aligned, conflict-free ds_read_b128 over 32 rows
+constexpr int TM = 128, TN = 128, NT = 256;
 
 template <typename T> struct Mma;
 template <> struct Mma<__half> {
@@ -40,143 +44,170 @@ template <> struct Mma<vtm_bf16> {
     __device__ static vtm_bf16 cvt(float v) { return __float2bfloat16(v); }
 };
 
-// TRANS = false: out[b][token][channel] (row stride ldo); TRANS = true: out[b][channel][token] (row stride ldo)
-template <typename T, bool TRANS>
-__global__ __launch_bounds__(NT, 3) void linear_rows_kernel(
+// TRANS = false: out[b][token][channel] (row stride ldo); TRANS = true: out[b][channel][token] (row stride ldo).
+// CH: channels of K a wave holds in registers per chunk; TKW: channels of K per weight-tile step (CH % TKW == 0);
+// PAIRS: K / CH is even.
+template <typename T, bool TRANS, int CH, int TKW, bool PAIRS>
+__global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
     const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1, int64_t P1, int64_t K,
     const int32_t *__restrict__ rows, int64_t rows_ld, const int32_t *__restrict__ rows2, int64_t n,
     const T *__restrict__ W, const T *__restrict__ bias, int64_t N, T *__restrict__ out, int64_t ldo,
     int64_t out_batch_stride) {
     using M = Mma<T>;
     using vec = typename M::vec;
-    __shared__ __attribute__((aligned(16))) T sX[2][TM * LDK];
-    __shared__ __attribute__((aligned(16))) T sW[2][TN * LDK];
+    constexpr int LDW = TKW + 8;                       // (TKW / 2 + 4) words = 4 x odd -> conflict-free ds_read_b128
+    constexpr int NA = CH / 16;                        // A fragments per chunk
+    constexpr int WSTEPS = CH / TKW, KK = TKW / 16;    // weight steps per chunk, k-steps per weight step
+    constexpr int WPIECES = TN * (TKW / 8), W_PER_T = (WPIECES + NT - 1) / NT;
+    static_assert(CH % TKW == 0 && TKW % 16 == 0 && ((TKW / 2 + 4) / 4) % 2 == 1, "tile shape");
+    __shared__ __attribute__((aligned(16))) T sW[2][TN * LDW];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;            // the wave's 64 x 64 quadrant: tokens 64 wm.., channels 64 wn..
     const int64_t m0 = (int64_t)blockIdx.x * TM, n0 = (int64_t)blockIdx.y * TN, b = blockIdx.z;
 
-    // staging: 128 rows x 4 pieces of 16 bytes per operand and K-step = 512 pieces, 2 per thread
-    const T *xsrc[2], *wsrc[2];
-    int soff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + i * NT, r = c >> 2, piece = c & 3;
-        int64_t t = m0 + r;
+    // this lane's token row (A operand), fetched through the map(s)
+    const T *xrow;
+    {
+        int64_t t = m0 + 32 * wave + l31;
         if (t >= n) t = n - 1;                            // surplus rows recompute the last one; never stored
         int64_t p = rows2 ? rows2[b * n + t] : t;         // live-query rows: position in the merged sequence ...
         if (rows) p = rows[b * rows_ld + p];              // ... -> pool row id
-        xsrc[i] = (p < P0 ? x0 + (b * P0 + p) * K : x1 + (b * P1 + (p - P0)) * K) + piece * 8;
+        xrow = (p < P0 ? x0 + (b * P0 + p) * K : x1 + (b * P1 + (p - P0)) * K) + hi * 8;
+    }
+    // weight tile staging: TN rows x TKW/8 pieces of 16 bytes per step
+    const T *wsrc[W_PER_T];
+    int woff[W_PER_T];
+    bool wok[W_PER_T];
+#pragma unroll
+    for (int i = 0; i < W_PER_T; ++i) {
+        const int c = tid + i * NT;
+        wok[i] = c < WPIECES;
+        const int r = wok[i] ? c / (TKW / 8) : 0, piece = wok[i] ? c % (TKW / 8) : 0;
         int64_t ch = n0 + r;
         if (ch >= N) ch = N - 1;
         wsrc[i] = W + ch * K + piece * 8;
-        soff[i] = r * LDK + piece * 8;
+        woff[i] = r * LDW + piece * 8;
     }
-    uint4 rx[2], rw[2];
-    auto issue = [&](int64_t k0) {
+    u32x4 rw[W_PER_T];
+    auto issue_w = [&](int64_t k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            rx[i] = *reinterpret_cast<const uint4 *>(xsrc[i] + k0);
-            rw[i] = *reinterpret_cast<const uint4 *>(wsrc[i] + k0);
-        }
+        for (int i = 0; i < W_PER_T; ++i) rw[i] = *reinterpret_cast<const u32x4 *>(wsrc[i] + k0);
     };
-    auto stage = [&](int buf) {
+    auto stage_w = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<uint4 *>(&sX[buf][soff[i]]) = rx[i];
-            *reinterpret_cast<uint4 *>(&sW[buf][soff[i]]) = rw[i];
-        }
+        for (int i = 0; i < W_PER_T; ++i)
+            if (wok[i]) *reinterpret_cast<u32x4 *>(&sW[buf][woff[i]]) = rw[i];
+    };
+    auto load_a = [&](vec (&a)[NA], int64_t k0) {
+#pragma unroll
+        for (int f = 0; f < NA; ++f) a[f] = *reinterpret_cast<const vec *>(xrow + k0 + f * 16);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
-    const int steps = (int)(K / TK);
-    issue(0);
-    stage(0);
-    __syncthreads();
-    for (int s = 0; s < steps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < steps) issue((int64_t)(s + 1) * TK);
-        const T *px = &sX[buf][(64 * wm + l31) * LDK + hi * 8];
-        const T *pw = &sW[buf][(64 * wn + l31) * LDK + hi * 8];
+    const int nchunks = (int)(K / CH);
+    const int64_t k_last = K - TKW;
+    int wbuf = 0;
+    // one K-chunk: `cur` holds this chunk's A fragments, `nxt` receives the next chunk's while this one runs.  Every
+    // load is issued unconditionally (the last chunk / step re-fetches itself, unused): with a fixed issue sequence the
+    // compiler's waits are counted ones, a conditional prefetch makes it drain everything right after issuing it.
+    auto run_chunk = [&](vec (&cur)[NA], vec (&nxt)[NA], int c) {
 #pragma unroll
-        for (int kk = 0; kk < TK / 16; ++kk) {
-            vec fx[2], fw[2];
+        for (int ws = 0; ws < WSTEPS; ++ws) {
+            const int64_t k_next = (int64_t)c * CH + (int64_t)(ws + 1) * TKW;
+            issue_w(k_next < k_last ? k_next : k_last);
+            // the token prefetch goes BEHIND the first weight loads of the chunk: vmcnt retires in order, so the wait
+            // for this step's weight tile then leaves the (younger) token loads in flight
+            if (ws == 0) load_a(nxt, (int64_t)(c + 1 < nchunks ? c + 1 : c) * CH);
+            const T *pw = &sW[wbuf][l31 * LDW + hi * 8];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fx[i] = *reinterpret_cast<const vec *>(px + i * 32 * LDK + kk * 16);
-                fw[i] = *reinterpret_cast<const vec *>(pw + i * 32 * LDK + kk * 16);
-            }
+            for (int kk = 0; kk < KK; ++kk) {
+                vec fw[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const vec *>(pw + j * 32 * LDW + kk * 16);
+                const vec fx = cur[ws * KK + kk];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // acc[i][j]: token block i, channel block j.  MFMA result rows = first operand's rows.
-                    if constexpr (TRANS) acc[i][j] = M::run(fx[i], fw[j], acc[i][j]);   // rows = tokens, cols = channels
-                    else acc[i][j] = M::run(fw[j], fx[i], acc[i][j]);                   // rows = channels, cols = tokens
+                for (int j = 0; j < 4; ++j) {
+                    // MFMA result rows = first operand's rows
+                    if constexpr (TRANS) acc[j] = M::run(fx, fw[j], acc[j]);   // rows = tokens, cols = channels
+                    else acc[j] = M::run(fw[j], fx, acc[j]);                   // rows = channels, cols = tokens
                 }
-        }
-        if (s + 1 < steps) {
-            stage(buf ^ 1);
+            }
+            stage_w(wbuf ^ 1);
             __syncthreads();
+            wbuf ^= 1;
+        }
+    };
+
+    vec a0[NA], a1[NA];
+    load_a(a0, 0);
+    issue_w(0);
+    stage_w(0);
+    __syncthreads();
+    if constexpr (PAIRS) {               // even number of chunks: no tail logic at all
+        for (int c = 0; c < nchunks; c += 2) {
+            run_chunk(a0, a1, c);
+            run_chunk(a1, a0, c + 1);
+        }
+    } else {
+        for (int c = 0; c < nchunks; c += 2) {
+            run_chunk(a0, a1, c);
+            if (c + 1 < nchunks) run_chunk(a1, a0, c + 1);
         }
     }
 
     // epilogue.  Accumulator register r of a lane = result row (r & 3) + 8 (r >> 2) + 4 hi, column l31.
     T *ob = out + b * out_batch_stride;
+    const int64_t tok0 = m0 + 32 * wave;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j) {
+        const int64_t ch0 = n0 + 32 * j;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t tok0 = m0 + 64 * wm + 32 * i, ch0 = n0 + 64 * wn + 32 * j;
+        for (int g = 0; g < 4; ++g) {
+            const int rr = 8 * g + 4 * hi;             // first of the 4 consecutive result rows of this group
+            T w4[4];
+            if constexpr (TRANS) {
+                // rows = tokens tok0 + rr .. + 3, column = channel ch0 + l31: out[ch][tok..tok+3]
+                const int64_t ch = ch0 + l31, tok = tok0 + rr;
+                if (ch < N && tok < n) {
+                    const float bv = bias ? vtm::to_f32(bias[ch]) : 0.0f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int rr = 8 * g + 4 * hi;             // first of the 4 consecutive result rows of this group
-                T w4[4];
-                if constexpr (TRANS) {
-                    // rows = tokens tok0 + rr .. + 3, column = channel ch0 + l31: out[ch][tok..tok+3]
-                    const int64_t ch = ch0 + l31, tok = tok0 + rr;
-                    if (ch < N && tok < n) {
-                        const float bv = bias ? vtm::to_f32(bias[ch]) : 0.0f;
+                    for (int e = 0; e < 4; ++e) w4[e] = M::cvt(acc[j][4 * g + e] + bv);
+                    T *dst = ob + ch * ldo + tok;
+                    if (tok + 3 < n && ((ldo | tok) & 3) == 0) {
+                        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(w4);
+                    } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) w4[e] = M::cvt(acc[i][j][4 * g + e] + bv);
-                        T *dst = ob + ch * ldo + tok;
-                        if (tok + 3 < n && ((ldo | tok) & 3) == 0) {
-                            *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(w4);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (tok + e < n) dst[e] = w4[e];
-                        }
+                        for (int e = 0; e < 4; ++e)
+                            if (tok + e < n) dst[e] = w4[e];
                     }
-                } else {
-                    // rows = channels ch0 + rr .. + 3, column = token tok0 + l31: out[tok][ch..ch+3]
-                    const int64_t tok = tok0 + l31, ch = ch0 + rr;
-                    if (tok < n && ch < N) {
+                }
+            } else {
+                // rows = channels ch0 + rr .. + 3, column = token tok0 + l31: out[tok][ch..ch+3]
+                const int64_t tok = tok0 + l31, ch = ch0 + rr;
+                if (tok < n && ch < N) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float bv = (bias && ch + e < N) ? vtm::to_f32(bias[ch + e]) : 0.0f;
-                            w4[e] = M::cvt(acc[i][j][4 * g + e] + bv);
-                        }
-                        T *dst = ob + tok * ldo + ch;
-                        if (ch + 3 < N && ((ldo | ch) & 3) == 0) {
-                            *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(w4);
-                        } else {
+                    for (int e = 0; e < 4; ++e) {
+                        const float bv = (bias && ch + e < N) ? vtm::to_f32(bias[ch + e]) : 0.0f;
+                        w4[e] = M::cvt(acc[j][4 * g + e] + bv);
+                    }
+                    T *dst = ob + tok * ldo + ch;
+                    if (ch + 3 < N && ((ldo | ch) & 3) == 0) {
+                        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(w4);
+                    } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (ch + e < N) dst[e] = w4[e];
-                        }
+                        for (int e = 0; e < 4; ++e)
+                            if (ch + e < N) dst[e] = w4[e];
                     }
                 }
             }
         }
+    }
 }
 
 template <typename T>
@@ -184,12 +215,15 @@ int launch(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, in
            int64_t rows_ld, const int32_t *rows2, int64_t n, const void *W, const void *bias, int64_t N, void *out,
            int64_t ldo, int64_t obs, int transposed, hipStream_t s) {
     const dim3 grid((unsigned)vtm::cdiv(n, TM), (unsigned)vtm::cdiv(N, TN), (unsigned)B), block(NT);
-    if (transposed)
-        hipLaunchKernelGGL((linear_rows_kernel<T, true>), grid, block, 0, s, (const T *)x0, P0, (const T *)x1, P1, K, rows,
-                           rows_ld, rows2, n, (const T *)W, (const T *)bias, N, (T *)out, ldo, obs);
-    else
-        hipLaunchKernelGGL((linear_rows_kernel<T, false>), grid, block, 0, s, (const T *)x0, P0, (const T *)x1, P1, K, rows,
-                           rows_ld, rows2, n, (const T *)W, (const T *)bias, N, (T *)out, ldo, obs);
+#define VTM_LIN(TR, CH_, TKW_, PAIRS_)                                                                                 \
+    hipLaunchKernelGGL((linear_rows_kernel<T, TR, CH_, TKW_, PAIRS_>), grid, block, 0, s, (const T *)x0, P0, (const T *)x1, \
+                       P1, K, rows, rows_ld, rows2, n, (const T *)W, (const T *)bias, N, (T *)out, ldo, obs)
+    if (K % 320 == 0) {                  // the SD channel counts (320, 640, 1280): chunks of 160, an even number of them
+        if (transposed) VTM_LIN(true, 160, 80, true); else VTM_LIN(false, 160, 80, true);
+    } else {                             // any other multiple of 32
+        if (transposed) VTM_LIN(true, 32, 32, false); else VTM_LIN(false, 32, 32, false);
+    }
+#undef VTM_LIN
     return vtm::launch_status("vtm_linear_rows");
 }
 
@@ -202,7 +236,7 @@ VTM_EXPORT int vtm_linear_rows(const void *x0, int64_t P0, const void *x1, int64
     VTM_REQUIRE(x0 && W && out, "vtm_linear_rows: null pointer");
     VTM_REQUIRE(P1 == 0 || x1, "vtm_linear_rows: x1 is null but P1 > 0");
     VTM_REQUIRE(B > 0 && B < 65536 && K > 0 && N > 0 && n >= 0 && P0 >= 0 && P1 >= 0, "vtm_linear_rows: bad sizes");
-    VTM_REQUIRE(K % TK == 0, "vtm_linear_rows: K=%lld must be a multiple of %d", (long long)K, TK);
+    VTM_REQUIRE(K % 32 == 0, "vtm_linear_rows: K=%lld must be a multiple of 32", (long long)K);
     VTM_REQUIRE(rows || rows2 || n <= P0 + P1, "vtm_linear_rows: identity rows must lie inside the pool");
     VTM_REQUIRE(!rows || rows_ld > 0, "vtm_linear_rows: rows_ld");
     VTM_REQUIRE(ldo >= (transposed ? n : N), "vtm_linear_rows: ldo too small");
