@@ -106,6 +106,17 @@ template <> struct Frag<vtm_bf16> {
     }
 };
 
+// XCD-aware placement of the work items (query block, head, sample).  Workgroups are dispatched round-robin over the 8
+// XCDs in index order (observed, not a contract -- this is a speed choice, any placement gives the same result), so
+// position p runs on XCD p % 8.  All query blocks of one (sample, head) share its K / V^T stream: with `xcd_groups`
+// = (B * H) / 8 > 0 the (sample, head) pairs are dealt to the XCDs -- pair hb runs on XCD hb % 8 only -- so that a
+// K / V^T slice is fetched into ONE L2 instead of all eight (9x the algorithmic HBM-side traffic otherwise).
+__device__ __forceinline__ int64_t item_of(int64_t pos, int64_t nqb, int xcd_groups) {
+    if (xcd_groups == 0) return pos;
+    const int64_t xcd = pos & 7, slot = pos >> 3;
+    return (xcd + 8 * (slot / nqb)) * nqb + slot % nqb;
+}
+
 // zero the 16-bit elements j >= valid of a 16-byte piece (8 elements), on whole dwords so that the staging
 // registers stay plain 32-bit values (an element-wise view makes the compiler repack them after every load)
 __device__ __forceinline__ void mask_keys(uint4 &v, int valid) {
@@ -185,13 +196,13 @@ __device__ __forceinline__ void write_output16(const f32x4 (&o)[(D + 16) / 16][2
 template <typename T, int D>
 __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
     const float *__restrict__ partial, T *__restrict__ out, int64_t ldo, int64_t H, int64_t M, int64_t Mp, int64_t nqb,
-    int64_t id0, int nsplit) {
+    int64_t id0, int nsplit, int xcd_groups) {
     constexpr int WAVES = waves_for(D), NT = WAVES * 64, QB = WAVES * QW, DV = (D + 31) / 32;
     constexpr bool PV16 = pv16_for(D);
     constexpr int NA = acc_floats(D), NM = max_floats(D), REC = rec_floats(D);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int64_t lin = id0 + blockIdx.x;
+    const int64_t lin = item_of(id0 + blockIdx.x, nqb, xcd_groups);
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
     float acc[NA], m[NM], l = 0.0f;
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
     int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t nwhole,
-    int nsplit_tail, float *__restrict__ partial_base) {
+    int nsplit_tail, float *__restrict__ partial_base, int xcd_groups) {
     // M / Mp: queries per sample and their row stride; Mk / Mkp: keys per sample and the row stride of k
     // (self-attention passes the same values; cross-attention, patch.py:178-183, has Mk = 77).
     // Work decomposition: work item = (query block, head, sample), query blocks fastest.  Workgroups [0, nwhole) take
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const bool tail_wg = (int64_t)blockIdx.x >= nwhole;
     const int64_t tail_id = (int64_t)blockIdx.x - nwhole;
     const int nsplit = tail_wg ? nsplit_tail : 1;
-    const int64_t lin = tail_wg ? nwhole + tail_id / nsplit : (int64_t)blockIdx.x;
+    const int64_t lin = item_of(tail_wg ? nwhole + tail_id / nsplit : (int64_t)blockIdx.x, nqb, xcd_groups);
     const int split = tail_wg ? (int)(tail_id % nsplit) : 0;
     float *partial = tail_wg ? partial_base + tail_id * rec_floats(D) * (waves_for(D) * 64) : nullptr;
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
@@ -713,12 +724,19 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
     // one launch: the whole workgroups first, the key-split ones of the last round behind them (they start as the
     // slots of the last whole round free up -- no launch boundary to drain)
     const int64_t rem = p.total - p.full;
+    // (sample, head) pairs pinned to XCDs when they divide evenly and every pair has enough query blocks to keep an
+    // XCD's share of the chip busy (see item_of); VTM_ATT_NO_XCD_MAP is an A/B build switch
+#ifdef VTM_ATT_NO_XCD_MAP
+    const int xcd_groups = 0;
+#else
+    const int xcd_groups = ((B * h) % 8 == 0 && p.nqb >= 64) ? (int)(B * h / 8) : 0;
+#endif
     hipLaunchKernelGGL((attention_kernel<T, D>), dim3((unsigned)(p.full + rem * p.nsplit)), dim3(WAVES * 64), lds, s,
                        (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
-                       scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws);
+                       scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws, xcd_groups);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem), dim3(WAVES * 64), 0, s,
-                           (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit);
+                           (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups);
     return vtm::launch_status("vtm_attention");
 }
 

@@ -20,7 +20,8 @@
 //     MFMA slot: the token-major outputs put the WEIGHT rows on the M axis (a lane then owns one token and 4
 //     consecutive channels per accumulator group: 8-byte stores along a token row), the channel-major output puts the
 //     TOKEN rows there (a lane owns one channel and 4 consecutive tokens).
-// Workgroup tile: 128 tokens x 128 output channels, accumulators 4 x 16 registers per lane.
+// Workgroup tile: 128 tokens x 160 output channels (128 when N is not a multiple of 160), 5 (4) x 16 accumulator
+// registers per lane.
 #include "common.h"
 
 namespace {
@@ -30,7 +31,7 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM = 128, TN = 128, NT = 256;
+constexpr int TM = 128, NT = 256;
 
 template <typename T> struct Mma;
 template <> struct Mma<__half> {
@@ -46,8 +47,8 @@ template <> struct Mma<vtm_bf16> {
 
 // TRANS = false: out[b][token][channel] (row stride ldo); TRANS = true: out[b][channel][token] (row stride ldo).
 // CH: channels of K a wave holds in registers per chunk; TKW: channels of K per weight-tile step (CH % TKW == 0);
-// PAIRS: K / CH is even.
-template <typename T, bool TRANS, int CH, int TKW, bool PAIRS>
+// PAIRS: K / CH is even; TN: output channels per workgroup (160 divides every SD channel count: no ragged last tile).
+template <typename T, bool TRANS, int CH, int TKW, bool PAIRS, int TN>
 __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
     const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1, int64_t P1, int64_t K,
     const int32_t *__restrict__ rows, int64_t rows_ld, const int32_t *__restrict__ rows2, int64_t n,
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
     constexpr int LDW = TKW + 8;                       // (TKW / 2 + 4) words = 4 x odd -> conflict-free ds_read_b128
     constexpr int NA = CH / 16;                        // A fragments per chunk
     constexpr int WSTEPS = CH / TKW, KK = TKW / 16;    // weight steps per chunk, k-steps per weight step
-    constexpr int WPIECES = TN * (TKW / 8), W_PER_T = (WPIECES + NT - 1) / NT;
+    constexpr int WPIECES = TN * (TKW / 8), W_PER_T = (WPIECES + NT - 1) / NT, NJ = TN / 32;
     static_assert(CH % TKW == 0 && TKW % 16 == 0 && ((TKW / 2 + 4) / 4) % 2 == 1, "tile shape");
     __shared__ __attribute__((aligned(16))) T sW[2][TN * LDW];
 
@@ -104,9 +105,9 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
         for (int f = 0; f < NA; ++f) a[f] = *reinterpret_cast<const vec *>(xrow + k0 + f * 16);
     };
 
-    f32x16 acc[4];
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
@@ -124,20 +125,24 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
             // the token prefetch goes BEHIND the first weight loads of the chunk: vmcnt retires in order, so the wait
             // for this step's weight tile then leaves the (younger) token loads in flight
             if (ws == 0) load_a(nxt, (int64_t)(c + 1 < nchunks ? c + 1 : c) * CH);
+            // keep the loads HERE: left alone, the scheduler sinks them below the MFMAs (fewer live registers) and the
+            // step then waits out their whole latency
+            __builtin_amdgcn_sched_barrier(0);
             const T *pw = &sW[wbuf][l31 * LDW + hi * 8];
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                vec fw[4];
+                vec fw[NJ];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const vec *>(pw + j * 32 * LDW + kk * 16);
+                for (int j = 0; j < NJ; ++j) fw[j] = *reinterpret_cast<const vec *>(pw + j * 32 * LDW + kk * 16);
                 const vec fx = cur[ws * KK + kk];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     // MFMA result rows = first operand's rows
                     if constexpr (TRANS) acc[j] = M::run(fx, fw[j], acc[j]);   // rows = tokens, cols = channels
                     else acc[j] = M::run(fw[j], fx, acc[j]);                   // rows = channels, cols = tokens
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
             stage_w(wbuf ^ 1);
             __syncthreads();
             wbuf ^= 1;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
     T *ob = out + b * out_batch_stride;
     const int64_t tok0 = m0 + 32 * wave;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int64_t ch0 = n0 + 32 * j;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -214,15 +219,21 @@ template <typename T>
 int launch(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, int64_t K, const int32_t *rows,
            int64_t rows_ld, const int32_t *rows2, int64_t n, const void *W, const void *bias, int64_t N, void *out,
            int64_t ldo, int64_t obs, int transposed, hipStream_t s) {
-    const dim3 grid((unsigned)vtm::cdiv(n, TM), (unsigned)vtm::cdiv(N, TN), (unsigned)B), block(NT);
-#define VTM_LIN(TR, CH_, TKW_, PAIRS_)                                                                                 \
-    hipLaunchKernelGGL((linear_rows_kernel<T, TR, CH_, TKW_, PAIRS_>), grid, block, 0, s, (const T *)x0, P0, (const T *)x1, \
-                       P1, K, rows, rows_ld, rows2, n, (const T *)W, (const T *)bias, N, (T *)out, ldo, obs)
+    const int tn = (N % 160 == 0) ? 160 : 128;
+    const dim3 grid((unsigned)vtm::cdiv(n, TM), (unsigned)vtm::cdiv(N, tn), (unsigned)B), block(NT);
+#define VTM_LIN(TR, CH_, TKW_, PAIRS_, TN_)                                                                            \
+    hipLaunchKernelGGL((linear_rows_kernel<T, TR, CH_, TKW_, PAIRS_, TN_>), grid, block, 0, s, (const T *)x0, P0,     \
+                       (const T *)x1, P1, K, rows, rows_ld, rows2, n, (const T *)W, (const T *)bias, N, (T *)out, ldo, obs)
+#define VTM_LIN_TN(TR, CH_, TKW_, PAIRS_)                                                                             \
+    do {                                                                                                              \
+        if (tn == 160) VTM_LIN(TR, CH_, TKW_, PAIRS_, 160); else VTM_LIN(TR, CH_, TKW_, PAIRS_, 128);                 \
+    } while (0)
     if (K % 320 == 0) {                  // the SD channel counts (320, 640, 1280): chunks of 160, an even number of them
-        if (transposed) VTM_LIN(true, 160, 80, true); else VTM_LIN(false, 160, 80, true);
+        if (transposed) VTM_LIN_TN(true, 160, 80, true); else VTM_LIN_TN(false, 160, 80, true);
     } else {                             // any other multiple of 32
-        if (transposed) VTM_LIN(true, 32, 32, false); else VTM_LIN(false, 32, 32, false);
+        if (transposed) VTM_LIN_TN(true, 32, 32, false); else VTM_LIN_TN(false, 32, 32, false);
     }
+#undef VTM_LIN_TN
 #undef VTM_LIN
     return vtm::launch_status("vtm_linear_rows");
 }
@@ -240,7 +251,7 @@ VTM_EXPORT int vtm_linear_rows(const void *x0, int64_t P0, const void *x1, int64
     VTM_REQUIRE(rows || rows2 || n <= P0 + P1, "vtm_linear_rows: identity rows must lie inside the pool");
     VTM_REQUIRE(!rows || rows_ld > 0, "vtm_linear_rows: rows_ld");
     VTM_REQUIRE(ldo >= (transposed ? n : N), "vtm_linear_rows: ldo too small");
-    VTM_REQUIRE(vtm::cdiv(N, TN) < 65536, "vtm_linear_rows: N too large");
+    VTM_REQUIRE(vtm::cdiv(N, 128) < 65536, "vtm_linear_rows: N too large");
     if (n == 0) return VTM_OK;
     hipStream_t s = vtm::as_stream(stream);
     switch (dtype) {
