@@ -126,7 +126,9 @@ def main():
                 ("q   rows", lambda: _lib.linear_rows(x, None, idx, q_rows, Mq, w, None), 2.0 * B * Mq * C * C),
                 ("k   blas", lambda: F.linear(_lib.gather_rows(x, None, idx), w), 2.0 * B * M * C * C),
                 ("v^T blas", lambda: torch.matmul(w, _lib.gather_rows(x, None, idx).transpose(1, 2)), 2.0 * B * M * C * C)):
-            med, best = timeit(fn, a.iters)
+            REP = 8                                   # several launches per timed interval: these kernels are short
+            med, best = timeit(lambda: [fn() for _ in range(REP)], a.iters)
+            med, best = med / REP, best / REP
             print(f"linear {name} B={B} M={M} Mq={Mq} C={C}: median {med * 1e3:.1f} us ({fl / med / 1e9:.1f} TFLOP/s), best {best * 1e3:.1f} us")
     else:
         raise SystemExit("unknown benchmark")

@@ -93,16 +93,31 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
     u32x4 rw[W_PER_T];
     auto issue_w = [&](int64_t k0) {
 #pragma unroll
-        for (int i = 0; i < W_PER_T; ++i) rw[i] = *reinterpret_cast<const u32x4 *>(wsrc[i] + k0);
+        for (int i = 0; i < W_PER_T; ++i) {
+#ifdef VTM_LIN_NOW
+            rw[i] = u32x4{(unsigned)k0, 1u, 2u, 3u};
+#else
+            rw[i] = *reinterpret_cast<const u32x4 *>(wsrc[i] + k0);
+#endif
+        }
     };
     auto stage_w = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < W_PER_T; ++i)
             if (wok[i]) *reinterpret_cast<u32x4 *>(&sW[buf][woff[i]]) = rw[i];
     };
+    // Ablation switches (never defined in the shipped build; they produce wrong results and only tell where the time
+    // goes): VTM_LIN_NOA no token loads, VTM_LIN_NOW no weight-tile loads, VTM_LIN_NOSTORE no output stores
     auto load_a = [&](vec (&a)[NA], int64_t k0) {
+#ifdef VTM_LIN_NOA
+#pragma unroll
+        for (int f = 0; f < NA; ++f)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[f][e] = (decltype(a[f][e] + a[f][e]))(k0 + f);
+#else
 #pragma unroll
         for (int f = 0; f < NA; ++f) a[f] = *reinterpret_cast<const vec *>(xrow + k0 + f * 16);
+#endif
     };
 
     f32x16 acc[NJ];
@@ -166,48 +181,138 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
         }
     }
 
-    // epilogue.  Accumulator register r of a lane = result row (r & 3) + 8 (r >> 2) + 4 hi, column l31.
+    // epilogue.  Accumulator register r of a lane = result row (r & 3) + 8 (r >> 2) + 4 hi, column l31: a lane owns
+    // 4 consecutive elements along one output row and 32 lanes sit on 32 DIFFERENT rows -- stored directly that is 8
+    // bytes per lane at a row stride, which costs more than the whole GEMM (measured: 107 -> 50 us at the cfg-2 top
+    // block without the stores).  The tile therefore goes through LDS (the weight ring is free by now) and leaves as
+    // 16-byte pieces of whole rows: 320 contiguous bytes per token (token-major), 256 per channel (channel-major).
+#ifdef VTM_LIN_NOSTORE
+    if (acc[0][0] != 12345.678f) return;
+#endif
     T *ob = out + b * out_batch_stride;
     const int64_t tok0 = m0 + 32 * wave;
+    constexpr bool STAGED = sizeof(sW) >= (size_t)(TRANS ? TN * (TM + 8) : 4 * 32 * (TN + 8)) * sizeof(T);
+    const bool vec_ok = ((ldo & 7) == 0) && ((reinterpret_cast<uintptr_t>(ob) & 15) == 0);
+    if constexpr (STAGED) {
+        __syncthreads();                                   // every wave is done with the weight ring
+        T *stage = &sW[0][0];
+        if constexpr (!TRANS) {
+            constexpr int SO = TN + 8;                     // (TN / 2 + 4) words = 4 x odd: conflict-free b64 writes
+            T *my = stage + wave * 32 * SO;                // this wave's 32 tokens x TN channels
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int64_t ch0 = n0 + 32 * j;
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int rr = 8 * g + 4 * hi;             // first of the 4 consecutive result rows of this group
-            T w4[4];
-            if constexpr (TRANS) {
-                // rows = tokens tok0 + rr .. + 3, column = channel ch0 + l31: out[ch][tok..tok+3]
-                const int64_t ch = ch0 + l31, tok = tok0 + rr;
-                if (ch < N && tok < n) {
-                    const float bv = bias ? vtm::to_f32(bias[ch]) : 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w4[e] = M::cvt(acc[j][4 * g + e] + bv);
-                    T *dst = ob + ch * ldo + tok;
-                    if (tok + 3 < n && ((ldo | tok) & 3) == 0) {
-                        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(w4);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (tok + e < n) dst[e] = w4[e];
-                    }
-                }
-            } else {
-                // rows = channels ch0 + rr .. + 3, column = token tok0 + l31: out[tok][ch..ch+3]
-                const int64_t tok = tok0 + l31, ch = ch0 + rr;
-                if (tok < n && ch < N) {
+                for (int g = 0; g < 4; ++g) {
+                    const int rr = 8 * g + 4 * hi;
+                    const int64_t ch = n0 + 32 * j + rr;
+                    T w4[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float bv = (bias && ch + e < N) ? vtm::to_f32(bias[ch + e]) : 0.0f;
                         w4[e] = M::cvt(acc[j][4 * g + e] + bv);
                     }
-                    T *dst = ob + tok * ldo + ch;
-                    if (ch + 3 < N && ((ldo | ch) & 3) == 0) {
-                        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(w4);
-                    } else {
+                    *reinterpret_cast<uint2 *>(my + l31 * SO + 32 * j + rr) = *reinterpret_cast<const uint2 *>(w4);
+                }
+            __builtin_amdgcn_wave_barrier();               // LDS is FIFO per wave: the reads below see the writes above
+            constexpr int PR = TN / 8;                     // 16-byte pieces per token row
+            static_assert((32 * PR) % 64 == 0, "whole wave-instructions");
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (ch + e < N) dst[e] = w4[e];
+            for (int it = 0; it < 32 * PR / 64; ++it) {
+                const int p = lane + 64 * it;
+                const int row = p / PR, c8 = (p % PR) * 8;
+                const int64_t tok = tok0 + row, ch = n0 + c8;
+                if (tok < n && ch < N) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(my + row * SO + c8);
+                    T *dst = ob + tok * ldo + ch;
+                    if (ch + 8 <= N && vec_ok) {
+                        *reinterpret_cast<uint4 *>(dst) = v;
+                    } else {
+                        const T *e8 = reinterpret_cast<const T *>(&v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (ch + e < N) dst[e] = e8[e];
+                    }
+                }
+            }
+        } else {
+            constexpr int SO = TM + 8;                     // channel rows of the whole 128-token tile
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int64_t ch = n0 + 32 * j + l31;
+                const float bv = (bias && ch < N) ? vtm::to_f32(bias[ch]) : 0.0f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int rr = 8 * g + 4 * hi;
+                    T w4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w4[e] = M::cvt(acc[j][4 * g + e] + bv);
+                    *reinterpret_cast<uint2 *>(stage + (32 * j + l31) * SO + 32 * wave + rr) = *reinterpret_cast<const uint2 *>(w4);
+                }
+            }
+            __syncthreads();
+            constexpr int PR = TM / 8;                     // 16 pieces per channel row
+            static_assert((TN * PR) % NT == 0, "whole workgroup passes");
+#pragma unroll
+            for (int it = 0; it < TN * PR / NT; ++it) {
+                const int p = tid + NT * it;
+                const int row = p / PR, c8 = (p % PR) * 8;
+                const int64_t ch = n0 + row, tok = m0 + c8;
+                if (ch < N && tok < n) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(stage + row * SO + c8);
+                    T *dst = ob + ch * ldo + tok;
+                    if (tok + 8 <= n && vec_ok) {
+                        *reinterpret_cast<uint4 *>(dst) = v;
+                    } else {
+                        const T *e8 = reinterpret_cast<const T *>(&v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (tok + e < n) dst[e] = e8[e];
+                    }
+                }
+            }
+        }
+    } else {
+        // small-K instantiation (its weight ring is too small to hold the tile): direct 8-byte stores
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int64_t ch0 = n0 + 32 * j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rr = 8 * g + 4 * hi;             // first of the 4 consecutive result rows of this group
+                T w4[4];
+                if constexpr (TRANS) {
+                    // rows = tokens tok0 + rr .. + 3, column = channel ch0 + l31: out[ch][tok..tok+3]
+                    const int64_t ch = ch0 + l31, tok = tok0 + rr;
+                    if (ch < N && tok < n) {
+                        const float bv = bias ? vtm::to_f32(bias[ch]) : 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w4[e] = M::cvt(acc[j][4 * g + e] + bv);
+                        T *dst = ob + ch * ldo + tok;
+                        if (tok + 3 < n && ((ldo | tok) & 3) == 0) {
+                            *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(w4);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (tok + e < n) dst[e] = w4[e];
+                        }
+                    }
+                } else {
+                    // rows = channels ch0 + rr .. + 3, column = token tok0 + l31: out[tok][ch..ch+3]
+                    const int64_t tok = tok0 + l31, ch = ch0 + rr;
+                    if (tok < n && ch < N) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float bv = (bias && ch + e < N) ? vtm::to_f32(bias[ch + e]) : 0.0f;
+                            w4[e] = M::cvt(acc[j][4 * g + e] + bv);
+                        }
+                        T *dst = ob + tok * ldo + ch;
+                        if (ch + 3 < N && ((ldo | ch) & 3) == 0) {
+                            *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(w4);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (ch + e < N) dst[e] = w4[e];
+                        }
                     }
                 }
             }
