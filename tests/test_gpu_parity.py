@@ -859,8 +859,9 @@ def test_projection_paths_agree(L):
     sl = [sites.Site("top", 1, 320, 8), sites.Site("mid", 2, 640, 8), sites.Site("low", 4, 1280, 8)]
     B, F, latent = 2, 4, (16, 16)
     outs = {}
+    saved = vpatch.PROJ_MODE
     for mode in (True, False):
-        vpatch.FUSED_PROJ = mode
+        vpatch.FUSED_PROJ, vpatch.PROJ_MODE = mode, "rows"       # "rows": every site through vtm_linear_rows
         try:
             unet = sites.SiteUNet(sl, seed=0).to(device=DEV, dtype=torch.float16)
             vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B)
@@ -874,7 +875,7 @@ def test_projection_paths_agree(L):
                     res.append([o.float() for o in sites.run_segment_pass(unet, hs)])
             outs[mode] = res
         finally:
-            vpatch.FUSED_PROJ = True
+            vpatch.FUSED_PROJ, vpatch.PROJ_MODE = True, saved
     for a, b in zip(outs[True], outs[False]):
         for x, y in zip(a, b):
             assert torch.isfinite(x).all()

@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU session producing everything profiles/ and DESIGN.md quote: full GPU test suite, smoke, bench (with the CPU
+# baseline leg), rocprofv3 kernel trace of the bench, PMC counters of the dominant kernels.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_session.sh r02x'
+TAG=${1:-session}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+python -m pytest tests -m gpu -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests.log
+python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python -c "
+import json;d=json.load(open('$O/bench.json'));print(d['value'],d['ms_per_step'],d['roofline']['frac'],d['roofline']['top_block'],d['matching'],d.get('projections'),d['cpu_baseline']['seconds_per_step'],d['cpu_baseline']['cores'])"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1; echo "prof rc=$?"
+grep '"metric"' $O/prof.log > $O/bench_profiled.json
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc -o sq_attn --output-format csv -- python $R/tools/kbench.py attn --Mq 34816 --M 52224 --d 40 --iters 3 > $O/pmc_sq_attn.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc -o sq_match --output-format csv -- python $R/tools/kbench.py match --shape top_l1 --iters 3 > $O/pmc_sq_match.log 2>&1
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc -o ${ctr}_attn --output-format csv -- python $R/tools/kbench.py attn --Mq 34816 --M 52224 --d 40 --iters 3 > $O/pmc_${ctr}_attn.log 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc -o ${ctr}_match --output-format csv -- python $R/tools/kbench.py match --shape top_l1 --iters 3 > $O/pmc_${ctr}_match.log 2>&1
+done
+ls $O/pmc | wc -l

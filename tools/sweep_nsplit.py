@@ -40,7 +40,7 @@ def main():
         os.environ.pop("VTM_DEBUG_NSPLIT", None)
         ref = _lib.match_filtered(x, None, ra, rb, False)
         out = [f"default {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}"]
-        for ns in range(2, 9):
+        for ns in range(2, 15):
             os.environ["VTM_DEBUG_NSPLIT"] = str(ns)
             assert torch.equal(_lib.match_filtered(x, None, ra, rb, False), ref)
             out.append(f"{ns}: {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}")

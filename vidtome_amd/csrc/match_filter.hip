@@ -742,7 +742,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         }
         if (const char *dbg = getenv("VTM_DEBUG_NSPLIT")) {   // tuning hook (tools/sweep_nsplit.py)
             const int v = atoi(dbg);
-            if (v >= 1 && v <= 8 && v <= nd_tiles) nsplit = v;
+            if (v >= 1 && v <= 16 && v <= nd_tiles) nsplit = v;
         }
         const int tiles_per_split = (int)vtm::cdiv(nd_tiles, nsplit);
         nsplit = (int)vtm::cdiv(nd_tiles, tiles_per_split);

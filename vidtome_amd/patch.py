@@ -303,15 +303,21 @@ def fused_attention_ok(attn: torch.nn.Module, x: torch.Tensor, self_attn: bool =
     return True
 
 
-# VIDTOME_PROJ=blas keeps the projections on library GEMMs (torch -> hipBLASLt) over materialised merged tokens;
-# the default feeds them through the composed merge map (vtm_linear_rows), so the C ABI covers attn1 end to end.
-FUSED_PROJ = os.environ.get("VIDTOME_PROJ", "rows") != "blas"
+# How attn1's projections are computed.  "rows": vtm_linear_rows, GEMMs whose A rows are fetched through the composed
+# merge map (no merged tensor, V produced channel-major; the C ABI then covers attn1 end to end).  "blas": library GEMMs
+# (torch -> hipBLASLt) over materialised merged tokens.  "auto" (default) picks per site what measures faster on MI355X
+# (profiles/r02_*): the gather-fused kernel at C <= 320 (cfg-2 top blocks: k 73 vs 99 us, v^T 65 vs 81 us), the library
+# at C >= 640, where its 256 x 256 macro-tiles move half the operand bytes of the 128 x 160 tiles of linear.hip.
+PROJ_MODE = os.environ.get("VIDTOME_PROJ", "auto")
+FUSED_PROJ = PROJ_MODE != "blas"                      # (tests toggle this to compare the two paths)
 
 
 def fused_projections_ok(attn: torch.nn.Module, x: torch.Tensor) -> bool:
     """The gather-fused projection GEMM (vtm_linear_rows) takes fp16 / bf16 tokens with C % 32 == 0."""
-    return FUSED_PROJ and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 32 == 0 \
-        and attn.to_q.weight.dtype == x.dtype
+    if not FUSED_PROJ or x.dtype not in (torch.float16, torch.bfloat16) or x.shape[-1] % 32 \
+            or attn.to_q.weight.dtype != x.dtype:
+        return False
+    return PROJ_MODE == "rows" or x.shape[-1] <= 320
 
 
 def _weight(m: torch.nn.Module, dtype) -> torch.Tensor:
