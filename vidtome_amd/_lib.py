@@ -115,6 +115,25 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_WS: dict = {}
+
+
+def _workspace(tag: str, nbytes: int, device: torch.device) -> torch.Tensor:
+    """Scratch memory of a call, cached per (device, stream, purpose) and grown on demand: calls on one stream are
+    ordered, so the next user of the buffer starts after the previous one finished -- no allocator round trip per
+    call (a block makes ~40 of them).  The library itself stays stateless: it is handed the pointer and the size."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WS[key] = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
+    return buf
+
+
+def release_workspaces() -> None:
+    """Drop the cached scratch buffers (they are re-created on demand)."""
+    _WS.clear()
+
+
 def _req(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (vidtome_amd has no CPU path)")
@@ -175,7 +194,7 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
     P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
     Ns, Nd = a_rows.shape[1], b_rows.shape[1]
     nbytes = lib().vtm_match_filtered_ws_bytes(B, C, Ns, Nd, int(align))
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x0.device)
+    ws = _workspace("match", nbytes, x0.device)
     best = torch.empty((1 if align else B, Ns), dtype=torch.int64, device=x0.device)
     flag = torch.zeros((4,), dtype=torch.int32, device=x0.device) if want_flag else None   # any, special, fifo, cap
     _check(lib().vtm_match_filtered(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(a_rows), Ns, _ptr(b_rows),
@@ -197,7 +216,7 @@ def sort_desc(best: torch.Tensor) -> torch.Tensor:
     rows, n = best.shape
     perm = torch.empty((rows, n), dtype=torch.int32, device=best.device)
     nbytes = lib().vtm_sort_ws_bytes(rows, n)
-    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=best.device)
+    ws = _workspace("sort", nbytes, best.device)
     _check(lib().vtm_sort_desc(_ptr(best), rows, n, _ptr(perm), _ptr(ws), nbytes, _stream()), "vtm_sort_desc")
     return perm
 
@@ -296,7 +315,7 @@ def _attention_ws(B: int, heads: int, Mq: int, Mk: int, d: int, device):
     nb = int(lib().vtm_attention_ws_bytes(B, heads, Mq, Mk, d))
     if nb == 0:
         return None, 0
-    return torch.empty(nb, dtype=torch.uint8, device=device), nb
+    return _workspace("attention", nb, device), nb
 
 
 @_on_device

@@ -106,11 +106,16 @@ __device__ __forceinline__ float from_orderable(uint32_t o) {   // 0 (never writ
 }
 
 // ---- operand preparation: canonical row norms + hi / lo fp16 panels [b][g = k/8][row][8], ONE launch ----
-// One thread per gathered row (both operands of the match in the same launch): the canonical k-ascending fmaf chain
-// (the order is part of the bit-exact contract, so it is not tree-reduced -- same bits as row_norms in normalize.hip),
-// then a second walk over the row (L1 / L2-resident) divides, scales, splits and stores the panels: lanes are
-// consecutive rows, so every panel store of a wave is one contiguous 1 KiB segment.  The launch also clears the
-// call's counters and zero-fills `best` (nothing in this kernel reads them: no ordering needed).
+// A wave owns 64 gathered rows (both operands of the match in the same launch), a lane one of them.  The canonical
+// norm is a k-ascending fmaf chain per row (the order is part of the bit-exact contract, so it is not tree-reduced --
+// same bits as row_norms in normalize.hip): serial per lane, but its INPUT need not arrive serially.  The rows are
+// fetched COOPERATIVELY, 80 channels at a time: the wave reads 64 x 160 contiguous bytes as 10 coalesced pieces per
+// lane (one chunk ahead), transposes them through a wave-private LDS slab, and each lane then walks its own row's
+// pieces out of LDS.  A second sweep of the same kind divides, scales, splits and stores the panels (lanes are
+// consecutive rows, so every panel store of a wave is one contiguous 1 KiB segment).  (A lane fetching its own row
+// directly issues 64 different cache lines per load and one dependent batch per 64 channels: 47 us at C = 640 however
+// few rows there are -- r02_b.)  The launch also clears the call's counters and zero-fills `best` (nothing in this
+// kernel reads them: no ordering needed).
 // A row whose norm is not a finite positive number (zero token -> 0/0, merge.py:84 has no eps; inf / NaN inputs) has
 // non-finite xhat components; survivors_kernel recognises it by the stored norm.
 struct SplitArgs {   // one operand: gathered rows, their norms (out), the panel outputs
@@ -121,59 +126,102 @@ struct SplitArgs {   // one operand: gathered rows, their norms (out), the panel
     int64_t n_pad;
 };
 
+constexpr int PREP_PIECES = 10;                        // 16-byte pieces (8 channels) of a row per chunk
+constexpr int PREP_STRIDE = PREP_PIECES * 16 + 16;     // bytes per LDS row: 44 words = 4 x odd -> conflict-free b128
+
 template <typename T>
 __global__ __launch_bounds__(256) void prep_operand(const T *__restrict__ x0, int64_t P0,
                                                     const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
                                                     SplitArgs A0, SplitArgs A1, int64_t C_pad,
                                                     uint32_t *__restrict__ zero, int64_t zero_words,
                                                     unsigned long long *__restrict__ best, int64_t nbest) {
+    static_assert(sizeof(T) == 2 || sizeof(T) == 4, "element size");
+    constexpr int EPP = 16 / (int)sizeof(T);           // elements per 16-byte piece (8 for the 16-bit types, 4 for fp32)
+    __shared__ __attribute__((aligned(16))) char slab[4][64 * PREP_STRIDE];
     const int64_t G = C_pad / 8;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
     for (int64_t w = gid; w < zero_words; w += gsz) zero[w] = 0u;      // amax, cnt, flags
     for (int64_t w = gid; w < nbest; w += gsz) best[w] = 0ull;         // packed results start from "nothing found"
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char *my = slab[wave];
+
+    // this lane's row
     int64_t idx = gid;
     const bool second = idx >= B * A0.n_pad;
     if (second) idx -= B * A0.n_pad;
     const SplitArgs &A = second ? A1 : A0;
     const int64_t n = A.n, n_pad = A.n_pad;
-    if (idx >= B * n_pad) return;
-    const int64_t i = idx % n_pad, b = idx / n_pad;
-    uint4 *__restrict__ out_hi = A.out_hi + (b * G) * n_pad + i;
-    uint4 *__restrict__ out_lo = A.out_lo ? A.out_lo + (b * G) * n_pad + i : nullptr;
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    if (i >= n) {                                                       // padding rows: all-zero operands
-        for (int64_t g = 0; g < G; ++g) {
-            out_hi[g * n_pad] = z;
-            if (out_lo) out_lo[g * n_pad] = z;
+    const bool in_range = idx < B * n_pad;
+    const int64_t i = in_range ? idx % n_pad : 0, b = in_range ? idx / n_pad : 0;
+    const bool real = in_range && i < n;
+    // rows outside the operands / padding rows stream row 0 of x0 (their results are never stored)
+    const T *src = real ? pool_row(x0, P0, x1, P1, b, A.rows[b * n + i], C) : x0;
+
+    const int pieces = (int)(C * sizeof(T) / 16);                      // 16-byte pieces per row
+    const int nchunks = (pieces + PREP_PIECES - 1) / PREP_PIECES;
+    // cooperative fetch of one chunk: piece q = lane + 64 t of the wave's 64 x PREP_PIECES block -> (row q / PP, col q % PP)
+    uint4 stage[PREP_PIECES];
+    auto issue = [&](int chunk) {
+#pragma unroll
+        for (int t = 0; t < PREP_PIECES; ++t) {
+            const int q = lane + 64 * t, r = q / PREP_PIECES, col = q % PREP_PIECES;
+            const T *rp = reinterpret_cast<const T *>(__shfl((unsigned long long)reinterpret_cast<uintptr_t>(src), r, 64));
+            const int piece = chunk * PREP_PIECES + col;
+            stage[t] = piece < pieces ? *reinterpret_cast<const uint4 *>(rp + (int64_t)piece * EPP) : make_uint4(0, 0, 0, 0);
         }
-        return;
-    }
-    const T *src = pool_row(x0, P0, x1, P1, b, A.rows[b * n + i], C);
-    // one thread walks one row twice (a wave keeps only 64 rows in flight): the loads are issued 4 pieces ahead of
-    // the serial chain (8 ahead measured slower: the rows of a wave are 64 different cache lines per load)
-    constexpr int AHEAD = 4;
-    const int64_t CG = C / 8;                      // 8-channel pieces of the row (C % 8 == 0)
+    };
+    auto to_lds = [&]() {
+#pragma unroll
+        for (int t = 0; t < PREP_PIECES; ++t) {
+            const int q = lane + 64 * t, r = q / PREP_PIECES, col = q % PREP_PIECES;
+            *reinterpret_cast<uint4 *>(my + r * PREP_STRIDE + col * 16) = stage[t];
+        }
+    };
+    auto my_piece = [&](int col, float (&f)[EPP]) {                    // this lane's row, piece `col` of the chunk in LDS
+        const uint4 v = *reinterpret_cast<const uint4 *>(my + lane * PREP_STRIDE + col * 16);
+        const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+        for (int k = 0; k < EPP; ++k) f[k] = to_f32(e[k]);
+    };
+
+    // sweep 1: the canonical norm chain
     float acc = 0.0f;
-    for (int64_t g0 = 0; g0 < CG; g0 += AHEAD) {
-        float f[AHEAD][8];
+    issue(0);
+    for (int c = 0; c < nchunks; ++c) {
+        to_lds();                                                       // (LDS is FIFO per wave: no barrier needed)
+        if (c + 1 < nchunks) issue(c + 1);
+        const int valid = min(PREP_PIECES, pieces - c * PREP_PIECES);
+        for (int col = 0; col < valid; ++col) {
+            float f[EPP];
+            my_piece(col, f);
 #pragma unroll
-        for (int u = 0; u < AHEAD; ++u)
-            if (g0 + u < CG) load8(src + (g0 + u) * 8, f[u]);
-#pragma unroll
-        for (int u = 0; u < AHEAD; ++u)
-            if (g0 + u < CG) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(f[u][e], f[u][e], acc);
-            }
+            for (int k = 0; k < EPP; ++k) acc = __builtin_fmaf(f[k], f[k], acc);
+        }
     }
     const float nrm = __builtin_sqrtf(acc);
-    A.norms[b * n + i] = nrm;
-#pragma unroll 2
-    for (int64_t g = 0; g < G; ++g) {
-        uint4 vh = z, vl = z;
-        if (g * 8 < C) {
+    if (real) A.norms[b * n + i] = nrm;
+
+    // sweep 2: xhat = x / norm (IEEE), scaled, split into fp16 hi (+ lo), written as panels
+    uint4 *__restrict__ out_hi = in_range ? A.out_hi + (b * G) * n_pad + i : nullptr;
+    uint4 *__restrict__ out_lo = (in_range && A.out_lo) ? A.out_lo + (b * G) * n_pad + i : nullptr;
+    constexpr int PPG = 8 / EPP;                                        // pieces per 8-channel panel group (1 or 2)
+    issue(0);
+    for (int c = 0; c < nchunks; ++c) {
+        to_lds();
+        if (c + 1 < nchunks) issue(c + 1);
+        const int valid = min(PREP_PIECES, pieces - c * PREP_PIECES);
+        for (int col = 0; col + PPG <= valid; col += PPG) {
             float f[8];
-            load8(src + g * 8, f);
+            if constexpr (PPG == 1) {
+                my_piece(col, f);
+            } else {
+                float f0[EPP], f1[EPP];
+                my_piece(col, f0);
+                my_piece(col + 1, f1);
+#pragma unroll
+                for (int k = 0; k < EPP; ++k) { f[k] = f0[k]; f[EPP + k] = f1[k]; }
+            }
+            uint4 vh, vl;
             _Float16 *ph = reinterpret_cast<_Float16 *>(&vh), *pl = reinterpret_cast<_Float16 *>(&vl);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -182,10 +230,19 @@ __global__ __launch_bounds__(256) void prep_operand(const T *__restrict__ x0, in
                 ph[e] = h;
                 pl[e] = (_Float16)(sc - (float)h);                     // exact difference, rounded once
             }
+            if (!real) vh = vl = make_uint4(0, 0, 0, 0);               // padding rows: all-zero operands
+            const int64_t g = ((int64_t)c * PREP_PIECES + col) / PPG;
+            if (in_range) {
+                out_hi[g * n_pad] = vh;
+                if (out_lo) out_lo[g * n_pad] = vl;
+            }
         }
-        out_hi[g * n_pad] = vh;
-        if (out_lo) out_lo[g * n_pad] = vl;
     }
+    if (in_range)                                                       // channel padding C .. C_pad: zeros
+        for (int64_t g = C / 8; g < G; ++g) {
+            out_hi[g * n_pad] = make_uint4(0, 0, 0, 0);
+            if (out_lo) out_lo[g * n_pad] = make_uint4(0, 0, 0, 0);
+        }
 }
 
 // ---- filter: approximate scores on the fp16 MFMA, candidate collection ----
