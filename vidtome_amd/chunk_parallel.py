@@ -94,6 +94,9 @@ class _Done:
     def wait(self):
         return self.tensor
 
+    def done(self) -> bool:
+        return True
+
 
 class DistTransport:
     """``torch.distributed`` point-to-point + all-gather.  With RCCL the operations run on the communicator's own
@@ -133,6 +136,9 @@ class DistTransport:
 
             def wait(_self):
                 work.wait()
+
+            def done(_self) -> bool:
+                return work.is_completed()
         return _Send()
 
     def irecv(self, shape, dtype, device, src: int):
@@ -379,6 +385,8 @@ class AnchorExchange:
         work = self.t.isend(tensor, dst)
         self._inflight.append((work, tensor))
         self.bytes_sent += tensor.numel() * tensor.element_size()
+        if len(self._inflight) > 64:                       # long steps: let finished transfers (and their buffers) go
+            self._inflight = [(w, t) for w, t in self._inflight if not getattr(w, "done", lambda: True)()]
 
 
 class RingExchange(AnchorExchange):
