@@ -129,9 +129,99 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_kernel(const T
     }
 }
 
+// sum over aligned groups of LPR lanes (8, 16 or 32): the first log2(LPR) steps of wave_sum's butterfly
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    if constexpr (LPR >= 16)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    if constexpr (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+// The SD channel counts (C = 40 LPR, LPR = 8 / 16 / 32 for 320 / 640 / 1280): LPR lanes per row, every lane 5 pieces of
+// 16 bytes at a stride of LPR pieces -- all 64 lanes busy (a wave per 320-channel row keeps 24 of them idle), a load
+// instruction covers 64 / LPR rows with 16 LPR contiguous bytes each, and a wave keeps R * 64 / LPR rows in flight.
+template <typename T, int LPR, int R>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_rows_kernel(const T *__restrict__ x, const T *__restrict__ gamma,
+                                                                              const T *__restrict__ beta, int64_t rows, float eps,
+                                                                              T *__restrict__ out) {
+    constexpr int NCH = 5, C = 8 * NCH * LPR, RPW = 64 / LPR;   // pieces per lane, channels, rows per wave and round
+    const int lane = threadIdx.x & 63, g = lane % LPR, sub = lane / LPR;
+    const int64_t row0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * (RPW * R) + sub;
+    float v[R][NCH][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t row = row0 + (int64_t)r * RPW;
+        if (row >= rows) row = rows - 1;                        // surplus rows recompute the last one, unstored
+        const T *xr = x + row * C;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) load8(xr + (g + LPR * i) * 8, v[r][i]);
+    }
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[r][i][j];
+        mean[r] = group_sum<LPR>(s) / (float)C;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[r][i][j] - mean[r];
+                q = __builtin_fmaf(d, d, q);
+            }
+        rstd[r] = 1.0f / sqrtf(group_sum<LPR>(q) / (float)C + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = g + LPR * i;
+        float gm[8], bt[8];
+        if (gamma) load8(gamma + c * 8, gm);
+        if (beta) load8(beta + c * 8, bt);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row0 + (int64_t)r * RPW;
+            if (row < rows) {
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float n = (v[r][i][j] - mean[r]) * rstd[r];
+                    y[j] = gamma ? (beta ? __builtin_fmaf(n, gm[j], bt[j]) : n * gm[j]) : (beta ? n + bt[j] : n);
+                }
+                store8(out + row * C + c * 8, y);
+            }
+        }
+    }
+}
+
 template <typename T>
 void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_t rows, int64_t C, float eps, void *out,
                       hipStream_t s) {
+#ifndef VTM_OLD_LN   // (A/B build switch)
+    // measured (profiles/r02_sweeps.txt): +24 % HBM rate at C = 320 beyond the Infinity Cache; no gain at 640 / 1280, where a
+    // wave per row already uses all its lanes -- those keep the kernel above
+    if (C == 320) {
+        constexpr int R = 2;
+        const int lpr = (int)(C / 40);
+        const dim3 g((unsigned)vtm::cdiv(rows, (int64_t)WAVES_PER_BLOCK * (64 / lpr) * R)), b(WAVES_PER_BLOCK * 64);
+#define VTM_LNR(LPR)                                                                                                   \
+    hipLaunchKernelGGL((layernorm_rows_kernel<T, LPR, R>), g, b, 0, s, (const T *)x, (const T *)gamma, (const T *)beta, rows, \
+                       eps, (T *)out)
+        if (lpr == 8) VTM_LNR(8); else if (lpr == 16) VTM_LNR(16); else VTM_LNR(32);
+#undef VTM_LNR
+        return;
+    }
+#endif
     const int nch = (int)vtm::cdiv(C, 512);
     const int R = nch == 1 ? 4 : 2;
     const dim3 grid((unsigned)vtm::cdiv(rows, (int64_t)WAVES_PER_BLOCK * R)), block(WAVES_PER_BLOCK * 64);
