@@ -21,4 +21,9 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc -o ${ctr}_attn --output-format csv -- python $R/tools/kbench.py attn --Mq 34816 --M 52224 --d 40 --iters 3 > $O/pmc_${ctr}_attn.log 2>&1
   rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc -o ${ctr}_match --output-format csv -- python $R/tools/kbench.py match --shape top_l1 --iters 3 > $O/pmc_${ctr}_match.log 2>&1
 done
+for what in gather unmerge layernorm; do
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc -o ${ctr}_$what --output-format csv -- python $R/tools/kbench.py $what --B 4 --n 147456 --iters 3 > $O/pmc_${ctr}_$what.log 2>&1
+  done
+done
 ls $O/pmc | wc -l
