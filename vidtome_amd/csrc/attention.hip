@@ -606,11 +606,6 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     if (tb < fe) issue_full(); else issue_tail((int64_t)tb * KV);
     write_lds(0);
     __syncthreads();
-#ifdef VTM_ATT_PRIO
-    // static priority for the second-dispatched half of an 8-wave workgroup (it loses VALU arbitration to the older
-    // half on every phase otherwise): one s_setprio before the loop, no flips inside
-    if (WAVES == 8 && __builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
-#endif
 
     // hot loop: full tiles whose successor is full too -- no bounds logic of any kind inside
     int t = tb;
