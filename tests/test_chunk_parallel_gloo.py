@@ -217,3 +217,38 @@ def test_simulated_draws_match_compute_merge(oracle):
                 assert sim["M_local"] == merged.shape[1]
             elif m_local is not None:
                 assert sim["M_local"] == m_local
+
+
+def test_long_stream_releases_finished_sends(oracle):
+    """bench.py runs its whole N > 1 measurement as ONE step of many chunks: the exchange must not keep every sent tensor
+    alive until the end of it (finished transfers are dropped once more than 64 are on the books)."""
+    from vidtome_amd import chunk_parallel as cp
+    frames = [2] * 80
+    tpf = HW[0] * HW[1]
+    fabric = cp.LocalTransport.fabric(2)
+    exs = [cp.AnchorExchange("neighbour", transport=t) for t in fabric]
+    mods = [[_Module(_fork()) for _ in range(NBLK)] for _ in range(2)]
+    for ex in exs:
+        ex.begin_step(frames)
+    for i, F in enumerate(frames):
+        ex, r = exs[i % 2], i % 2
+        ex.begin_chunk(i)
+        for blk in range(NBLK):
+            key, mod = f"b{blk}", mods[r][blk]
+            h = _hidden(0, i % 5, blk, F)
+            like = torch.from_numpy(h).reshape(B, F * tpf, C)
+            ex.begin_block(mod, key, F, tpf, ARGS, like)
+            local = _local_tokens(oracle, h, mod.generator)
+
+            class State(dict):
+                def get(self, k, d=None):
+                    got = ex.anchors_for(key, lambda: torch.from_numpy(local), like)
+                    return None if got is None else got.numpy()
+            state = State()
+            oracle.compute_merge(h, HW, ARGS, oracle.RandomDraws.from_torch_generator(mod.generator), state)
+            ex.publish(key, torch.from_numpy(np.ascontiguousarray(state["global_tokens"])))
+        assert len(ex._inflight) <= 65
+    for ex in exs:
+        ex.end_step()
+        assert not ex._inflight
+    assert torch.equal(mods[0][0].generator.get_state(), mods[1][0].generator.get_state())
