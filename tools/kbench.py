@@ -4,6 +4,7 @@
     python tools/kbench.py match  [--shape top_l1|top_l2|top_g|mid_l1] [--iters 5]
     python tools/kbench.py attn   [--M 52224 --d 40 --heads 8 --B 2] [--iters 3]
     python tools/kbench.py sort   [--n 49152]
+    python tools/kbench.py sites  --shape cfg2|cfg3|cfg4|cfg5            (a hot-path pass at the other BASELINE configurations)
     python tools/kbench.py gather|unmerge|layernorm [--B 4 --n 147456 --C 320]   (HBM-bound kernels beyond the MALL)
 """
 import argparse
@@ -130,6 +131,27 @@ def main():
             med, best = timeit(lambda: [fn() for _ in range(REP)], a.iters)
             med, best = med / REP, best / REP
             print(f"linear {name} B={B} M={M} Mq={Mq} C={C}: median {med * 1e3:.1f} us ({fl / med / 1e9:.1f} TFLOP/s), best {best * 1e3:.1f} us")
+    elif a.what == "sites":
+        # one hot-path pass over all 16 block sites for the BASELINE.json configurations other than the bench's cfg-2
+        # (steady state: anchors populated by a preceding chunk): ms per chunk-step
+        import vidtome_amd
+        from vidtome_amd import sites
+        cfgs = {"cfg2": (sites.sd15_sites(), 2, 16, (64, 64), 0.5, 0.5, False),
+                "cfg3": (sites.sd15_sites(), 3, 16, (64, 64), 0.5, 0.5, True),       # PnP batch 3, align_batch
+                "cfg4": (sites.sd15_sites(), 2, 8, (64, 64), 0.5, 0.5, False),        # one of the 8 chunks of 8 frames
+                "cfg5": (sites.sd21_sites(), 2, 16, (96, 96), 0.6, 0.6, False)}       # SD-2.1-768, ratio 0.6
+        sl, Bc, Fc, latent, lr, gr, align = cfgs[a.shape]
+        unet = sites.SiteUNet(sl, seed=0).to(device=dev, dtype=torch.float16)
+        vidtome_amd.apply_patch(unet, local_merge_ratio=lr, merge_global=True, global_merge_ratio=gr, batch_size=Bc,
+                                align_batch=align)
+        unet.set_size(latent)
+        torch.manual_seed(123)
+        hs = [sites.synthetic_hidden(s_, Bc, Fc, latent, torch.float16, dev, seed=1234 + i) for i, s_ in enumerate(sl)]
+        with torch.no_grad():
+            sites.run_segment_pass(unet, hs)
+            med, best = timeit(lambda: sites.run_segment_pass(unet, hs), a.iters)
+        print(f"sites {a.shape}: B={Bc} F={Fc} latent={latent} local={lr} global={gr} align={align}: median {med:.2f} ms per "
+              f"chunk-step ({1e3 / med:.2f} steps/s), best {best:.2f} ms")
     else:
         raise SystemExit("unknown benchmark")
 
