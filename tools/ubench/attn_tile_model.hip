@@ -1,0 +1,181 @@
+// Micro-benchmark: the INSTRUCTION MIX of attention_kernel<half,40>'s tile (per wave and 64 keys: 6 x v_mfma_f32_32x32x16_f16 in two
+// dependent chains of 3, 32 v_exp_f32, 16 v_cvt_pk_f16_f32, 8 v_pk_maximum3_f16 + compare, 8 v_permlane16_swap, 12 x
+// v_mfma_f32_16x16x32_f16) with every operand in registers -- no LDS, no global memory, no barrier.  What it takes per tile on a SIMD
+// shared by 4 waves is the floor the real kernel can approach by scheduling alone; the difference to the kernel is what LDS latency,
+// the per-tile barrier and the staging cost.
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 tools/ubench/attn_tile_model.hip -o tools/ubench/attn_tile_model
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t pmax3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// MODE 0: the kernel's order (QK^T, exps, check, PV).  MODE 1: no exps (v_mov instead).  MODE 2: no MFMAs at all (VALU only).
+// MODE 3: the PV MFMAs only (the unused QK^T is eliminated).  MODE 4: as 0 with PV from 32-row blocks (8 x 32x32x16, no swaps).
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void tile_model(float *out, int iters, float seed) {
+    h16x8 q[3], kf[2][3], vf[2][3];
+    for (int i = 0; i < 3; ++i)
+        for (int e = 0; e < 8; ++e) {
+            q[i][e] = (_Float16)(seed * 0.01f + 0.001f * e);
+            for (int b = 0; b < 2; ++b) {
+                kf[b][i][e] = (_Float16)(seed * 0.02f + 0.001f * (e + b));
+                vf[b][i][e] = (_Float16)(seed * 0.03f + 0.002f * (e + b));
+            }
+        }
+    f32x4 o[3][2];
+    for (int d = 0; d < 3; ++d)
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 4; ++e) o[d][h][e] = 0.0f;
+    f32x16 o32[2];
+    for (int d = 0; d < 2; ++d)
+        for (int r = 0; r < 16; ++r) o32[d][r] = 0.0f;
+    uint32_t flag = 0;
+    f32x16 s_next[2];
+    for (int kb = 0; kb < 2; ++kb)
+        for (int r = 0; r < 16; ++r) s_next[kb][r] = seed;
+    for (int it = 0; it < iters; ++it) {
+        // keep the loop body from being hoisted: the K fragments "change" every tile
+        asm volatile("" : "+v"(kf[0][0]), "+v"(kf[1][0]));
+        f32x16 s[2];
+        if constexpr (MODE == 5) {
+            // software pipeline: this iteration's scores were computed LAST iteration; issue the next tile's QK^T now, so
+            // that its MFMAs run beside this tile's exps (independent work inside ONE wave)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) s[kb] = s_next[kb];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_next[kb][r] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) s_next[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], q[ks], s_next[kb], 0, 0, 0);
+            }
+        } else if constexpr (MODE != 2) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], q[ks], s[kb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = seed * 1e-3f * (r + it);
+            asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+        }
+        h16x8 pf[4];
+        if constexpr (MODE != 3) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sv = s[st >> 1][8 * (st & 1) + e];
+                    float p;
+                    if constexpr (MODE == 1) asm volatile("v_mov_b32 %0, %1" : "=v"(p) : "v"(sv));
+                    else p = __builtin_amdgcn_exp2f(sv);
+                    pf[st][e] = (_Float16)p;
+                }
+            uint32_t pw[16];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const u32x4 w = __builtin_bit_cast(u32x4, pf[st]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pw[4 * st + j] = w[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) pw[j] = pmax3(pw[3 * j], pw[3 * j + 1], pw[3 * j + 2]);
+            const uint32_t pr = pmax3(pmax3(pw[0], pw[1], pw[2]), pmax3(pw[3], pw[4], pw[15]), pw[15]);
+            flag |= (max(pr >> 16, pr & 0xffffu) > 0x5C00u) ? 1u : 0u;
+        } else {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) pf[st] = q[st % 3];
+        }
+        if constexpr (MODE == 4) {   // PV from 32-row blocks: 2 blocks x 4 k-steps of 16 keys, P straight from the packing
+#pragma unroll
+            for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) o32[dv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dv][st % 3], pf[st], o32[dv], 0, 0, 0);
+        } else
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 x = __builtin_bit_cast(u32x4, pf[2 * ks]), y = __builtin_bit_cast(u32x4, pf[2 * ks + 1]);
+            if constexpr (MODE != 3) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(x[w], y[w], false, false);
+                    x[w] = r[0];
+                    y[w] = r[1];
+                }
+            }
+            const h16x8 p0 = __builtin_bit_cast(h16x8, x), p1 = __builtin_bit_cast(h16x8, y);
+            if constexpr (MODE != 2) {
+#pragma unroll
+                for (int dv = 0; dv < 3; ++dv) {
+                    o[dv][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[ks][dv], p0, o[dv][0], 0, 0, 0);
+                    o[dv][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[ks][dv], p1, o[dv][1], 0, 0, 0);
+                }
+            } else {
+                o[0][0][0] += (float)p0[0] + (float)p1[0];
+            }
+        }
+    }
+    float acc = (float)flag;
+    for (int d = 0; d < 2; ++d)
+        for (int r = 0; r < 16; ++r) acc += o32[d][r];
+    for (int d = 0; d < 3; ++d)
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 4; ++e) acc += o[d][h][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int MODE, int NT>
+void run(const char *name, int wgs_per_cu) {
+    const int cus = 256, iters = 4000;
+    float *out;
+    (void)hipMalloc(&out, sizeof(float) * cus * wgs_per_cu * NT);
+    dim3 grid(cus * wgs_per_cu), block(NT);   // NT / 256 waves of a workgroup per SIMD
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((tile_model<MODE, NT>), grid, block, 0, 0, out, 10, 1.0f);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((tile_model<MODE, NT>), grid, block, 0, 0, out, iters, 1.0f);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const int wps = NT / 256 * wgs_per_cu;
+    const double ns = ms * 1e6 / ((double)iters * wps);   // per tile-wave one SIMD executed
+    printf("%-48s %d waves/SIMD: %.3f ms -> %.1f ns per tile-wave per SIMD (= %.0f cycles @2.4 GHz; matrix pipe alone: 384)\n", name,
+           wps, ms, ns, ns * 2.4);
+    (void)hipFree(out);
+}
+
+int main() {
+    for (int w : {1, 2}) {
+        run<0, 512>("kernel mix (QK^T, exp, check, PV16)", w);
+        run<1, 512>("same without the exps (v_mov)", w);
+        run<2, 512>("VALU part only", w);
+        run<3, 512>("PV MFMAs only (12 x 16x16x32)", w);
+        run<4, 512>("PV from 32-row blocks (8 x 32x32x16, no swaps)", w);
+        run<5, 512>("software-pipelined (QK^T of t+1 beside exps of t)", w);
+    }
+    run<0, 768>("kernel mix, 12-wave workgroup", 1);
+    run<5, 768>("software-pipelined, 12-wave workgroup", 1);
+    run<5, 256>("software-pipelined, 4-wave workgroup", 1);
+    run<5, 256>("software-pipelined, 4-wave workgroups", 3);
+    return 0;
+}
