@@ -95,6 +95,19 @@ __device__ __forceinline__ void load8(const T *src, float (&f)[8]) {
     }
 }
 
+// max of three without the canonicalising v_max x, x the compiler puts in front of fmaxf on values it cannot prove
+// quiet (every MFMA result): a NaN operand is ignored, like fmaxf
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 __device__ __forceinline__ uint32_t orderable(float f) {
     if (f != f) return 0xffffffffu;
     const uint32_t u = __float_as_uint(f + 0.0f);
@@ -379,175 +392,331 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         }
     }
 
-    load_a_half(jt0, 0, 0, 0);
-    load_a_half(jt0, 0, 0, 1);
-    load_b(0, 0, rb[0]);
-    load_b(0, 1, rb[1]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // dst tile finished: every score within the window of the lane's running max becomes a candidate
+    // The other dst splits of a row (other workgroups) and the lane holding the row's other 64 dst rows of every tile
+    // work on the same maximum: each lane publishes its running maximum in amax[row] whenever a tile raised it and picks
+    // up the row's published maximum (fetched two groups earlier, see the loop) before it looks at a tile.  Any published
+    // value is an approximate score of the row, hence a valid running maximum; starting every split from -inf instead
+    // would multiply the record-breaking tiles (8 splits: 71 % of the blocks trigger the candidate path, shared: 25 %).
+    uint32_t am[2] = {0u, 0u};
+    auto collect_tile = [&](int jt, auto share_tag) {
+        constexpr bool SHARE = decltype(share_tag)::value;
+        const int dst0 = jt * FBD + 4 * kh;
+        const bool full = (int64_t)(jt + 1) * FBD <= Nd;
+        if constexpr (SHARE)   // the two amax loads of this step: g2's and g3's 6 operations are younger
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(am[0]), "+v"(am[1]) : "n"(2 * NB + PG));
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            float rm = runmax[sb];
+            if constexpr (SHARE) rm = fmaxf(rm, from_orderable(am[sb]) * (SCALE * SCALE));
+            const float rm_in = rm;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                if (!full) {   // the last tile of the dst range: rows beyond Nd never match
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (dst0 + ib * 32 + (r & 3) + 8 * (r >> 2) >= Nd) acc[ib][sb][r] = -INFINITY;
+                }
+                // The block's 16 scores of this lane, as 4 quarters of 4 (quarter k = dst rows 8 k + 0..3).
+                // Everything within the window of the running maximum AFTER this block becomes a candidate
+                // (a running maximum is never above the final one, so this collects a superset of what the
+                // final maximum requires).  Almost always that is nothing, or exactly the block's maximum:
+                // that case is handled without a loop -- locate the maximum by compare/select, check that the
+                // second largest score stays outside the window, insert.  Ties and near-ties inside one block
+                // (rare) take the element-by-element path below.
+                const f32x16 &v = acc[ib][sb];
+                float q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = vmax2(vmax3(v[4 * k], v[4 * k + 1], v[4 * k + 2]), v[4 * k + 3]);
+                const float gm = vmax2(vmax3(q[0], q[1], q[2]), q[3]);
+                const float newmax = fmaxf(rm, gm);
+                const float thr = newmax - WS;
+                const bool trig = gm >= thr && gm > -INFINITY;   // NaN / masked blocks never pass
+                if (__any(trig)) {
+                    // quarter and element of the (first) maximum
+                    const bool c0 = q[0] == gm, c1 = q[1] == gm, c2 = q[2] == gm;
+                    float w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = c0 ? v[j] : c1 ? v[4 + j] : c2 ? v[8 + j] : v[12 + j];
+                    const int kq = c0 ? 0 : c1 ? 1 : c2 ? 2 : 3;
+                    const bool d0 = w[0] == gm, d1 = w[1] == gm, d2 = w[2] == gm;
+                    const int eq = d0 ? 0 : d1 ? 1 : d2 ? 2 : 3;
+                    // largest score of the block apart from that element
+                    const float qo = fmaxf(fmaxf(fmaxf(c0 ? -INFINITY : q[0], (!c0 && c1) ? -INFINITY : q[1]),
+                                                 (!c0 && !c1 && c2) ? -INFINITY : q[2]),
+                                           (c0 || c1 || c2) ? q[3] : -INFINITY);
+                    const float wo = fmaxf(fmaxf(fmaxf(d0 ? -INFINITY : w[0], (!d0 && d1) ? -INFINITY : w[1]),
+                                                 (!d0 && !d1 && d2) ? -INFINITY : w[2]),
+                                           (d0 || d1 || d2) ? w[3] : -INFINITY);
+                    const float second = fmaxf(qo, wo);
+                    if (!__any(trig && second >= thr)) {
+                        if (trig) {
+                            if (cv[sb][3] >= thr)   // evicted entry still inside the window: spill it
+                                push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3]);
+                            cv[sb][3] = cv[sb][2]; ci[sb][3] = ci[sb][2];
+                            cv[sb][2] = cv[sb][1]; ci[sb][2] = ci[sb][1];
+                            cv[sb][1] = cv[sb][0]; ci[sb][1] = ci[sb][0];
+                            cv[sb][0] = gm;
+                            ci[sb][0] = (uint32_t)(dst0 + ib * 32 + eq + 8 * kq);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float x = v[r];
+                            if (x >= rm - WS && x > -INFINITY) {
+                                const float nrm_ = fmaxf(rm, x);
+                                if (cv[sb][3] >= nrm_ - WS) push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3]);
+                                cv[sb][3] = cv[sb][2]; ci[sb][3] = ci[sb][2];
+                                cv[sb][2] = cv[sb][1]; ci[sb][2] = ci[sb][1];
+                                cv[sb][1] = cv[sb][0]; ci[sb][1] = ci[sb][0];
+                                cv[sb][0] = x;
+                                ci[sb][0] = (uint32_t)(dst0 + ib * 32 + (r & 3) + 8 * (r >> 2));
+                                rm = nrm_;
+                            }
+                        }
+                    }
+                }
+                rm = fmaxf(rm, gm);
+            }
+            runmax[sb] = rm;
+            if constexpr (SHARE) {
+                if (rm > rm_in && rm < INFINITY) atomicMax(&amax[out_row0 + srow0 + sb * 32 + l31], orderable(rm * INV_S2));
+            }
+        }
+    };
 
+#if VTM_FILTER_PRODUCTS > 1 || defined(VTM_FILTER_PHASED)
+    {   // the 2- / 3-product variants (and the A/B switch): load phase, then 8-16 MFMAs, per group
+        load_a_half(jt0, 0, 0, 0);
+        load_a_half(jt0, 0, 0, 1);
+        load_b(0, 0, rb[0]);
+        load_b(0, 1, rb[1]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        int kt = 0, jt = jt0;
+        for (int st = 0; st < steps; ++st) {
+            const int buf = st & 1;
+            const bool wrap = kt + 1 == KT;
+            const int ktn = wrap ? 0 : kt + 1, jtn = wrap ? jt + 1 : jt;
+            // the last step prefetches too (its own operands again, never used), so that the issue sequence -- and
+            // with it every wait count -- is the same in all steps
+            const bool more = st + 1 < steps;
+            const int ktp = more ? ktn : kt, jtp = more ? jtn : jt;
+            // A fragments (dst rows) come from LDS one half-group ahead: the hi halves of group s + 1 are read while
+            // the lo products of group s run, the lo halves of group s while its hi products run -- every read has
+            // 8 MFMAs (256 cycles) to land, in the registers the previous fragments just vacated
+            auto read_a = [&](int which, int s_, h16x8 (&f)[4]) {
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+                    f[ib] = __builtin_bit_cast(h16x8, sA[buf][which][(s_ * 2 + kh) * FBD + ib * 32 + l31]);
+            };
+            h16x8 fa[2][4], fl[4];
+            read_a(0, 0, fa[0]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < 2) load_b(kt, s + 2, rb[s + 2]);
+                else load_b(ktp, s - 2, rb[s - 2]);
+#ifndef VTM_EXP_NODMA
+                if (s < 2) load_a_half(jtp, ktp, buf ^ 1, s);
+#endif
+                // operations issued after B(s): see the table above
+#ifdef VTM_EXP_NOAWAIT
+                await_b(std::integral_constant<int, 63>{}, rb[s]);
+#else
+                if (s == 0 || s == 3) await_b(std::integral_constant<int, 2 * NB + PG>{}, rb[s]);
+                else await_b(std::integral_constant<int, 2 * NB + 2 * PG>{}, rb[s]);
+#endif
+                if constexpr (DST_LO) read_a(1, s, fl);
+                else if (s < 3) read_a(0, s + 1, fa[(s + 1) & 1]);   // one group ahead, alternating register sets
+                __builtin_amdgcn_sched_barrier(0);
+                h16x8 (&fh)[4] = fa[DST_LO ? 0 : (s & 1)];
+                auto hi_products = [&](auto first_tag) {
+                    constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) {
+                        const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s][sb][0]);
+                        const h16x8 blf = __builtin_bit_cast(h16x8, rb[s][sb][1]);
+#pragma unroll
+                        for (int ib = 0; ib < 4; ++ib) {
+                            f32x16 c = acc[ib][sb];
+                            if constexpr (FIRST) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) c[r] = 0.0f;   // folds into the MFMA's zero C operand
+                            }
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], bhf, c, 0, 0, 0);
+                            if constexpr (SRC_LO) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], blf, c, 0, 0, 0);
+                            acc[ib][sb] = c;
+                        }
+                    }
+                };
+                if (s == 0 && kt == 0) hi_products(std::true_type{});
+                else hi_products(std::false_type{});
+                if constexpr (DST_LO) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s < 3) read_a(0, s + 1, fa[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) {
+                        const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s][sb][0]);
+#pragma unroll
+                        for (int ib = 0; ib < 4; ++ib)
+                            acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ib], bhf, acc[ib][sb], 0, 0, 0);
+                    }
+                }
+            }
+#ifdef VTM_EXP_NOWRAP
+            if (wrap && jt < 0) collect_tile(jt, std::false_type{});
+#else
+            if (wrap) collect_tile(jt, std::false_type{});
+#endif
+            // every wave's DMA pieces of the next tile must have landed before anybody reads them; they are older
+            // than the 2 NB loads of groups 2 and 3
+#ifndef VTM_EXP_NOBARRIER
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
+            __syncthreads();
+#endif
+            kt = ktn;
+            jt = jtn;
+        }
+    }
+#else
+    // ---- shipped loop (one product): every load / LDS read / DMA piece rides BETWEEN two MFMAs ----------------------
+    // A wave that issues its ~25 memory instructions of a group in one clump leaves the matrix pipe without work for
+    // 100+ cycles each time (the pipe holds one MFMA, not a queue), and the SIMD's other wave is in its own clump a
+    // third of the time.  Here the issue order is pinned instruction by instruction (sched_barrier around each): after
+    // MFMA j of group s comes ONE of -- j < 4: the LDS read of fragment j of group s + 1 (group 3: of the NEXT step's
+    // group 0, out of the other buffer); j = 4, 5: the two B loads of group s + 2; j = 6, 7: a DMA piece (groups 0 and
+    // 3 only).  The per-step barrier sits at the end of group 2: by then every wave has read the last fragments of this
+    // step's tile (so group 3 may start overwriting it with the tile after next) and the next tile has had two groups
+    // to land (its first half is issued in group 3 of the previous step, its second in group 0).
+    // Group 1's last two slots fetch the row maxima the other splits have published (X; used at the end of a tile).
+    // Vector-memory issue order of a step:  g0: B(2) x2, D x2 | g1: B(3) x2, X x2 | g2: B(0') x2 | g3: B(1') x2, D x2
+    // hence the counts at the START of a group (operations issued after the awaited one):
+    //     g0 awaits B(0): 2 + 2     g1 awaits B(1): 2 + 2 + 2     g2 awaits B(2): 2 + 2 + 2     g3 awaits B(3): 2 + 2
+    // the barrier (after g2's own loads) needs g0's pieces: 2 + 2 + 2 younger loads, and the tile end needs X: 2 + 2 + 2.
+    static_assert(NB == 2 && PG == 2, "the schedule below is written for the one-product filter");
+    // Addresses are running wave-uniform byte pointers advanced with scalar adds (nothing is recomputed from (kt, jt)):
+    //   B fragments of k-step group ks of step kt:   pb + ks * kstep_b   (sb = 1: + 512 through the offset field)
+    //   DMA piece t of the wave (panel 2 wave + t / 2, row half t & 1) of a dst tile: pa + (t / 2) * panel_b + (t & 1) * 1024,
+    //   into LDS at lds_a + buffer * 16 KiB + t * 1024
+    const char *const src_b = reinterpret_cast<const char *>(srch);
+    const int64_t kstep_b = bgroup * 16;                         // bytes per k-step group (2 panels of Ns_pad rows)
+    const int64_t panel_b = Nd_pad * 16;                         // bytes per dst panel
+    const int64_t tile_dk = 8 * panel_b;                         // next channel step of the same dst tile
+    const int64_t tile_dwrap = FBD * 16 - (int64_t)(KT - 1) * tile_dk;   // first channel step of the next dst tile
+    const uint32_t lds_a = (uint32_t)reinterpret_cast<uintptr_t>((lds_void *)&sA[0][0][wave * 2 * FBD]);
+    auto load_b1 = [&](const char *pb_, int ks, int sb, u32x4 &dst) {
+        const char *ph = pb_ + ks * kstep_b;   // uniform
+        if (sb == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_b), "s"(ph));
+        else asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(dst) : "v"(voff_b), "s"(ph));
+    };
+    auto load_a_piece = [&](const char *pa_, int buf_, int t) {
+        const char *g = pa_ + (t >> 1) * panel_b + (t & 1) * 1024;
+        const uint32_t lds_off = lds_a + (uint32_t)buf_ * (uint32_t)sizeof(sA[0]) + (uint32_t)t * 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_off), "v"(voff_a), "s"(g) : "memory");
+    };
+    const unsigned int *const amax_rows = amax + out_row0;
+    uint32_t voff_m[2];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) voff_m[sb] = (uint32_t)min(srow0 + sb * 32 + l31, Ns - 1) * 4u;   // padding rows: any valid row
+    h16x8 fa[2][4];
+    const char *pa1 = reinterpret_cast<const char *>(dsth + (int64_t)wave * 2 * Nd_pad + (int64_t)jt0 * FBD);   // tile of step 0
+    const char *pb = src_b;
+    {
+        load_a_piece(pa1, 0, 0);
+        load_a_piece(pa1, 0, 1);
+        load_a_piece(pa1, 0, 2);
+        load_a_piece(pa1, 0, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (steps > 1) pa1 += KT == 1 ? tile_dwrap : tile_dk;   // tile of step 1
+        load_b1(pb, 0, 0, rb[0][0][0]);
+        load_b1(pb, 0, 1, rb[0][1][0]);
+        load_b1(pb, 1, 0, rb[1][0][0]);
+        load_b1(pb, 1, 1, rb[1][1][0]);
+        load_a_piece(pa1, 1, 0);   // what group 3 of a previous step would have issued
+        load_a_piece(pa1, 1, 1);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) fa[0][ib] = __builtin_bit_cast(h16x8, sA[0][0][kh * FBD + ib * 32 + l31]);
+    }
     int kt = 0, jt = jt0;
     for (int st = 0; st < steps; ++st) {
         const int buf = st & 1;
         const bool wrap = kt + 1 == KT;
-        const int ktn = wrap ? 0 : kt + 1, jtn = wrap ? jt + 1 : jt;
-        // the last step prefetches too (its own operands again, never used), so that the issue sequence -- and
-        // with it every wait count -- is the same in all steps
-        const bool more = st + 1 < steps;
-        const int ktp = more ? ktn : kt, jtp = more ? jtn : jt;
-        // A fragments (dst rows) come from LDS one half-group ahead: the hi halves of group s + 1 are read while
-        // the lo products of group s run, the lo halves of group s while its hi products run -- every read has
-        // 8 MFMAs (256 cycles) to land, in the registers the previous fragments just vacated
-        auto read_a = [&](int which, int s_, h16x8 (&f)[4]) {
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib)
-                f[ib] = __builtin_bit_cast(h16x8, sA[buf][which][(s_ * 2 + kh) * FBD + ib * 32 + l31]);
-        };
-        h16x8 fa[2][4], fl[4];
-        read_a(0, 0, fa[0]);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < 2) load_b(kt, s + 2, rb[s + 2]);
-            else load_b(ktp, s - 2, rb[s - 2]);
-#ifndef VTM_EXP_NODMA
-            if (s < 2) load_a_half(jtp, ktp, buf ^ 1, s);
-#endif
-            // operations issued after B(s): see the table above
+        // the last steps prefetch too (valid addresses, never used), so that the issue sequence -- and with it every
+        // wait count -- is the same in all steps
+        const int kt1 = wrap ? 0 : kt + 1;                        // channel step of step st + 1 (if there is one)
+        const bool wrap1 = kt1 + 1 == KT;
+        const char *const pbn = st + 1 < steps ? (wrap ? src_b : pb + 4 * kstep_b) : pb;
+        const char *const pa2 = st + 2 < steps ? pa1 + (wrap1 ? tile_dwrap : tile_dk) : pa1;   // tile of step st + 2
+        auto group = [&](auto s_tag, auto first_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;
+            constexpr int COUNT = s == 1 ? NB + 2 * PG : s == 2 ? NB + PG + 2 : NB + 2;
+            if constexpr (s != 0) {   // group 0's wait precedes the branch on kt (below)
 #ifdef VTM_EXP_NOAWAIT
-            await_b(std::integral_constant<int, 63>{}, rb[s]);
+                await_b(std::integral_constant<int, 63>{}, rb[s]);
 #else
-            if (s == 0 || s == 3) await_b(std::integral_constant<int, 2 * NB + PG>{}, rb[s]);
-            else await_b(std::integral_constant<int, 2 * NB + 2 * PG>{}, rb[s]);
+                await_b(std::integral_constant<int, COUNT>{}, rb[s]);
 #endif
-            if constexpr (DST_LO) read_a(1, s, fl);
-            else if (s < 3) read_a(0, s + 1, fa[(s + 1) & 1]);   // one group ahead, alternating register sets
-            __builtin_amdgcn_sched_barrier(0);
-            h16x8 (&fh)[4] = fa[DST_LO ? 0 : (s & 1)];
-            auto hi_products = [&](auto first_tag) {
-                constexpr bool FIRST = decltype(first_tag)::value;
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb) {
-                    const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s][sb][0]);
-                    const h16x8 blf = __builtin_bit_cast(h16x8, rb[s][sb][1]);
-#pragma unroll
-                    for (int ib = 0; ib < 4; ++ib) {
-                        f32x16 c = acc[ib][sb];
-                        if constexpr (FIRST) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) c[r] = 0.0f;   // folds into the MFMA's zero C operand
-                        }
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], bhf, c, 0, 0, 0);
-                        if constexpr (SRC_LO) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], blf, c, 0, 0, 0);
-                        acc[ib][sb] = c;
-                    }
-                }
-            };
-            if (s == 0 && kt == 0) hi_products(std::true_type{});
-            else hi_products(std::false_type{});
-            if constexpr (DST_LO) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (s < 3) read_a(0, s + 1, fa[0]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb) {
-                    const h16x8 bhf = __builtin_bit_cast(h16x8, rb[s][sb][0]);
-#pragma unroll
-                    for (int ib = 0; ib < 4; ++ib)
-                        acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ib], bhf, acc[ib][sb], 0, 0, 0);
-                }
             }
-        }
-#ifdef VTM_EXP_NOWRAP
-        if (wrap && jt < 0) {
+            h16x8 (&fh)[4] = fa[s & 1];
+            h16x8 (&fn)[4] = fa[(s + 1) & 1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int sb = j >> 2, ib = j & 3;
+                f32x16 c = acc[ib][sb];
+                if constexpr (FIRST) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = 0.0f;   // folds into the MFMA's zero C operand
+                }
+                acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], __builtin_bit_cast(h16x8, rb[s][sb][0]), c, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j < 4) {
+                    if constexpr (s < 3) fn[j] = __builtin_bit_cast(h16x8, sA[buf][0][((s + 1) * 2 + kh) * FBD + j * 32 + l31]);
+                    else fn[j] = __builtin_bit_cast(h16x8, sA[buf ^ 1][0][kh * FBD + j * 32 + l31]);
+                } else if (j < 6) {
+                    if constexpr (s < 2) load_b1(pb, s + 2, j - 4, rb[s + 2][j - 4][0]);
+                    else load_b1(pbn, s - 2, j - 4, rb[s - 2][j - 4][0]);
+                } else {
+#ifndef VTM_EXP_NODMA
+                    if constexpr (s == 0) load_a_piece(pa1, buf ^ 1, j - 4);   // pieces 2, 3 of the next tile
+                    if constexpr (s == 3) load_a_piece(pa2, buf, j - 6);       // pieces 0, 1 of the one after
+#endif
+                    if constexpr (s == 1)   // agent scope: from L2, where the other workgroups' atomics land
+                        asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(am[j - 6]) : "v"(voff_m[j - 6]), "s"(amax_rows));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // ONE wait statement for both variants of group 0: the fragments are usable only through the registers this
+        // statement returns, and a second copy of it behind the branch would make the compiler copy them BEFORE it
+#ifdef VTM_EXP_NOAWAIT
+        await_b(std::integral_constant<int, 63>{}, rb[0]);
 #else
-        if (wrap) {
+        await_b(std::integral_constant<int, NB + PG>{}, rb[0]);
 #endif
-            // dst tile finished: every score within the window of the lane's running max becomes a candidate
-            const int dst0 = jt * FBD + 4 * kh;
-            const bool full = (int64_t)(jt + 1) * FBD <= Nd;
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                float rm = runmax[sb];
-#pragma unroll
-                for (int ib = 0; ib < 4; ++ib) {
-                    if (!full) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (dst0 + ib * 32 + (r & 3) + 8 * (r >> 2) >= Nd) acc[ib][sb][r] = -INFINITY;
-                    }
-                    // The block's 16 scores of this lane, as 4 quarters of 4 (quarter k = dst rows 8 k + 0..3).
-                    // Everything within the window of the running maximum AFTER this block becomes a candidate
-                    // (a running maximum is never above the final one, so this collects a superset of what the
-                    // final maximum requires).  Almost always that is nothing, or exactly the block's maximum:
-                    // that case is handled without a loop -- locate the maximum by compare/select, check that the
-                    // second largest score stays outside the window, insert.  Ties and near-ties inside one block
-                    // (rare) take the element-by-element path below.
-                    const f32x16 &v = acc[ib][sb];
-                    float q[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) q[k] = fmaxf(fmaxf(fmaxf(v[4 * k], v[4 * k + 1]), v[4 * k + 2]), v[4 * k + 3]);
-                    const float gm = fmaxf(fmaxf(fmaxf(q[0], q[1]), q[2]), q[3]);
-                    const float newmax = fmaxf(rm, gm);
-                    const float thr = newmax - WS;
-                    const bool trig = gm >= thr && gm > -INFINITY;   // NaN / masked blocks never pass
-                    if (__any(trig)) {
-                        // quarter and element of the (first) maximum
-                        const bool c0 = q[0] == gm, c1 = q[1] == gm, c2 = q[2] == gm;
-                        float w[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) w[j] = c0 ? v[j] : c1 ? v[4 + j] : c2 ? v[8 + j] : v[12 + j];
-                        const int kq = c0 ? 0 : c1 ? 1 : c2 ? 2 : 3;
-                        const bool d0 = w[0] == gm, d1 = w[1] == gm, d2 = w[2] == gm;
-                        const int eq = d0 ? 0 : d1 ? 1 : d2 ? 2 : 3;
-                        // largest score of the block apart from that element
-                        const float qo = fmaxf(fmaxf(fmaxf(c0 ? -INFINITY : q[0], (!c0 && c1) ? -INFINITY : q[1]),
-                                                     (!c0 && !c1 && c2) ? -INFINITY : q[2]),
-                                               (c0 || c1 || c2) ? q[3] : -INFINITY);
-                        const float wo = fmaxf(fmaxf(fmaxf(d0 ? -INFINITY : w[0], (!d0 && d1) ? -INFINITY : w[1]),
-                                                     (!d0 && !d1 && d2) ? -INFINITY : w[2]),
-                                               (d0 || d1 || d2) ? w[3] : -INFINITY);
-                        const float second = fmaxf(qo, wo);
-                        if (!__any(trig && second >= thr)) {
-                            if (trig) {
-                                if (cv[sb][3] >= thr)   // evicted entry still inside the window: spill it
-                                    push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3]);
-                                cv[sb][3] = cv[sb][2]; ci[sb][3] = ci[sb][2];
-                                cv[sb][2] = cv[sb][1]; ci[sb][2] = ci[sb][1];
-                                cv[sb][1] = cv[sb][0]; ci[sb][1] = ci[sb][0];
-                                cv[sb][0] = gm;
-                                ci[sb][0] = (uint32_t)(dst0 + ib * 32 + eq + 8 * kq);
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float x = v[r];
-                                if (x >= rm - WS && x > -INFINITY) {
-                                    const float nrm_ = fmaxf(rm, x);
-                                    if (cv[sb][3] >= nrm_ - WS) push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3]);
-                                    cv[sb][3] = cv[sb][2]; ci[sb][3] = ci[sb][2];
-                                    cv[sb][2] = cv[sb][1]; ci[sb][2] = ci[sb][1];
-                                    cv[sb][1] = cv[sb][0]; ci[sb][1] = ci[sb][0];
-                                    cv[sb][0] = x;
-                                    ci[sb][0] = (uint32_t)(dst0 + ib * 32 + (r & 3) + 8 * (r >> 2));
-                                    rm = nrm_;
-                                }
-                            }
-                        }
-                    }
-                    rm = fmaxf(rm, gm);
-                }
-                runmax[sb] = rm;
-            }
-        }
-        // every wave's DMA pieces of the next tile must have landed before anybody reads them; they are older
-        // than the 2 NB loads of groups 2 and 3
+        if (kt == 0) group(std::integral_constant<int, 0>{}, std::true_type{});
+        else group(std::integral_constant<int, 0>{}, std::false_type{});
+        group(std::integral_constant<int, 1>{}, std::false_type{});
+        group(std::integral_constant<int, 2>{}, std::false_type{});
 #ifndef VTM_EXP_NOBARRIER
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NB + 2) : "memory");
         __syncthreads();
 #endif
-        kt = ktn;
-        jt = jtn;
+        group(std::integral_constant<int, 3>{}, std::false_type{});
+#ifdef VTM_EXP_NOWRAP
+        if (wrap && jt < 0) collect_tile(jt, std::true_type{});
+#else
+        if (wrap) collect_tile(jt, std::true_type{});
+#endif
+        if (wrap) ++jt;
+        kt = kt1;
+        pb = pbn;
+        pa1 = pa2;
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused prefetches of the last step
 
     // flush: the entries still inside the window of this lane's final maximum
