@@ -27,3 +27,5 @@ for what in gather unmerge layernorm; do
   done
 done
 ls $O/pmc | wc -l
+(cd $R/tools/ubench && hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 attn_tile_model.hip -o /tmp/atm 2>/dev/null && /tmp/atm > $O/attn_tile_model.txt 2>&1)
+python $R/tools/sweep_nsplit.py > $O/sweep_nsplit.txt 2>&1

@@ -21,7 +21,8 @@ __device__ __forceinline__ uint32_t pmax3(uint32_t a, uint32_t b, uint32_t c) {
 // MODE 0: the kernel's order (QK^T, exps, check, PV).  MODE 1: no exps (v_mov instead).  MODE 2: no MFMAs at all (VALU only).
 // MODE 3: the PV MFMAs only (the unused QK^T is eliminated).  MODE 4: as 0 with PV from 32-row blocks (8 x 32x32x16, no swaps).
 template <int MODE, int NT>
-__global__ __launch_bounds__(NT) void tile_model(float *out, int iters, float seed) {
+__global__ __launch_bounds__(NT) void tile_model(float *out, int iters, float seed, unsigned long long *cyc) {
+    const unsigned long long c_begin = clock64();   // s_memtime: shader-clock cycles
     h16x8 q[3], kf[2][3], vf[2][3];
     for (int i = 0; i < 3; ++i)
         for (int e = 0; e < 8; ++e) {
@@ -138,6 +139,9 @@ __global__ __launch_bounds__(NT) void tile_model(float *out, int iters, float se
         for (int h = 0; h < 2; ++h)
             for (int e = 0; e < 4; ++e) acc += o[d][h][e];
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    // wave 0's own duration: the shader clock of the run when every SIMD holds ONE wave (with more, the oldest wave is
+    // served first and finishes early, so its duration says nothing about the launch)
+    if (cyc && blockIdx.x == 0 && threadIdx.x == 0) *cyc = clock64() - c_begin;
 }
 
 template <int MODE, int NT>
@@ -149,19 +153,26 @@ void run(const char *name, int wgs_per_cu) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((tile_model<MODE, NT>), grid, block, 0, 0, out, 10, 1.0f);
+    unsigned long long *cyc;
+    (void)hipMalloc(&cyc, sizeof(*cyc));
+    hipLaunchKernelGGL((tile_model<MODE, NT>), grid, block, 0, 0, out, 10, 1.0f, (unsigned long long *)nullptr);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((tile_model<MODE, NT>), grid, block, 0, 0, out, iters, 1.0f);
+    hipLaunchKernelGGL((tile_model<MODE, NT>), grid, block, 0, 0, out, iters, 1.0f, cyc);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
     const int wps = NT / 256 * wgs_per_cu;
     const double ns = ms * 1e6 / ((double)iters * wps);   // per tile-wave one SIMD executed
-    printf("%-48s %d waves/SIMD: %.3f ms -> %.1f ns per tile-wave per SIMD (= %.0f cycles @2.4 GHz; matrix pipe alone: 384)\n", name,
+    unsigned long long hc = 0;
+    (void)hipMemcpy(&hc, cyc, sizeof(hc), hipMemcpyDeviceToHost);
+    printf("%-48s %d waves/SIMD: %.3f ms -> %.1f ns per tile-wave per SIMD (= %.0f cycles @2.4 GHz; matrix pipe alone: 384)", name,
            wps, ms, ns, ns * 2.4);
+    if (wps == 1) printf("  [measured: %.0f shader cycles per tile-wave, clock %.2f GHz]", (double)hc / iters, (double)hc / (ms * 1e6));
+    printf("\n");
     (void)hipFree(out);
+    (void)hipFree(cyc);
 }
 
 int main() {
@@ -175,6 +186,7 @@ int main() {
     }
     run<0, 768>("kernel mix, 12-wave workgroup", 1);
     run<5, 768>("software-pipelined, 12-wave workgroup", 1);
+    run<0, 256>("kernel mix, 4-wave workgroup", 1);
     run<5, 256>("software-pipelined, 4-wave workgroup", 1);
     run<5, 256>("software-pipelined, 4-wave workgroups", 3);
     return 0;

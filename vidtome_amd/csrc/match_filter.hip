@@ -34,7 +34,8 @@ namespace {
 // Ablation switches (never defined in the shipped build; used for the measurements quoted in DESIGN.md section 9):
 //   VTM_EXP_NOWRAP     skip the candidate collection at the end of every dst tile
 //   VTM_EXP_NOBARRIER  drop the end-of-step wait + barrier      VTM_EXP_NOAWAIT  never wait for fragment loads
-//   VTM_EXP_NODMA      do not fetch dst tiles                   VTM_EXP_HOTMEM   fetch everything from one hot tile
+//   VTM_EXP_NODMA      do not fetch dst tiles                   VTM_EXP_HOTMEM   fetch everything from one hot tile (phased loop)
+//   VTM_EXP_NOBLOAD    do not fetch src fragments               VTM_EXP_NOLDSREAD  do not read dst fragments from LDS
 // (all of them produce wrong results; they only tell where the time goes)
 constexpr int FBD = 128;      // dst rows per tile (MFMA A operand, LDS)
 constexpr int FBS = 256;      // src rows per workgroup (B operand, registers), 64 per wave
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const uint32_t voff_b = (uint32_t)(kh * Ns_pad + srow0 + l31) * 16u;
     const int64_t bgroup = 2 * Ns_pad;   // uint4 entries per k-step group (2 panels)
     u32x4 rb[4][2][2];
-    auto load_b = [&](int kt, int ks, u32x4 (&dst)[2][2]) {
+    [[maybe_unused]] auto load_b = [&](int kt, int ks, u32x4 (&dst)[2][2]) {
 #ifdef VTM_EXP_HOTMEM
         const uint4 *ph = srch + ks * bgroup;
 #else
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         alds[t] = (uint32_t)reinterpret_cast<uintptr_t>((lds_void *)&sA[0][which][p * FBD + half * 64]);
     }
     const uint32_t voff_a = (uint32_t)lane * 16u;
-    auto load_a_half = [&](int jt, int kt, int buf, int half_id) {
+    [[maybe_unused]] auto load_a_half = [&](int jt, int kt, int buf, int half_id) {
 #ifdef VTM_EXP_HOTMEM
         const int64_t step_off = 0;
 #else
@@ -674,11 +675,17 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                 acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], __builtin_bit_cast(h16x8, rb[s][sb][0]), c, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 4) {
+#ifndef VTM_EXP_NOLDSREAD
                     if constexpr (s < 3) fn[j] = __builtin_bit_cast(h16x8, sA[buf][0][((s + 1) * 2 + kh) * FBD + j * 32 + l31]);
                     else fn[j] = __builtin_bit_cast(h16x8, sA[buf ^ 1][0][kh * FBD + j * 32 + l31]);
+#else
+                    fn[j] = fh[j];
+#endif
                 } else if (j < 6) {
+#ifndef VTM_EXP_NOBLOAD
                     if constexpr (s < 2) load_b1(pb, s + 2, j - 4, rb[s + 2][j - 4][0]);
                     else load_b1(pbn, s - 2, j - 4, rb[s - 2][j - 4][0]);
+#endif
                 } else {
 #ifndef VTM_EXP_NODMA
                     if constexpr (s == 0) load_a_piece(pa1, buf ^ 1, j - 4);   // pieces 2, 3 of the next tile
