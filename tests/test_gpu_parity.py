@@ -124,6 +124,24 @@ def test_match_filtered_equals_exact(L, dtype, align):
         _filtered_vs_exact(L, x, Ns, Nd, align, expect_flag=0)
 
 
+def test_match_filtered_run_to_run(L):
+    """The dst splits of a row share their running maximum WHILE they run (atomicMax / re-read every step), so the candidate
+    sets depend on timing; the result must not.  Same call 20 times, thousands of near-ties inside the window, vs the exact matcher
+    (tools/stress_match.py runs the cfg-2 shapes 100 times each)."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for (B, Ns, Nd, C, noise) in [(2, 12288, 4096, 320, 1e-3), (2, 6000, 9000, 64, 0.1)]:
+        base = torch.randn(B, Nd, C, generator=g, device=DEV)
+        idx = torch.arange(Ns + Nd, device=DEV) % Nd
+        x = (base[:, idx] + noise * torch.randn(B, Ns + Nd, C, generator=g, device=DEV)).half()
+        ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+        rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+        a_op, _ = L.normalize_gather(x, None, ra)
+        b_op, _ = L.normalize_gather(x, None, rb)
+        exact = L.match(a_op, b_op, Ns, Nd, False)
+        for _ in range(20):
+            assert torch.equal(L.match_filtered(x, None, ra, rb, False), exact)
+
+
 def test_match_filtered_fuzz(L):
     """Random shapes / dtypes / data regimes (tools/fuzz_match.py; 1 800 cases were run while developing)."""
     import importlib.util

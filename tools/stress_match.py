@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Run-to-run stability of vtm_match_filtered: the dst splits of a row share their running maximum while they run, so the
+candidate SETS depend on timing -- the result must not.  Repeats the same call many times at the cfg-2 shapes (and with many
+near-ties) and compares every result with the first one and with the exact fp32 matcher.
+    python tools/stress_match.py [--reps 100]      (needs an MI355X)"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vidtome_amd import _lib as L  # noqa: E402
+
+SHAPES = [(2, 49152, 16384, 320), (2, 12288, 28672, 320), (2, 8704, 8704, 640), (3, 3000, 5000, 64), (1, 700, 9000, 1280)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=100)
+    a = ap.parse_args()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    bad = 0
+    for (B, Ns, Nd, C) in SHAPES:
+        for regime in ("correlated", "near-ties"):
+            base = torch.randn(B, Nd, C, generator=g, device="cuda")
+            idx = torch.arange(Ns + Nd, device="cuda") % Nd
+            noise = 0.1 if regime == "correlated" else 1e-3     # near-ties: thousands of scores inside the window
+            x = (base[:, idx] + noise * torch.randn(B, Ns + Nd, C, generator=g, device="cuda")).half()
+            ra = torch.arange(Ns, dtype=torch.int32, device="cuda").expand(B, Ns).contiguous()
+            rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device="cuda").expand(B, Nd).contiguous()
+            a_op, _ = L.normalize_gather(x, None, ra)
+            b_op, _ = L.normalize_gather(x, None, rb)
+            exact = L.match(a_op, b_op, Ns, Nd, False)
+            diff = 0
+            for _ in range(a.reps):
+                diff += int(not torch.equal(L.match_filtered(x, None, ra, rb, False), exact))
+            bad += diff
+            print(f"B={B} Ns={Ns} Nd={Nd} C={C} {regime}: {a.reps} runs, {diff} differ from the exact matcher", flush=True)
+    print("FAIL" if bad else "OK")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
