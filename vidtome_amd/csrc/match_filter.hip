@@ -303,13 +303,16 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     // or LDS read into "s_waitcnt vmcnt(0) lgkmcnt(0)" (the instruction counts as a flat access to two address
     // spaces), which drains the prefetches the moment they are issued -- measured: the MFMA pipe idles half the
     // time.  vmcnt retires in order, so a counted wait only needs the number of operations issued AFTER the one
-    // awaited; the loop below issues a fixed sequence per step (no conditional loads), hence constant counts:
-    //     group 0: B(2) x NB, DMA x PG | group 1: B(3) x NB, DMA x PG | group 2: B(0') x NB | group 3: B(1') x NB
-    // B(s) = src fragments of group s (' = next step), DMA = LDS-DMA pieces of the next dst tile.  B fragments are
-    // fetched two groups (32 MFMAs) ahead, the DMA pieces ride behind the B loads of groups 0 / 1 so that no B wait
-    // drags a freshly issued piece along, and the end-of-step wait leaves the 2 NB youngest loads in flight.
-    // Any additional vector-memory operation the compiler issues (candidate pushes) is younger than ours and can
-    // only make these waits stricter, never laxer.
+    // awaited; both loops below issue a fixed sequence per step (no conditional loads), hence constant counts.
+    // B(s) = src fragments of k-step group s (' = next step), always fetched two groups (32 MFMAs) ahead; DMA = LDS-DMA
+    // pieces of an upcoming dst tile.  The sequences and their counts are written next to each loop (shipped: below
+    // "shipped loop"; the phased one of the 2- / 3-product builds: g0: B(2) x NB, DMA x PG | g1: B(3) x NB, DMA x PG |
+    // g2: B(0') x NB | g3: B(1') x NB, the DMA pieces behind the B loads of groups 0 / 1 so that no B wait drags a freshly
+    // issued piece along, end-of-step wait with the 2 NB youngest loads in flight).
+    // Any additional vector-memory operation the compiler issues (candidate pushes, maximum publishing) is younger than
+    // ours and can only make these waits stricter, never laxer.  Two rules keep the scheme sound: every wait statement
+    // exists ONCE (a copy behind a branch makes the compiler copy the awaited registers before it -- stale fragments),
+    // and the kernel must not spill SGPRs (a spilling build of this loop faults on gfx950 / ROCm 7.2).
     constexpr int NB = SRC_LO ? 4 : 2;
     // addresses = wave-uniform 64-bit base (SGPR pair, advanced with scalar adds) + per-lane 32-bit byte offset
     const uint32_t voff_b = (uint32_t)(kh * Ns_pad + srow0 + l31) * 16u;
