@@ -30,6 +30,29 @@ def test_library_exports_every_declared_symbol(built):
     assert _lib.lib().vtm_pad_rows(257) == 512 and _lib.lib().vtm_pad_k(320) == 320 and _lib.lib().vtm_pad_k(40) == 64
 
 
+def test_hot_kernels_keep_their_register_budget(built):
+    """Code-object metadata of the built gfx950 kernels: the filter's hand-counted memory pipeline must not spill (a
+    build whose SGPRs spilled faulted on the GPU) and must fit two waves per SIMD; the d = 40 attention kernel must keep
+    four waves per SIMD (<= 128 VGPRs, no scratch); the shipped GEMM tiles fit two."""
+    from vidtome_amd import build
+    res = {}
+    for obj in ("match_filter.o", "attention.o", "linear.o"):
+        res.update(build.kernel_resources(os.path.join(build.LIBDIR, obj)))
+
+    def only(*parts):
+        hits = {k: v for k, v in res.items() if all(p in k for p in parts)}
+        assert hits, parts
+        return hits
+
+    for k, v in only("filter_kernel").items():
+        assert v["sgpr_spill_count"] == 0 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+        assert v["vgpr_count"] <= 256, (k, v)
+    for k, v in only("16attention_kernel", "Li40E").items():      # half and bf16
+        assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+    for k, v in only("linear_rows_kernel").items():
+        assert v["vgpr_count"] <= 256 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+
+
 def test_partition_counts_match_reference_arithmetic(built, oracle):
     """vtm_partition_counts (host helper) vs the reference's own boolean-mask construction (merge.py:52-69)."""
     from vidtome_amd import _lib

@@ -75,6 +75,38 @@ def build(force: bool = False, verbose: bool = False, defines=(), tag: str = "")
     return lib
 
 
+def kernel_resources(obj: str) -> dict:
+    """Register / scratch budget of every gfx950 kernel in one of the built objects (`lib/<source>.o`), from the code
+    object's metadata: {demangled-ish name: {vgpr_count, sgpr_count, vgpr_spill_count, sgpr_spill_count,
+    private_segment_fixed_size}}.  tests/test_host.py pins the hot kernels with it (the filter's hand-counted memory
+    pipeline must not spill; the attention kernel must keep 4 waves per SIMD)."""
+    import re
+    import tempfile
+    llvm = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib", "llvm", "bin")
+    if not os.path.isdir(llvm):
+        llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, dev = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        for cmd in ([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj],
+                    [os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--unbundle", "--input=" + fat, "--output=" + dev,
+                     "--targets=hipv4-amdgcn-amd-amdhsa--" + ARCH]):
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if p.returncode != 0:
+                raise RuntimeError(" ".join(cmd) + "\n" + p.stdout)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", dev], stdout=subprocess.PIPE, text=True,
+                               check=True).stdout
+    out, cur = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s*\.(name|vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "name":
+            cur = out.setdefault(m.group(2), {})
+        elif cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    return {k: v for k, v in out.items() if "vgpr_count" in v}
+
+
 if __name__ == "__main__":
     # python -m vidtome_amd.build [--force] [--tag NAME -DMACRO ...]
     argv = sys.argv[1:]
