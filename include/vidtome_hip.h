@@ -95,7 +95,7 @@ int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd,
  * rigorous error window of the row's running maximum, and an fp32 refine pass evaluates the canonical
  * fmaf chain on those candidates only.  A row with more than 64 candidates (massively duplicated dst
  * rows) is recomputed exactly on its own; a row without a finite positive norm (zero token -> NaN xhat,
- * merge.py:84 has no eps) raises a device flag that makes the refine pass recompute EVERY row of the call
+ * merge.py:84 has no eps), or with a norm outside [2^-100, 2^100], raises a device flag that makes the refine pass recompute EVERY row of the call
  * exactly (no host round trip).  Four launches per call: operand preparation (canonical norms + fp16 panels),
  * filter, survivor compaction, refine.  C > 1280 is rejected (the error budget is derived for C <= 1280; use
  * vtm_match).

@@ -178,6 +178,19 @@ def test_match_filtered_hard_cases(L):
     x[1, Ns + 50] = 0
     _filtered_vs_exact(L, x.to(DEV), Ns, Nd, False, expect_flag=1)
     _filtered_vs_exact(L, x.to(DEV), Ns, Nd, True, expect_flag=1)
+    # (4b) fp32 tokens with norms far outside the range where the filter's reciprocal-multiply operands are trustworthy
+    #      (1e-38 .. 1e-33 and 1e+33): same flag, same exact result; moderate scales (1e-20, 1e+15) stay on the fast path
+    xf = torch.randn(B, Ns + Nd, C, generator=g)
+    xs = xf.clone()
+    xs[0, 7] *= 1e-20
+    xs[1, Ns + 3] *= 1e15
+    _filtered_vs_exact(L, xs.to(DEV), Ns, Nd, False, expect_flag=0)
+    xs = xf.clone()
+    xs[0, 7] *= 1e-36
+    _filtered_vs_exact(L, xs.to(DEV), Ns, Nd, False, expect_flag=1)
+    xs = xf.clone()
+    xs[1, Ns + 3] *= 3e31
+    _filtered_vs_exact(L, xs.to(DEV), Ns, Nd, True, expect_flag=1)
     # (5) candidate overflow: every dst row identical -> more than 32 candidates per row -> those rows are
     #     recomputed by the exact row pass (no whole-call fallback)
     x = torch.randn(B, Ns + Nd, C, generator=g).half()

@@ -54,6 +54,7 @@ constexpr float INV_S2 = 1.0f / (1024.0f * 1024.0f);
 // (|lo| <= u |1024 xhat| element-wise):
 //   each dropped lo operand                <= u * sum |a_k b_k|               = 4.9e-4   (both: 2u + u^2 = 9.8e-4)
 //   hi/lo representation tails             <= 3 * 2^-22                       = 7e-7
+//   reciprocal-multiply operands (1 product) <= 2 * 2.4e-7                      = 5e-7
 //   fp32 accumulation inside the MFMA      <= (#products) * C * 2^-24         = 7.6e-5 per product
 //   the canonical fp32 chain itself        <= C * 2^-24                       = 7.6e-5
 // EPS = 3.25e-4 (3 products) / 7.5e-4 (2) / 1.2e-3 (1); observed filter errors are ~1e-6 / ~1e-5 / ~2e-5.
@@ -215,7 +216,13 @@ __global__ __launch_bounds__(256) void prep_operand(const T *__restrict__ x0, in
     const float nrm = __builtin_sqrtf(acc);
     if (real) A.norms[b * n + i] = nrm;
 
-    // sweep 2: xhat = x / norm (IEEE), scaled, split into fp16 hi (+ lo), written as panels
+    // sweep 2: xhat = x / norm, scaled, split into fp16 hi (+ lo), written as panels.  The one-product filter only needs
+    // hi = fp16(1024 xhat (1 + d)) with |d| <= 2.4e-7 (reciprocal <= 1 ulp, one product rounding; two such operands add
+    // <= 5e-7 to the score error, inside the 7e-5 the window keeps in reserve), so it multiplies by ONE reciprocal per row
+    // instead of dividing 320-1280 times (~10 instructions each).  The refine pass has its own IEEE divisions; norms
+    // outside [2^-100, 2^100] (where the reciprocal could leave the normal range) send the call down the exact path like
+    // non-finite ones (survivors_kernel).
+    const float rscale = SCALE * __builtin_amdgcn_rcpf(nrm);
     uint4 *__restrict__ out_hi = in_range ? A.out_hi + (b * G) * n_pad + i : nullptr;
     uint4 *__restrict__ out_lo = (in_range && A.out_lo) ? A.out_lo + (b * G) * n_pad + i : nullptr;
     constexpr int PPG = 8 / EPP;                                        // pieces per 8-channel panel group (1 or 2)
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256) void prep_operand(const T *__restrict__ x0, in
             _Float16 *ph = reinterpret_cast<_Float16 *>(&vh), *pl = reinterpret_cast<_Float16 *>(&vl);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float sc = (f[e] / nrm) * SCALE;                 // the canonical xhat (IEEE divide), scaled
+                const float sc = DST_LO ? (f[e] / nrm) * SCALE : f[e] * rscale;   // 2 / 3 products: the canonical xhat
                 const _Float16 h = (_Float16)sc;
                 ph[e] = h;
                 pl[e] = (_Float16)(sc - (float)h);                     // exact difference, rounded once
@@ -755,14 +762,15 @@ __global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const 
                                                         uint2 *__restrict__ pairs, const float *__restrict__ na,
                                                         int64_t n_na, const float *__restrict__ nb, int64_t n_nb) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // any row of either operand without a finite positive norm (zero token -> NaN xhat, merge.py:84): the filter's
+    // any row of either operand without a finite positive norm (zero token -> NaN xhat, merge.py:84), or with one so
+    // small / large that prep_operand's reciprocal is not a normal number: the filter's
     // error window means nothing for this call -> refine_kernel recomputes EVERY row exactly (flags[0]).  The scan
     // rides on this launch (a kernel boundary separates it from the reader).
     {
         const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
         bool bad = false;
-        for (int64_t t = row; t < n_na; t += gsz) bad |= !(na[t] > 0.0f && na[t] < INFINITY);
-        for (int64_t t = row; t < n_nb; t += gsz) bad |= !(nb[t] > 0.0f && nb[t] < INFINITY);
+        for (int64_t t = row; t < n_na; t += gsz) bad |= !(na[t] >= 0x1p-100f && na[t] <= 0x1p100f);
+        for (int64_t t = row; t < n_nb; t += gsz) bad |= !(nb[t] >= 0x1p-100f && nb[t] <= 0x1p100f);
         if (bad) { flags[0] = 1; flags[1] = 1; }
     }
     if (row >= rows_out) return;
