@@ -110,6 +110,31 @@ __device__ __forceinline__ float vmax2(float a, float b) {
     return d;
 }
 
+// ---- x / n for MANY x and ONE n, bit-identical to the IEEE division ----
+// hipcc expands x / n (fp32, denormals on) to  d = div_scale(n), m = div_scale(x), r = rcp(d), e = fma(-d, r, 1), r1 = fma(e, r, r),
+// q = m * r1, t = fma(-d, q, m), q1 = fma(t, r1, q), t2 = fma(-d, q1, m), div_fmas(t2, r1, q1), div_fixup -- 11 instructions, the
+// reciprocal refinement redone for every x because v_div_scale looks at both operands.  When neither operand needs scaling
+// (n in [2^-100, 2^100]: guaranteed on the filtered path, survivors_kernel; x = 0, or |x| >= 2^-102 and x / n >= 2^-124: checked,
+// `div_ok`) div_scale returns its input, div_fmas is a plain fma and div_fixup passes the value through (a zero quotient may
+// lose its sign, which a fused multiply-add chain starting from +0 cannot see), so the SAME operations with the SAME roundings can
+// be issued with r1 computed once per row: 5 instructions per quotient.
+struct RowDivisor {
+    float n, r1, lo;
+};
+__device__ __forceinline__ RowDivisor row_divisor(float n) {
+    const float r = __builtin_amdgcn_rcpf(n);
+    const float e = __builtin_fmaf(-n, r, 1.0f);
+    return {n, __builtin_fmaf(e, r, r), fmaxf(0x1p-102f, n * 0x1p-124f)};
+}
+__device__ __forceinline__ bool div_ok(float x, const RowDivisor &d) { return __builtin_fabsf(x) >= d.lo || x == 0.0f; }
+__device__ __forceinline__ float div_by_row(float x, const RowDivisor &d) {
+    const float q = x * d.r1;
+    const float t = __builtin_fmaf(-d.n, q, x);
+    const float q1 = __builtin_fmaf(t, d.r1, q);
+    const float t2 = __builtin_fmaf(-d.n, q1, x);
+    return __builtin_fmaf(t2, d.r1, q1);
+}
+
 __device__ __forceinline__ uint32_t orderable(float f) {
     if (f != f) return 0xffffffffu;
     const uint32_t u = __float_as_uint(f + 0.0f);
@@ -271,7 +296,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const uint4 *__restrict__ ah, const uint4 *__restrict__ al, const uint4 *__restrict__ bh,
     const uint4 *__restrict__ bl, int64_t Ns, int64_t Nd, int64_t Ns_pad, int64_t Nd_pad, int64_t C_pad, int align,
     int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split, int total_src_tiles, int patch_tiles,
-    unsigned int *__restrict__ amax, int *__restrict__ cnt, uint2 *__restrict__ cand, int *__restrict__ flags) {
+    unsigned int *__restrict__ amax, int *__restrict__ cnt, uint2 *__restrict__ cand, int cand_rows, int *__restrict__ flags) {
     // dst tile of one step: 8 panels x 128 rows x 16 B, hi and lo, double-buffered: 2 x 2 x 16 KiB
     __shared__ __attribute__((aligned(16))) uint4 sA[2][DST_LO ? 2 : 1][8 * FBD];
 
@@ -385,10 +410,12 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     constexpr float WS = WINDOW * SCALE * SCALE;
     float runmax[2], cv[2][4];
     uint32_t ci[2][4];
+    // candidate lists are slot-major, [slot][row] (cand_rows rows): the first entries of neighbouring rows -- all that most
+    // rows ever have -- share cache lines for the lanes of survivors_kernel; 32-bit index (the launcher checks the size)
     auto push = [&](int64_t srow, float v_scaled, uint32_t d) {   // append to the row's global candidate list
         const int slot = atomicAdd(&cnt[out_row0 + srow], 1);     // cnt > CAP marks the row for the exact row pass
         if (slot < CAP)
-            cand[(out_row0 + srow) * CAP + slot] = make_uint2(__float_as_uint(v_scaled * INV_S2), d + idx_base);
+            cand[(uint32_t)slot * (uint32_t)cand_rows + (uint32_t)(out_row0 + srow)] = make_uint2(__float_as_uint(v_scaled * INV_S2), d + idx_base);
     };
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
@@ -773,23 +800,44 @@ __global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const 
         for (int64_t t = row; t < n_nb; t += gsz) bad |= !(nb[t] >= 0x1p-100f && nb[t] <= 0x1p100f);
         if (bad) { flags[0] = 1; flags[1] = 1; }
     }
-    if (row >= rows_out) return;
-    const int n = cnt[row];
-    if (n > CAP) {   // candidate list overflowed: the row is recomputed exactly by refine_kernel's row pass
-        ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
-        return;
-    }
-    const float thr = from_orderable(amax[row]) - WINDOW;
+    // per row: count the candidates inside the window of the row's final approximate maximum.  The first PRE list entries
+    // are fetched in ONE batch (a loop that waits for every entry costs a memory latency per entry, twice: ~16 entries per
+    // row at 8 dst splits); longer lists continue with a loop.  The wave reserves its slice of the pair list with ONE atomic.
+    const bool live = row < rows_out;
+    const int n = live ? cnt[row] : 0;
+    const float thr = live ? from_orderable(amax[row]) - WINDOW : 0.0f;
+    constexpr int PRE = 16;
+    uint2 pre[PRE];
+#pragma unroll
+    for (int c = 0; c < PRE; ++c) pre[c] = c < n && n <= CAP ? cand[(int64_t)c * rows_out + row] : make_uint2(0x7fc00000u, 0u);
     int ns = 0;
-    for (int c = 0; c < n; ++c) ns += __uint_as_float(cand[row * CAP + c].x) >= thr;
-    if (ns > MAX_SURVIVORS) {
+#pragma unroll
+    for (int c = 0; c < PRE; ++c) ns += __uint_as_float(pre[c].x) >= thr;   // NaN (not fetched) never counts
+    if (n <= CAP)
+        for (int c = PRE; c < n; ++c) ns += __uint_as_float(cand[(int64_t)c * rows_out + row].x) >= thr;
+    if (n > CAP || ns > MAX_SURVIVORS) {   // list overflowed / too many survivors: refine_kernel's exact row pass
         ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
-        return;
+        ns = 0;
     }
-    int at = atomicAdd(&flags[3], ns);
-    for (int c = 0; c < n; ++c) {
-        const uint2 cd = cand[row * CAP + c];
-        if (__uint_as_float(cd.x) >= thr) pairs[at++] = make_uint2((uint32_t)row, cd.y);
+    const int lane = threadIdx.x & 63;
+    int incl = ns;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    int base = 0;
+    if (lane == 63 && incl > 0) base = atomicAdd(&flags[3], incl);
+    base = __shfl(base, 63, 64);
+    int at = base + incl - ns;
+    if (ns > 0) {
+#pragma unroll
+        for (int c = 0; c < PRE; ++c)
+            if (__uint_as_float(pre[c].x) >= thr) pairs[at++] = make_uint2((uint32_t)row, pre[c].y);
+        for (int c = PRE; c < n; ++c) {
+            const uint2 cd = cand[(int64_t)c * rows_out + row];
+            if (__uint_as_float(cd.x) >= thr) pairs[at++] = make_uint2((uint32_t)row, cd.y);
+        }
     }
 }
 
@@ -804,7 +852,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
                                                      const uint2 *__restrict__ pairs, const int *__restrict__ ovf_rows,
                                                      unsigned long long *__restrict__ best, int64_t rows_out) {
     extern __shared__ float sa[];   // exact-row pass: the normalised src row (C floats)
-    const int npairs = flags[3];
+    // a call with a norm outside [2^-100, 2^100] (flags[0]) is recomputed row by row below: its pairs are skipped, the fast
+    // division is only ever used inside that range
+    const int npairs = flags[0] ? 0 : flags[3];
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (int64_t)gridDim.x * blockDim.x) {
         const uint2 pr = pairs[p];
         const int64_t row = pr.x;
@@ -815,13 +865,40 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
         const T *pa = pool_row(x0, P0, x1, P1, bi, a_rows[bi * Ns + i], C);
         const T *pb = pool_row(x0, P0, x1, P1, bi, b_rows[bi * Nd + j], C);
         const float nrm_a = na[bi * Ns + i], nrm_b = nb[bi * Nd + j];
+        const RowDivisor da = row_divisor(nrm_a), db = row_divisor(nrm_b);
         float acc = 0.0f;
-        for (int64_t k = 0; k < C; k += 8) {
+        auto chain8 = [&](const float (&fa)[8], const float (&fb)[8]) {
+            bool ok = true;
+            if constexpr (!std::is_same<T, __half>::value) {   // fp16 tokens: 2^-24 <= |x| and norms < 2^23, always in range
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ok = ok && div_ok(fa[e], da) && div_ok(fb[e], db);
+            }
+            if (ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(div_by_row(fa[e], da), div_by_row(fb[e], db), acc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(fa[e] / nrm_a, fb[e] / nrm_b, acc);
+            }
+        };
+        // 32 channels per step: 4 + 4 independent 16-byte loads in flight per lane (a lane walks its own two rows; with one
+        // load per row and step every step costs a cache round trip)
+        int64_t k = 0;
+        for (; k + 32 <= C; k += 32) {
+            float fa[4][8], fb[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                load8(pa + k + 8 * u, fa[u]);
+                load8(pb + k + 8 * u, fb[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) chain8(fa[u], fb[u]);
+        }
+        for (; k < C; k += 8) {
             float fa[8], fb[8];
             load8(pa + k, fa);
             load8(pb + k, fb);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(fa[e] / nrm_a, fb[e] / nrm_b, acc);
+            chain8(fa, fb);
         }
         atomicMax(&best[row], ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col));
     }
@@ -923,6 +1000,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     int *ovf_rows = (int *)(w + L.ovf);
     uint2 *pairs = (uint2 *)(w + L.pairs);
     const int64_t rows_out = align ? Ns : B * Ns;
+    VTM_REQUIRE(rows_out * CAP < (1ll << 31), "vtm_match_filtered: too many rows for the 32-bit candidate index");
 
     VTM_REQUIRE(dtype == VTM_F32 || dtype == VTM_F16 || dtype == VTM_BF16, "vtm_match_filtered: bad dtype");
     {
@@ -993,7 +1071,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         const int64_t grid = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit;
         hipLaunchKernelGGL(filter_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
                            L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles, amax,
-                           cnt, cand, flags);
+                           cnt, cand, (int)rows_out, flags);
     }
     {
         hipLaunchKernelGGL(survivors_kernel, dim3((unsigned)vtm::cdiv(rows_out, 256)), dim3(256), 0, s, rows_out, amax, cnt,
