@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--n", type=int, default=49152)
     ap.add_argument("--align", action="store_true")
     ap.add_argument("--C", type=int, default=320)
+    ap.add_argument("--data", default="random", choices=["random", "zeros", "const"], help="attn: operand values")
     a = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
@@ -73,9 +74,14 @@ def main():
         Mp = (M + 7) // 8 * 8
         qk = torch.randn(B, Mp, 2 * C, generator=g, device=dev, dtype=torch.float16)
         vt = torch.randn(B, C, Mp, generator=g, device=dev, dtype=torch.float16)
+        if a.data != "random":       # how much of the time is the operands' switching activity (power-limited clock)?
+            qk = torch.zeros_like(qk) if a.data == "zeros" else torch.full_like(qk, 0.25)
+            vt = torch.zeros_like(vt) if a.data == "zeros" else torch.full_like(vt, 0.25)
         if a.Mq:
             Mq = a.Mq
             q = torch.randn(B, (Mq + 7) // 8 * 8, C, generator=g, device=dev, dtype=torch.float16)
+            if a.data != "random":
+                q = torch.zeros_like(q) if a.data == "zeros" else torch.full_like(q, 0.25)
             med, best = timeit(lambda: _lib.attention_kv(q, qk[:, :, C:], vt, h, Mq, M, d ** -0.5), a.iters)
         else:
             Mq = M
