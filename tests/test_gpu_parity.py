@@ -191,6 +191,19 @@ def test_match_filtered_hard_cases(L):
     xs = xf.clone()
     xs[1, Ns + 3] *= 3e31
     _filtered_vs_exact(L, xs.to(DEV), Ns, Nd, True, expect_flag=1)
+    # (4c) fp32 / bf16 rows with components 25-40 orders of magnitude below the rest: the refine pass divides by a per-row
+    #      reciprocal only where that is bit-identical to x / norm (|x| >= 2^-102 and x / norm >= 2^-124) and falls back to the
+    #      IEEE division element group by element group elsewhere
+    for dt in (torch.float32, torch.bfloat16):
+        xs = torch.randn(B, Ns + Nd, C, generator=g)
+        tiny = torch.tensor([1e-25, 1e-30, 1e-36, 3e-38, 1e-40, 0.0])
+        for r in range(0, Ns + Nd, 7):
+            xs[:, r, (r * 5) % C] = tiny[r % 6]
+            xs[:, r, (r * 11 + 3) % C] = -tiny[(r + 2) % 6]
+        xs[0, 11] *= 1e-12
+        xs[1, Ns + 9] *= 1e10
+        _filtered_vs_exact(L, xs.to(dt).to(DEV), Ns, Nd, False, expect_flag=0)
+        _filtered_vs_exact(L, xs.to(dt).to(DEV), Ns, Nd, True, expect_flag=0)
     # (5) candidate overflow: every dst row identical -> more than 32 candidates per row -> those rows are
     #     recomputed by the exact row pass (no whole-call fallback)
     x = torch.randn(B, Ns + Nd, C, generator=g).half()
