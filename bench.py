@@ -398,7 +398,10 @@ def main():
                          # the top-block launches alone (compare with attention_kernel<half,40> in profiles/*_kernel_stats.txt)
                          "top_block": {"launches": top_n, "avg_ms": round(top_ms, 4),
                                        "tflops": round(top_flops / (top_ms * 1e-3) / 1e12, 1) if top_ms > 0 else 0.0},
-                         "attention_ms_per_step": round(ams / args.steps, 3)},
+                         "attention_ms_per_step": round(ams / args.steps, 3),
+                         "note": "power-limited: with these (random) operand values the kernel runs at the 1400 W package cap, "
+                                 "sclk ~1.95 GHz; the same launch with non-toggling operands reaches 1 130-1 166 TFLOP/s = the floor "
+                                 "of its instruction mix (profiles/r02_ubench.txt, DESIGN.md section 10)"},
             # the fused similarity + top-1 step (second largest).  The filtered matcher executes the reference's
             # 2 B Ns Nd C flops ONCE on the fp16 MFMA (one-product filter) and re-evaluates the few surviving pairs in
             # fp32: its roof is the fp16 MFMA peak.  The exact fallback kernel runs on the fp32 MFMA (157.3 TFLOP/s).
