@@ -415,7 +415,7 @@ def main():
             # cfg-2 working sets (<= 212 MB) fit the 256 MB Infinity Cache, so `pmc` carries the counter-derived rates
             # measured beyond it
             # q / k / v^T / out projections: GEMMs whose A rows are gathered through the composed merge map
-            "projections": (lambda f, ms, n: {"kernel": "linear_rows_kernel (vtm_linear_rows, fp16 MFMA)", "launches": n,
+            "projections": (lambda f, ms, n: {"kernel": "linear_rows_ws_kernel / linear_rows_kernel (vtm_linear_rows, fp16 MFMA)", "launches": n,
                                               "ms_per_step": round(ms / args.steps, 3),
                                               "tflops": round(f / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0})(
                 *mt.summary("projections")),

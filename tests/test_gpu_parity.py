@@ -588,7 +588,10 @@ def test_geglu_vs_torch_fp32(L, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,P0,P1,K,N,n", [(2, 300, 100, 64, 96, 257), (1, 128, 0, 32, 128, 128), (3, 50, 77, 320, 320, 91),
-                                            (2, 4096, 1000, 640, 640, 3000)])
+                                            (2, 4096, 1000, 640, 640, 3000),
+                                            # K = 320: the weight-stationary kernel -- several blocks per wave, ragged last block,
+                                            # more than one 160-channel half per sample
+                                            (2, 60000, 3000, 320, 320, 40013), (1, 2000, 0, 320, 640, 1500)])
 def test_linear_rows_vs_torch_fp32(L, dtype, B, P0, P1, K, N, n):
     """vtm_linear_rows = Linear(gather(pool, rows)): both output layouts, one- and two-level maps, bias, ragged tiles."""
     g = torch.Generator().manual_seed(K + n)

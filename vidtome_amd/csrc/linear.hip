@@ -24,6 +24,9 @@
 // registers per lane.
 #include "common.h"
 
+#include <atomic>
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -320,10 +323,215 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
     }
 }
 
+// ---- K = 320 (the cfg-2 / cfg-5 top blocks: 3 of a step's 4 projection GEMMs per site): weights stay in LDS --------------
+// A 128 x 160 tile of the kernel above re-stages its 100 KB weight half for every 128 tokens (4 barrier-separated steps whose
+// 400 ns of MFMAs cannot cover a global-memory round trip): 69 us where the traffic floor is 27.  Here a workgroup (8 waves,
+// one per CU) loads ITS half of W (160 output channels x 320, 105 KB with padding) once and keeps it; after that its waves
+// are independent -- no barrier in the loop: each wave takes 32-token blocks (block w, w + 8, ... of the workgroup's span),
+// fetches their operand fragments straight from global memory half a block ahead (2 x 10 k-steps = 80 VGPRs), runs the
+// 100 MFMAs of a block against LDS fragments, and writes the block out through a small LDS staging area of its own
+// (16-byte pieces of whole rows, as above).  LDS fragment reads and MFMAs are 1 : 1 (32 tokens per wave: the 64-token
+// variant does not fit next to 80 accumulator registers), which is what bounds it.
+constexpr int WS_K = 320, WS_TN = 160, WS_NT = 512, WS_LDW = WS_K + 8;   // 164 words per row = 4 x odd: conflict-free b128
+constexpr int WS_W_BYTES = WS_TN * WS_LDW * 2;
+constexpr int WS_STAGE_TOK = 16 * (WS_TN + 8) * 2;   // per wave: 16 tokens x 168 elements (token-major phase); the channel-major
+                                                     // phase (32 channels x 40 elements) fits inside
+constexpr int WS_LDS_BYTES = WS_W_BYTES + 8 * WS_STAGE_TOK;
+
+template <typename T, bool TRANS>
+__global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
+    const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1, int64_t P1, const int32_t *__restrict__ rows,
+    int64_t rows_ld, const int32_t *__restrict__ rows2, int64_t n, const T *__restrict__ W, const T *__restrict__ bias,
+    int64_t N, T *__restrict__ out, int64_t ldo, int64_t out_batch_stride, int blocks_per_wave, int spans, int64_t B) {
+    using M = Mma<T>;
+    using vec = typename M::vec;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *sW = reinterpret_cast<T *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    // Workgroup -> (row span, channel half, sample).  Every half of a row span reads the same token rows: the halves of a span
+    // are placed on the SAME XCD (workgroup L runs on XCD L % 8), next to each other in dispatch order, so that the second reader
+    // finds the rows in that XCD's L2 instead of fetching them from HBM again (two 160-channel halves = twice the operand bytes).
+    const int halves = (int)(N / WS_TN);
+    const int64_t slot = blockIdx.x >> 3, q = (slot / halves) * 8 + (blockIdx.x & 7);
+    if (q >= (int64_t)spans * B) return;
+    const int64_t n0 = (slot % halves) * WS_TN, b = q / spans, span = q % spans;
+    T *stage = reinterpret_cast<T *>(smem + WS_W_BYTES + wave * WS_STAGE_TOK);
+
+    // the workgroup's weight half: 160 rows x 40 pieces of 16 bytes
+    for (int c = tid; c < WS_TN * (WS_K / 8); c += WS_NT) {
+        const int r = c / (WS_K / 8), piece = c % (WS_K / 8);
+        *reinterpret_cast<u32x4 *>(&sW[r * WS_LDW + piece * 8]) =
+            *reinterpret_cast<const u32x4 *>(W + (n0 + r) * WS_K + piece * 8);
+    }
+    __syncthreads();
+
+    const int64_t RB = (n + 31) / 32;
+    const int64_t blk0 = span * blocks_per_wave * 8 + wave;                  // this wave: blk0, blk0 + 8, ...
+    if (blk0 >= RB) return;                                                  // (no barrier below)
+    int nblk = (int)((RB - blk0 + 7) / 8);
+    if (nblk > blocks_per_wave) nblk = blocks_per_wave;
+
+    auto row_ptr = [&](int64_t blk) -> const T * {
+        int64_t t = blk * 32 + l31;
+        if (t >= n) t = n - 1;                            // surplus rows recompute the last one; never stored
+        int64_t p = rows2 ? rows2[b * n + t] : t;
+        if (rows) p = rows[b * rows_ld + p];
+        return (p < P0 ? x0 + (b * P0 + p) * WS_K : x1 + (b * P1 + (p - P0)) * WS_K) + hi * 8;
+    };
+    vec a[2][10];                                         // the two K-halves of a block: 10 k-steps each
+    auto load_half = [&](const T *xr, int c) {
+#pragma unroll
+        for (int f = 0; f < 10; ++f) {
+#ifdef VTM_LIN_NOA
+            for (int e = 0; e < 8; ++e) a[c][f][e] = (decltype(a[c][f][e] + a[c][f][e]))(f + c);
+#else
+            a[c][f] = *reinterpret_cast<const vec *>(xr + (c * 10 + f) * 16);
+#endif
+        }
+    };
+    const T *xr = row_ptr(blk0);
+    load_half(xr, 0);
+    load_half(xr, 1);
+
+    T *ob = out + b * out_batch_stride;
+    const T *pw = &sW[l31 * WS_LDW + hi * 8];
+    for (int i = 0; i < nblk; ++i) {
+        const int64_t blk = blk0 + 8 * i;
+        // the last block re-fetches itself (never used): a fixed issue sequence keeps the compiler's waits counted
+        const T *xn = row_ptr(i + 1 < nblk ? blk + 8 : blk);
+        f32x16 acc[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int kk = 0; kk < 10; ++kk) {
+                vec fw[5];
+#pragma unroll
+#ifdef VTM_LIN_NOLDS
+                for (int j = 0; j < 5; ++j) fw[j] = a[c][(kk + j) % 10];
+#else
+                for (int j = 0; j < 5; ++j) fw[j] = *reinterpret_cast<const vec *>(pw + j * 32 * WS_LDW + (c * 10 + kk) * 16);
+#endif
+                const vec fx = a[c][kk];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    if constexpr (TRANS) acc[j] = M::run(fx, fw[j], acc[j]);   // rows = tokens, cols = channels
+                    else acc[j] = M::run(fw[j], fx, acc[j]);                   // rows = channels, cols = tokens
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_half(xn, c);                             // the next block's half into the registers this one just freed
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        const int64_t tok0 = blk * 32;
+#ifdef VTM_LIN_NOSTORE
+        if (acc[0][0] != 12345.678f) continue;
+#endif
+        if constexpr (!TRANS) {
+            constexpr int SO = WS_TN + 8;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {              // 16 tokens at a time
+                if ((l31 >> 4) == ph) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int rr = 8 * g + 4 * hi;
+                            const int64_t ch = n0 + 32 * j + rr;
+                            T w4[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) w4[e] = M::cvt(acc[j][4 * g + e] + (bias ? vtm::to_f32(bias[ch + e]) : 0.0f));
+                            *reinterpret_cast<uint2 *>(stage + (l31 & 15) * SO + 32 * j + rr) = *reinterpret_cast<const uint2 *>(w4);
+                        }
+                }
+                __builtin_amdgcn_wave_barrier();          // LDS is FIFO per wave: the reads below see the writes above
+                constexpr int PR = WS_TN / 8;             // 20 pieces per token row; 16 x 20 = 5 wave-instructions
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    const int p = lane + 64 * it;
+                    const int row = p / PR, c8 = (p % PR) * 8;
+                    const int64_t tok = tok0 + 16 * ph + row;
+                    if (tok < n)
+                        *reinterpret_cast<uint4 *>(ob + tok * ldo + n0 + c8) = *reinterpret_cast<const uint4 *>(stage + row * SO + c8);
+                }
+                __builtin_amdgcn_wave_barrier();          // ... and the next phase's writes follow these reads
+            }
+        } else {
+            constexpr int SO = 32 + 8;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {                 // 32 channels at a time
+                const int64_t ch = n0 + 32 * j + l31;
+                const float bv = bias ? vtm::to_f32(bias[ch]) : 0.0f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    T w4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w4[e] = M::cvt(acc[j][4 * g + e] + bv);
+                    *reinterpret_cast<uint2 *>(stage + l31 * SO + 8 * g + 4 * hi) = *reinterpret_cast<const uint2 *>(w4);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {          // 32 channel rows x 4 pieces of 8 tokens
+                    const int p = lane + 64 * it;
+                    const int row = p >> 2, c8 = (p & 3) * 8;
+                    const int64_t tok = tok0 + c8;
+                    if (tok < n) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(stage + row * SO + c8);
+                        T *dst = ob + (n0 + 32 * j + row) * ldo + tok;
+                        if (tok + 8 <= n) {
+                            *reinterpret_cast<uint4 *>(dst) = v;
+                        } else {
+                            const T *e8 = reinterpret_cast<const T *>(&v);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (tok + e < n) dst[e] = e8[e];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+template <typename T, bool TRANS>
+int launch_ws(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, const int32_t *rows, int64_t rows_ld,
+              const int32_t *rows2, int64_t n, const void *W, const void *bias, int64_t N, void *out, int64_t ldo, int64_t obs,
+              hipStream_t s) {
+    static std::atomic<bool> attr_set[vtm::MAX_DEVICES];
+    const int dev = vtm::current_device();
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_rows_ws_kernel<T, TRANS>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+        if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_linear_rows: LDS attribute: %s", hipGetErrorString(e));
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    // every wave gets the same number of 32-token blocks, as few as fill the chip's CUs once
+    const int64_t RB = vtm::cdiv(n, 32), halves = N / WS_TN;
+    int64_t bpw = vtm::cdiv(RB * halves * B, (int64_t)vtm::device_cus() * 8);
+    if (bpw < 1) bpw = 1;
+    const int64_t spans = vtm::cdiv(RB, 8 * bpw);                      // row spans per sample
+    const dim3 grid((unsigned)(8 * vtm::cdiv(spans * B, 8) * halves)), block(WS_NT);
+    hipLaunchKernelGGL((linear_rows_ws_kernel<T, TRANS>), grid, block, WS_LDS_BYTES, s, (const T *)x0, P0, (const T *)x1, P1,
+                       rows, rows_ld, rows2, n, (const T *)W, (const T *)bias, N, (T *)out, ldo, obs, (int)bpw, (int)spans, B);
+    return vtm::launch_status("vtm_linear_rows");
+}
+
 template <typename T>
 int launch(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, int64_t K, const int32_t *rows,
            int64_t rows_ld, const int32_t *rows2, int64_t n, const void *W, const void *bias, int64_t N, void *out,
            int64_t ldo, int64_t obs, int transposed, hipStream_t s) {
+    // K = 320 with whole 160-channel halves and 16-byte-aligned output rows: the weight-stationary kernel
+    if (K == WS_K && N % WS_TN == 0 && (ldo & 7) == 0 && (obs & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+        vtm::cdiv(n, 32) * B * (N / WS_TN) < (1ll << 30) && !getenv("VTM_LINEAR_TILED")) {
+        return transposed ? launch_ws<T, true>(x0, P0, x1, P1, B, rows, rows_ld, rows2, n, W, bias, N, out, ldo, obs, s)
+                          : launch_ws<T, false>(x0, P0, x1, P1, B, rows, rows_ld, rows2, n, W, bias, N, out, ldo, obs, s);
+    }
     const int tn = (N % 160 == 0) ? 160 : 128;
     const dim3 grid((unsigned)vtm::cdiv(n, TM), (unsigned)vtm::cdiv(N, tn), (unsigned)B), block(NT);
 #define VTM_LIN(TR, CH_, TKW_, PAIRS_, TN_)                                                                            \
