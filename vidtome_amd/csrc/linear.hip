@@ -332,11 +332,20 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
 // 100 MFMAs of a block against LDS fragments, and writes the block out through a small LDS staging area of its own
 // (16-byte pieces of whole rows, as above).  LDS fragment reads and MFMAs are 1 : 1 (32 tokens per wave: the 64-token
 // variant does not fit next to 80 accumulator registers), which is what bounds it.
-constexpr int WS_K = 320, WS_TN = 160, WS_NT = 512, WS_LDW = WS_K + 8;   // 164 words per row = 4 x odd: conflict-free b128
+constexpr int WS_K = 320, WS_TN = 160, WS_LDW = WS_K + 8;   // 164 words per row = 4 x odd: conflict-free b128
 constexpr int WS_W_BYTES = WS_TN * WS_LDW * 2;
-constexpr int WS_STAGE_TOK = 16 * (WS_TN + 8) * 2;   // per wave: 16 tokens x 168 elements (token-major phase); the channel-major
-                                                     // phase (32 channels x 40 elements) fits inside
-constexpr int WS_LDS_BYTES = WS_W_BYTES + 8 * WS_STAGE_TOK;
+#ifndef VTM_WS_WAVES
+#define VTM_WS_WAVES 8
+#endif
+constexpr int WS_NW = VTM_WS_WAVES;                  // waves per workgroup: 8 (two per SIMD) or 12 (three, <= 168 VGPRs)
+constexpr int WS_NT = 64 * WS_NW;
+constexpr int WS_KCH = WS_NW == 8 ? 10 : 5;          // k-steps per operand chunk (two chunks in registers)
+constexpr int WS_NC = 20 / WS_KCH;
+constexpr int WS_TP = WS_NW == 8 ? 16 : 8;           // tokens per staging phase
+constexpr int WS_STAGE_TOK = WS_TP * (WS_TN + 8) * 2;   // per wave: WS_TP tokens x 168 elements (token-major phase); the
+                                                        // channel-major phase (32 channels x 40 elements = 2560 B) fits inside
+static_assert(WS_STAGE_TOK >= 32 * 40 * 2, "channel-major staging");
+constexpr int WS_LDS_BYTES = WS_W_BYTES + WS_NW * WS_STAGE_TOK;
 
 template <typename T, bool TRANS>
 __global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
@@ -367,9 +376,9 @@ __global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
     __syncthreads();
 
     const int64_t RB = (n + 31) / 32;
-    const int64_t blk0 = span * blocks_per_wave * 8 + wave;                  // this wave: blk0, blk0 + 8, ...
+    const int64_t blk0 = span * blocks_per_wave * WS_NW + wave;              // this wave: blk0, blk0 + WS_NW, ...
     if (blk0 >= RB) return;                                                  // (no barrier below)
-    int nblk = (int)((RB - blk0 + 7) / 8);
+    int nblk = (int)((RB - blk0 + WS_NW - 1) / WS_NW);
     if (nblk > blocks_per_wave) nblk = blocks_per_wave;
 
     auto row_ptr = [&](int64_t blk) -> const T * {
@@ -379,44 +388,44 @@ __global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
         if (rows) p = rows[b * rows_ld + p];
         return (p < P0 ? x0 + (b * P0 + p) * WS_K : x1 + (b * P1 + (p - P0)) * WS_K) + hi * 8;
     };
-    vec a[2][10];                                         // the two K-halves of a block: 10 k-steps each
-    auto load_half = [&](const T *xr, int c) {
+    vec a[2][WS_KCH];                                     // two operand chunks of WS_KCH k-steps: this one and the next
+    auto load_chunk = [&](const T *xr, int c) {           // chunk c of a block into buffer c & 1
 #pragma unroll
-        for (int f = 0; f < 10; ++f) {
+        for (int f = 0; f < WS_KCH; ++f) {
 #ifdef VTM_LIN_NOA
-            for (int e = 0; e < 8; ++e) a[c][f][e] = (decltype(a[c][f][e] + a[c][f][e]))(f + c);
+            for (int e = 0; e < 8; ++e) a[c & 1][f][e] = (decltype(a[c & 1][f][e] + a[c & 1][f][e]))(f + c);
 #else
-            a[c][f] = *reinterpret_cast<const vec *>(xr + (c * 10 + f) * 16);
+            a[c & 1][f] = *reinterpret_cast<const vec *>(xr + (c * WS_KCH + f) * 16);
 #endif
         }
     };
     const T *xr = row_ptr(blk0);
-    load_half(xr, 0);
-    load_half(xr, 1);
+    load_chunk(xr, 0);
+    load_chunk(xr, 1);
 
     T *ob = out + b * out_batch_stride;
     const T *pw = &sW[l31 * WS_LDW + hi * 8];
     for (int i = 0; i < nblk; ++i) {
-        const int64_t blk = blk0 + 8 * i;
+        const int64_t blk = blk0 + WS_NW * i;
         // the last block re-fetches itself (never used): a fixed issue sequence keeps the compiler's waits counted
-        const T *xn = row_ptr(i + 1 < nblk ? blk + 8 : blk);
+        const T *xn = row_ptr(i + 1 < nblk ? blk + WS_NW : blk);
         f32x16 acc[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < WS_NC; ++c) {
 #pragma unroll
-            for (int kk = 0; kk < 10; ++kk) {
+            for (int kk = 0; kk < WS_KCH; ++kk) {
                 vec fw[5];
 #pragma unroll
 #ifdef VTM_LIN_NOLDS
-                for (int j = 0; j < 5; ++j) fw[j] = a[c][(kk + j) % 10];
+                for (int j = 0; j < 5; ++j) fw[j] = a[c & 1][(kk + j) % WS_KCH];
 #else
-                for (int j = 0; j < 5; ++j) fw[j] = *reinterpret_cast<const vec *>(pw + j * 32 * WS_LDW + (c * 10 + kk) * 16);
+                for (int j = 0; j < 5; ++j) fw[j] = *reinterpret_cast<const vec *>(pw + j * 32 * WS_LDW + (c * WS_KCH + kk) * 16);
 #endif
-                const vec fx = a[c][kk];
+                const vec fx = a[c & 1][kk];
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                     if constexpr (TRANS) acc[j] = M::run(fx, fw[j], acc[j]);   // rows = tokens, cols = channels
@@ -424,7 +433,9 @@ __global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            load_half(xn, c);                             // the next block's half into the registers this one just freed
+            // two chunks ahead, into the registers this one just freed: the rest of this block, then the next block's
+            if (c + 2 < WS_NC) load_chunk(xr, c + 2);
+            else load_chunk(xn, c + 2 - WS_NC);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -435,8 +446,8 @@ __global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
         if constexpr (!TRANS) {
             constexpr int SO = WS_TN + 8;
 #pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {              // 16 tokens at a time
-                if ((l31 >> 4) == ph) {
+            for (int ph = 0; ph < 32 / WS_TP; ++ph) {     // WS_TP tokens at a time
+                if (l31 / WS_TP == ph) {
 #pragma unroll
                     for (int j = 0; j < 5; ++j)
 #pragma unroll
@@ -446,17 +457,17 @@ __global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
                             T w4[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) w4[e] = M::cvt(acc[j][4 * g + e] + (bias ? vtm::to_f32(bias[ch + e]) : 0.0f));
-                            *reinterpret_cast<uint2 *>(stage + (l31 & 15) * SO + 32 * j + rr) = *reinterpret_cast<const uint2 *>(w4);
+                            *reinterpret_cast<uint2 *>(stage + (l31 % WS_TP) * SO + 32 * j + rr) = *reinterpret_cast<const uint2 *>(w4);
                         }
                 }
                 __builtin_amdgcn_wave_barrier();          // LDS is FIFO per wave: the reads below see the writes above
-                constexpr int PR = WS_TN / 8;             // 20 pieces per token row; 16 x 20 = 5 wave-instructions
+                constexpr int PR = WS_TN / 8;             // 20 pieces per token row
 #pragma unroll
-                for (int it = 0; it < 5; ++it) {
+                for (int it = 0; it < (WS_TP * PR + 63) / 64; ++it) {
                     const int p = lane + 64 * it;
                     const int row = p / PR, c8 = (p % PR) * 8;
-                    const int64_t tok = tok0 + 16 * ph + row;
-                    if (tok < n)
+                    const int64_t tok = tok0 + WS_TP * ph + row;
+                    if (row < WS_TP && tok < n)
                         *reinterpret_cast<uint4 *>(ob + tok * ldo + n0 + c8) = *reinterpret_cast<const uint4 *>(stage + row * SO + c8);
                 }
                 __builtin_amdgcn_wave_barrier();          // ... and the next phase's writes follow these reads
@@ -496,6 +507,7 @@ __global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        xr = xn;
     }
 }
 
@@ -513,9 +525,9 @@ int launch_ws(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B,
     }
     // every wave gets the same number of 32-token blocks, as few as fill the chip's CUs once
     const int64_t RB = vtm::cdiv(n, 32), halves = N / WS_TN;
-    int64_t bpw = vtm::cdiv(RB * halves * B, (int64_t)vtm::device_cus() * 8);
+    int64_t bpw = vtm::cdiv(RB * halves * B, (int64_t)vtm::device_cus() * WS_NW);
     if (bpw < 1) bpw = 1;
-    const int64_t spans = vtm::cdiv(RB, 8 * bpw);                      // row spans per sample
+    const int64_t spans = vtm::cdiv(RB, WS_NW * bpw);                  // row spans per sample
     const dim3 grid((unsigned)(8 * vtm::cdiv(spans * B, 8) * halves)), block(WS_NT);
     hipLaunchKernelGGL((linear_rows_ws_kernel<T, TRANS>), grid, block, WS_LDS_BYTES, s, (const T *)x0, P0, (const T *)x1, P1,
                        rows, rows_ld, rows2, n, (const T *)W, (const T *)bias, N, (T *)out, ldo, obs, (int)bpw, (int)spans, B);
