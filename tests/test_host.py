@@ -49,8 +49,9 @@ def test_hot_kernels_keep_their_register_budget(built):
         assert v["vgpr_count"] <= 256, (k, v)
     for k, v in only("16attention_kernel", "Li40E").items():      # half and bf16
         assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
-    for k, v in only("linear_rows_kernel").items():
-        assert v["vgpr_count"] <= 256 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+    for name in ("linear_rows_kernel", "linear_rows_ws_kernel"):
+        for k, v in only(name).items():
+            assert v["vgpr_count"] <= 256 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
 
 
 def test_partition_counts_match_reference_arithmetic(built, oracle):
