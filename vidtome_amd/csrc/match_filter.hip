@@ -699,6 +699,10 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                 await_b(std::integral_constant<int, COUNT>{}, rb[s]);
 #endif
             }
+            // the maxima fetched one step ago (X) are older than the fragments just awaited: only NOW have they certainly
+            // landed.  Keeping their registers "in use" up to this point stops the compiler from handing them out while the
+            // load is still in flight on the paths that never read them (every step that does not end a tile)
+            if constexpr (s == 1) asm volatile("" : : "v"(am[0]), "v"(am[1]));
             h16x8 (&fh)[4] = fa[s & 1];
             h16x8 (&fn)[4] = fa[(s + 1) & 1];
 #pragma unroll
