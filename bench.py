@@ -10,7 +10,15 @@ transformer-block sites (10 merged: 5x N=4096/C=320/d=40 and 5x N=1024/C=640/d=8
 batch 2 (CFG [uncond | cond]) x 16 frames, local merge 0.5 + global merge 0.5 in steady state (the
 block's anchor tokens were populated by a preceding chunk, as for every chunk but the first of a step).
 Synthetic fp16 hidden states (frame-correlated), random-init weights; inputs are resident in HBM before
-the timed region.  N > 1: one process per GPU, each rank runs its own chunk (weak scaling); local merging needs
+the timed region.  The passes rotate over `--chunks` (3) distinct chunks of ONE synthetic clip (shared per-sample base,
+independent frame noise), so every pass merges against anchor tokens that came from a DIFFERENT chunk -- the regime of
+generate.py:215-219 (`--same-chunk` = rounds 1-2's regime: one chunk fed to every pass, whose anchors are then copies of
+its own rows; kept for the A/B under profiles/).  HIP events are recorded around the hot launches on every
+`--event-every`-th timed pass only (the other passes run event-free); a background thread samples the GPU's shader
+clock and package power during the timed region.
+`python bench.py --gpus N` with N > 1 and no launcher starts its N ranks itself (one process per GPU, RCCL, rendezvous
+on 127.0.0.1); under torchrun it uses the RANK / LOCAL_RANK / WORLD_SIZE it is given.
+N > 1: one process per GPU, each rank runs its own chunk (weak scaling); local merging needs
 no collective, the global level takes its anchor tokens from the previous rank's chunk (chunk_parallel.py:
 `--exchange neighbour` = point-to-point shift of every rank's local merged tokens over one xGMI link, the default;
 `allgather` = the same semantics through an RCCL all-gather per merging block; `ring` = the exact serial chain);
@@ -27,9 +35,13 @@ The JSON line also carries
                 gather + SDPA, fp32) TIMED on this host's cores on one full site of every kind and summed to a step.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -50,8 +62,8 @@ LOCAL_RATIO, GLOBAL_RATIO = 0.5, 0.5
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=150.0,
                     help="time budget of the CPU baseline: a top site whose full batch would not fit is timed on one "
@@ -61,7 +73,104 @@ def parse():
     ap.add_argument("--exchange", choices=["neighbour", "allgather", "ring"], default="neighbour",
                     help="N > 1: how the global level gets its anchor tokens (chunk_parallel.py)")
     ap.add_argument("--local-only", action="store_true", help="merge_global=False variant (not the headline)")
+    ap.add_argument("--chunks", type=int, default=3,
+                    help="distinct chunks of the synthetic clip the passes rotate over (anchors come from another chunk)")
+    ap.add_argument("--same-chunk", action="store_true",
+                    help="rounds 1-2's regime: every pass processes the same chunk (anchors = copies of its own rows)")
+    ap.add_argument("--event-every", type=int, default=5,
+                    help="record HIP events around the hot launches on every k-th timed pass (the others are event-free)")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and wait for them.
+    Rank 0 prints the JSON line on the inherited stdout.  Returns the first non-zero exit code (the other ranks are
+    then terminated by PID), 0 otherwise."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VIDTOME_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:                      # a rank died: do not leave the others in a collective
+                    other.terminate()
+    return rc
+
+
+class BoxSampler(threading.Thread):
+    """Shader clock and package power of the GPU this rank runs on, sampled from sysfs (amdgpu hwmon) during the
+    timed region: the dominant kernels are power-limited, so the number belongs next to the
+    roofline fraction -- measured on THIS box, in THIS run."""
+
+    def __init__(self, device_index: int, period_s: float = 0.05):
+        super().__init__(daemon=True)
+        self.period = period_s
+        self.samples = []
+        self._halt = threading.Event()
+        self.files = self._find(device_index)
+
+    @staticmethod
+    def _find(device_index: int):
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except Exception:
+            pass
+        cands = []
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            devp = os.path.realpath(os.path.join(card, "device"))
+            for hw in glob.glob(os.path.join(devp, "hwmon", "hwmon*")):
+                pw = next((f for f in (os.path.join(hw, n) for n in ("power1_average", "power1_input")) if os.path.exists(f)), None)
+                fq = os.path.join(hw, "freq1_input")
+                if pw or os.path.exists(fq):
+                    cands.append((devp, pw, fq if os.path.exists(fq) else None))
+        if not cands:
+            return None
+        for devp, pw, fq in cands:
+            if want and want in devp:
+                return pw, fq
+        return cands[min(device_index, len(cands) - 1)][1:]
+
+    def run(self):
+        if not self.files:
+            return
+        pw, fq = self.files
+        while not self._halt.is_set():
+            try:
+                w = int(open(pw).read()) / 1e6 if pw else None
+                f = int(open(fq).read()) / 1e6 if fq else None
+                self.samples.append((w, f))
+            except Exception:
+                pass
+            self._halt.wait(self.period)
+
+    def stop(self):
+        self._halt.set()
+        if self.is_alive():
+            self.join(timeout=2.0)
+        if not self.samples:
+            return None
+        out = {"samples": len(self.samples), "period_ms": self.period * 1e3, "source": "sysfs amdgpu hwmon (power1_average, freq1_input)"}
+        for name, idx in (("power_w", 0), ("sclk_mhz", 1)):
+            v = [s_[idx] for s_ in self.samples if s_[idx] is not None]
+            if v:
+                out[name] = {"mean": round(sum(v) / len(v), 1), "min": round(min(v), 1), "max": round(max(v), 1)}
+        return out
 
 
 class KernelTimer:
@@ -267,6 +376,8 @@ def cpu_baseline_torch(budget_s: float):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -277,6 +388,11 @@ def main():
     backend = os.environ.get("VIDTOME_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{local_rank} but this node has {torch.cuda.device_count()} "
+                         f"GPU(s) (one process per GPU over RCCL)")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -284,7 +400,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)    # backend "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import vidtome_amd
     from vidtome_amd import _lib, sites
@@ -294,6 +409,7 @@ def main():
                             global_merge_ratio=GLOBAL_RATIO, batch_size=BATCH, target_stride=4, global_rand=0.5)
     unet.set_size(LATENT)
     total_passes = 1 + args.warmup + args.steps
+    torch.manual_seed(123)           # the block generators fork this state (default.yaml seed)
     ex = None
     if world > 1 and not args.local_only:
         # every rank owns one chunk per pass; per merging block the global level takes its anchor tokens from the
@@ -303,18 +419,29 @@ def main():
         ex = cp.AnchorExchange(args.exchange)
         cp.enable(unet, ex)
         ex.begin_step([FRAMES] * (total_passes * world))
-    torch.manual_seed(123)           # the block generators fork this state (default.yaml seed)
-    # each rank works on its own chunk of the video: different synthetic frames per rank
-    hiddens = [sites.synthetic_hidden(s, BATCH, FRAMES, LATENT, torch.float16, dev, seed=1234 + 97 * rank + i)
-               for i, s in enumerate(sites.sd15_sites())]
+    # The run is one stream of chunks of ONE synthetic clip: chunk c = pass * world + rank holds frame set c % K
+    # (per-sample base shared by all sets, independent frame noise), so the anchor tokens a chunk merges against always
+    # come from a different chunk, at every N.  --same-chunk: one set per rank, fed to every pass (rounds 1-2).
+    K = 1 if args.same_chunk else max(2, args.chunks)
+    site_list = sites.sd15_sites()
+
+    def make_set(j):
+        if args.same_chunk:
+            return [sites.synthetic_hidden(s, BATCH, FRAMES, LATENT, torch.float16, dev, seed=1234 + 97 * rank + i)
+                    for i, s in enumerate(site_list)]
+        return [sites.synthetic_hidden(s, BATCH, FRAMES, LATENT, torch.float16, dev, seed=1234 + 97 * j + i,
+                                       clip_seed=4321 + i) for i, s in enumerate(site_list)]
+
+    sets = {j: make_set(j) for j in sorted({(p_ * world + rank) % K for p_ in range(total_passes)})}
     passes = [0]
 
     def step():
+        c = passes[0] * world + rank
         if ex is not None:
-            ex.begin_chunk(passes[0] * world + rank)
+            ex.begin_chunk(c)
         passes[0] += 1
         with torch.no_grad():
-            return sites.run_segment_pass(unet, hiddens)
+            return sites.run_segment_pass(unet, sets[c % K])
 
     def fence():
         torch.cuda.synchronize()
@@ -325,20 +452,30 @@ def main():
     step()                            # preceding chunk: populates the anchor tokens (steady state)
     for _ in range(args.warmup):
         step()
+    every = max(1, args.event_every)
+    sampler = BoxSampler(local_rank) if rank == 0 else None
     with KernelTimer(_lib) as mt:
-        mt.enabled = True
         fence()
+        if sampler is not None:
+            sampler.start()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            mt.enabled = i % every == 0           # HIP events on every k-th pass only
             step()
+        mt.enabled = False
         fence()
         dt = time.perf_counter() - t0
+    box = sampler.stop() if sampler is not None else None
     if ex is not None:
         ex.end_step()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    # (gloo -- the test hook -- moves host tensors)
+    mine = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    per_rank = [mine.clone() for _ in range(world)]
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_gather(per_rank, mine)
+    per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in per_rank]
+    dt = max(float(t.item()) for t in per_rank)      # MAX over ranks
+    timed_passes = len(range(0, args.steps, every))
     aflops, ams, an = mt.summary("attention")
     top_flops, top_ms, top_n = mt.largest("attention")
     mflops, mms, mn = mt.summary("matching")
@@ -357,7 +494,7 @@ def main():
             by, ms, n = mt.summary(kind)
             tb_, tms, tn = mt.largest(kind)
             rate = lambda b_, m_: round(b_ / (m_ * 1e-3) / 1e9, 1) if m_ > 0 else 0.0
-            return {"launches": n, "ms_per_step": round(ms / args.steps, 3), "GBps": rate(by, ms),
+            return {"launches": n, "ms_per_step": round(ms / timed_passes, 3), "GBps": rate(by, ms),
                     "largest": {"launches": tn, "MB": round(tb_ / 1e6, 1), "avg_us": round(tms * 1e3, 1),
                                 "GBps": rate(tb_, tms), "frac_of_hbm_peak": round(rate(tb_, tms) / HBM_PEAK_GBPS, 3)}}
 
@@ -372,6 +509,12 @@ def main():
             "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
+            # what the communicator reports, and every rank's own time per step (value uses the slowest)
+            "ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
+            "launcher": os.environ.get("VIDTOME_BENCH_LAUNCHER", "torchrun/env" if "WORLD_SIZE" in os.environ else "single process"),
+            "per_rank_ms_per_step": per_rank_ms,
+            "box": box,
             # the arithmetic types of the path: tokens fp16; matching = fp16-MFMA candidate filter + fp32 exact
             # refinement (result bit-identical to an all-fp32 matcher); attention = fp16 MFMA, fp32 accumulate / softmax
             "dtype": "f16 tokens; matching f16-MFMA filter + f32 exact refine (f32-identical indices); attention f16 MFMA "
@@ -381,6 +524,10 @@ def main():
             "config": {"workload": "SD-1.5 16 frames 512x512 (cfg-2): hot-path pass over the 16 transformer-block "
                                    "sites, batch 2 (CFG), local merge 0.5" +
                                    ("" if args.local_only else " + global merge 0.5 (steady state)"),
+                       "regime": ("same chunk fed to every pass (anchors = copies of its own rows; rounds 1-2)"
+                                  if args.same_chunk else
+                                  f"{K} distinct chunks of one synthetic clip rotate: every pass's anchor tokens come "
+                                  f"from a different chunk (generate.py:215-219)"),
                        "sites": 16, "merged_sites": 10, "chunk_frames": FRAMES, "batch": BATCH,
                        "matcher": _merge.MATCH_MODE + (" (fp16-MFMA filter, fp32 refine; global-level index order inside "
                                                        "groups of EXACTLY equal similarity is the stable one, the "
@@ -398,7 +545,8 @@ def main():
                          # the top-block launches alone (compare with attention_kernel<half,40> in profiles/*_kernel_stats.txt)
                          "top_block": {"launches": top_n, "avg_ms": round(top_ms, 4),
                                        "tflops": round(top_flops / (top_ms * 1e-3) / 1e12, 1) if top_ms > 0 else 0.0},
-                         "attention_ms_per_step": round(ams / args.steps, 3),
+                         "attention_ms_per_step": round(ams / timed_passes, 3),
+                         "event_passes": timed_passes,
                          "note": "power-limited: with these (random) operand values the kernel runs at the 1400 W package cap, "
                                  "sclk ~1.95 GHz; the same launch with non-toggling operands reaches 1 130-1 166 TFLOP/s = the floor "
                                  "of its instruction mix (profiles/r02_ubench.txt, DESIGN.md section 10)"},
@@ -410,13 +558,13 @@ def main():
                          "executed_tflops": round(mat_tf, 1),
                          "peak": FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS,
                          "frac": round(mat_tf / (FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS), 4),
-                         "calls": mn, "matching_ms_per_step": round(mms / args.steps, 3)},
+                         "calls": mn, "matching_ms_per_step": round(mms / timed_passes, 3)},
             # the HBM-bound kernels of the path: algorithmic bytes (rows read + rows written) / HIP-event time.  The
             # cfg-2 working sets (<= 212 MB) fit the 256 MB Infinity Cache, so `pmc` carries the counter-derived rates
             # measured beyond it
             # q / k / v^T / out projections: GEMMs whose A rows are gathered through the composed merge map
             "projections": (lambda f, ms, n: {"kernel": "linear_rows_ws_kernel / linear_rows_kernel (vtm_linear_rows, fp16 MFMA)", "launches": n,
-                                              "ms_per_step": round(ms / args.steps, 3),
+                                              "ms_per_step": round(ms / timed_passes, 3),
                                               "tflops": round(f / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0})(
                 *mt.summary("projections")),
             "gather_path": {"hbm_peak_GBps": HBM_PEAK_GBPS, "layernorm": hbm("layernorm"),

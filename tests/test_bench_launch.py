@@ -1,0 +1,83 @@
+"""bench.py's launcher: `python bench.py --gpus N` must start its N ranks itself when no launcher set WORLD_SIZE (the
+driver runs it exactly like the N = 1 line), run the chunk-parallel exchange, and print ONE JSON line from rank 0.
+
+CPU: the self-launch path is taken and fails loudly per rank (no GPU -> no product path).  GPU: two ranks on ONE GPU
+through the `VIDTOME_BENCH_BACKEND=gloo` hook in all three exchange modes; with two or more GPUs also over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(argv, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the CPU half of the launcher test")
+def test_self_launch_without_gpu_fails_loudly_per_rank():
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], timeout=300)
+    assert p.returncode != 0
+    assert "AssertionError" not in p.stderr
+    assert p.stderr.count("needs an MI355X") >= 1          # a rank that died takes the other down by PID
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_world_size_mismatch_is_an_error_not_an_assert():
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+             {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, timeout=300)
+    assert p.returncode != 0 and "AssertionError" not in p.stderr
+    assert ("WORLD_SIZE=1" in p.stderr) or ("needs an MI355X" in p.stderr)
+
+
+def _line(p):
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["neighbour", "allgather", "ring"])
+def test_bench_two_ranks_one_gpu_gloo(exchange):
+    """The N > 1 branch end to end (self-launch -> process group -> exchange through compute_merge -> barrier-fenced
+    timing -> per-rank times -> one JSON line), two ranks sharing cuda:0 over gloo."""
+    d = _line(_run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--exchange", exchange],
+                   {"VIDTOME_BENCH_BACKEND": "gloo"}))
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["launcher"] == "self" and d["backend"] == "gloo"
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert abs(d["ms_per_step"] - max(d["per_rank_ms_per_step"])) < 1e-3
+    assert d["roofline"]["achieved"] > 0 and d["matching"]["calls"] > 0
+    assert exchange in d["config"]["parallelism"] or exchange == "neighbour"
+    assert "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+@pytest.mark.parametrize("exchange", ["neighbour", "allgather", "ring"])
+def test_bench_two_ranks_rccl(exchange):
+    d = _line(_run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--exchange", exchange]))
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"].startswith("rccl")
+    assert len(d["per_rank_ms_per_step"]) == 2
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_has_the_contract_fields():
+    d = _line(_run(["--steps", "5", "--warmup", "1", "--no-cpu-baseline"]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["ranks"] == 1 and d["roofline"]["event_passes"] == 1
+    assert "different chunk" in d["config"]["regime"]
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3

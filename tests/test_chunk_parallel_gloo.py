@@ -252,3 +252,61 @@ def test_long_stream_releases_finished_sends(oracle):
         ex.end_step()
         assert not ex._inflight
     assert torch.equal(mods[0][0].generator.get_state(), mods[1][0].generator.get_state())
+
+
+class _LateModule:                 # a patched block before its first forward: no generator yet
+    pass
+
+
+@pytest.mark.parametrize("mode", ["ring", "neighbour"])
+def test_idle_ranks_keep_the_sequential_draw_stream(oracle, mode):
+    """A step may have fewer chunks than ranks (the first chunk of a step has a random length, generate.py:176-178), so a
+    rank can sit out a whole step -- here rank 2 of 3 in the first AND the third step, rank 1 in the third -- before it
+    runs a block for the first time.  Its generators are forked at the first begin_step (registered blocks, same point
+    of the global stream on every rank) and the block replays the steps it missed when it first appears, so merged
+    tokens, anchors and the final generator states still equal the sequential run's.  The 6- and 5-frame chunks make the
+    merged length depend on the draws: a rank on a wrong stream would also post receives of the wrong shape."""
+    from vidtome_amd import chunk_parallel as cp
+    steps = [[3, 6], [2, 4, 4, 5, 6], [6], [5, 3, 6]]
+    W = 3
+    ref, ref_end = _reference(oracle, mode, steps)
+    tpf = HW[0] * HW[1]
+    fabric = cp.LocalTransport.fabric(W)
+    exs = [cp.AnchorExchange(mode, transport=t) for t in fabric]
+    mods = [[_LateModule() for _ in range(NBLK)] for _ in range(W)]
+    for r in range(W):
+        for blk in range(NBLK):
+            exs[r].register(f"b{blk}", mods[r][blk])
+    torch.manual_seed(123)                                   # what _fork() seeds in _reference
+    for s, frames in enumerate(steps):
+        for ex in exs:
+            ex.begin_step(frames)
+        if s == 0:
+            torch.randperm(7)                                # later draws from the global stream must not matter
+        for i, F in enumerate(frames):
+            ex, r = exs[i % W], i % W
+            ex.begin_chunk(i)
+            for blk in range(NBLK):
+                key, mod = f"b{blk}", mods[r][blk]
+                h = _hidden(s, i, blk, F)
+                like = torch.from_numpy(h).reshape(B, F * tpf, C)
+                ex.begin_block(mod, key, F, tpf, ARGS, like)
+                local = _local_tokens(oracle, h, mod.generator)
+
+                class State(dict):
+                    def get(self, k, d=None):
+                        got = ex.anchors_for(key, lambda: torch.from_numpy(local), like)
+                        return None if got is None else got.numpy()
+                state = State()
+                merged = oracle.compute_merge(h, HW, ARGS, oracle.RandomDraws.from_torch_generator(mod.generator), state)[2]
+                ex.publish(key, torch.from_numpy(np.ascontiguousarray(state["global_tokens"])))
+                assert np.array_equal(merged, ref[(s, i, blk)][0]), (mode, s, i, blk)
+                assert np.array_equal(state["global_tokens"], ref[(s, i, blk)][1]), (mode, s, i, blk)
+        for ex in exs:
+            ex.end_step()
+    # rank 2 never ran a chunk in steps 0 and 2; every block it DID run ends on the sequential stream
+    for r in range(W):
+        for blk in range(NBLK):
+            st = exs[r]._blocks.get(f"b{blk}")
+            assert st is not None and st.steps_done == len(steps)
+            assert torch.equal(mods[r][blk].generator.get_state(), ref_end[blk]), (r, blk)

@@ -116,14 +116,18 @@ STEPS = [[3, 6, 4, 1, 4], [2, 4, 4]]
 SMALL_LATENT = (16, 16)
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, backend="gloo"):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda:0")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dev = torch.device("cuda", rank if backend == "nccl" else 0)     # RCCL: one GPU per rank
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         import vidtome_amd
         from vidtome_amd import chunk_parallel as cp
         from vidtome_amd import sites
@@ -190,6 +194,24 @@ def test_two_processes_one_gpu_through_compute_merge(mode):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in results:
+        assert ok, f"rank {rank} failed: {err}"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+@pytest.mark.parametrize("mode", ["ring", "neighbour", "allgather"])
+def test_two_processes_two_gpus_rccl(mode):
+    """SURVEY.md 8e, second clause: the real N-rank RCCL run equals the replay -- ring == the sequential run bit for bit
+    (block outputs, anchors, generator states), neighbour / all-gather == the one-rank run of the same semantics."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q, "nccl")) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in procs]

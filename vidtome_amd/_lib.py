@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes
 import functools
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
@@ -121,8 +122,10 @@ _WS: dict = {}
 def _workspace(tag: str, nbytes: int, device: torch.device) -> torch.Tensor:
     """Scratch memory of a call, cached per (device, stream, purpose) and grown on demand: calls on one stream are
     ordered, so the next user of the buffer starts after the previous one finished -- no allocator round trip per
-    call (a block makes ~40 of them).  The library itself stays stateless: it is handed the pointer and the size."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    call (a block makes ~40 of them).  The library itself stays stateless: it is handed the pointer and the size.
+    The host thread is part of the key: two threads launching on the same stream never share a buffer (their launches
+    are not ordered against each other by anything the caller can rely on).  `remove_patch` drops the cache."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag, threading.get_ident())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _WS[key] = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
@@ -411,7 +414,9 @@ def linear_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], rows: Optional[tor
                 transposed: bool = False, pad_to: int = 8, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[b, i] = pool[b, rows[b, rows2[b, i]]] @ weight^T (+ bias) for i < n (either map may be None = identity).
     Returns (B, n_pad, N) token-major, or (B, N, n_pad) channel-major when ``transposed`` (n_pad = n rounded up to
-    ``pad_to``; the padding is NOT written).  ``out`` may be a preallocated view (last axis contiguous)."""
+    ``pad_to``; the padding rows / columns are zero when this function allocates the result -- consumers such as a
+    gate multiply or a later GEMM then see finite values -- and left alone in a preallocated ``out`` view, last axis
+    contiguous)."""
     _req(x0, "x0"), _req(weight, "weight")
     B, P0, K = x0.shape
     P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
@@ -425,6 +430,8 @@ def linear_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], rows: Optional[tor
     n_pad = (n + pad_to - 1) // pad_to * pad_to
     if out is None:
         out = torch.empty((B, N, n_pad) if transposed else (B, n_pad, N), dtype=x0.dtype, device=x0.device)
+        if n_pad != n:
+            (out[:, :, n:] if transposed else out[:, n:]).zero_()
     if out.stride(2) != 1:
         raise RuntimeError("linear_rows: out must be contiguous along its last axis")
     _check(lib().vtm_linear_rows(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, K, _ptr(rows),

@@ -202,10 +202,11 @@ class LocalTransport:
 # the exchange
 # ----------------------------------------------------------------------------------------------------
 class _BlockState:
-    __slots__ = ("module", "tsize", "args", "drawn", "lens", "recv", "carry")
+    __slots__ = ("module", "tsize", "args", "drawn", "lens", "recv", "carry", "steps_done")
 
-    def __init__(self, module, tsize, args):
+    def __init__(self, module, tsize, args, steps_done=0):
         self.module, self.tsize, self.args = module, tsize, args
+        self.steps_done = steps_done   # finished steps whose draws this block's generator has consumed in full
         self.drawn = 0          # chunks of the current step whose draws this block's generator has consumed
         self.lens: Dict[int, int] = {}    # chunk index -> merged local length (simulated or own)
         self.recv = None        # pending receive of the predecessor's tokens
@@ -234,6 +235,12 @@ class AnchorExchange:
         self._cur: Optional[int] = None
         self._blocks: Dict[str, _BlockState] = {}
         self._inflight: List[Tuple[object, torch.Tensor]] = []     # (work, tensor kept alive until the send is done)
+        # A rank may sit out whole steps (fewer chunks than ranks; the first chunk of a step has a random length, so
+        # the chunk count varies, generate.py:176-178).  A block it has not run yet has no _BlockState -- its token
+        # count per frame is only known once the model reaches it -- so the schedules of the finished steps are kept
+        # and a block replays the ones it missed when it first appears (begin_block).
+        self._history: List[List[int]] = []
+        self._modules: Dict[str, object] = {}                      # patched blocks registered by enable()
 
     # ---- step / chunk bookkeeping (host side only)
     @property
@@ -249,6 +256,27 @@ class AnchorExchange:
                              f"{self.world} chunks (got {len(self._frames)}); use 'neighbour' or 'ring'")
         for st in self._blocks.values():
             st.drawn, st.lens, st.recv, st.carry = 0, {}, None, None
+        # The sequential run forks every block generator at the block's first forward of the FIRST step
+        # (patch.py:215-231), i.e. right after that step's schedule was drawn.  A rank whose first chunk comes later
+        # would fork later -- after further draws from the global generator (the next steps' schedules) -- and its
+        # randf / coin stream would differ from the other ranks'.  Every registered block forks here instead: the same
+        # point of the global stream on every rank.
+        for module in self._modules.values():
+            if not hasattr(module, "generator"):
+                from .utils import init_generator
+                module.generator = init_generator(None)
+
+    def register(self, key: str, module) -> None:
+        """A patched block this exchange serves (called by `enable`)."""
+        self._modules[key] = module
+
+    def reset(self) -> None:
+        """Forget every block and every finished step (a new model / a new run on the same process group)."""
+        if self._cur is not None:
+            raise RuntimeError("reset inside a step (call end_step first)")
+        self._blocks.clear()
+        self._modules.clear()
+        self._history.clear()
 
     def my_chunks(self) -> List[int]:
         return list(range(self.rank, len(self._frames), self.world))
@@ -262,8 +290,10 @@ class AnchorExchange:
         """Consume the draws of the chunks after this rank's last one (the next step continues the same generator
         streams, like the sequential run) and retire the sends."""
         n = len(self._frames)
+        self._history.append(self._frames)
         for st in self._blocks.values():
             self._replay(st, n)
+            st.steps_done = len(self._history)
             if st.recv is not None:                       # a posted receive nobody consumed (cannot happen in a
                 st.recv.wait()                            # well-formed step; drain it rather than leak it)
                 st.recv = None
@@ -281,6 +311,12 @@ class AnchorExchange:
             st.lens[c] = sim["M_local"]
             st.drawn += 1
 
+    def _catch_up(self, st: _BlockState) -> None:
+        """Consume the draws of the finished steps this block took no part in on this rank (it sat them out)."""
+        while st.steps_done < len(self._history):
+            replay_draws(st.module.generator, self._history[st.steps_done], st.tsize, st.args)
+            st.steps_done += 1
+
     def _owner(self, chunk: int) -> int:
         return chunk % self.world
 
@@ -294,9 +330,12 @@ class AnchorExchange:
         if fsize != self._frames[i]:
             raise RuntimeError(f"chunk {i} has {fsize} frames, the step schedule says {self._frames[i]}")
         st = self._blocks.get(key)
-        if st is None or st.module is not module:
+        if st is None:
             st = self._blocks[key] = _BlockState(module, tsize, args)
+        elif st.module is not module:                      # the block object was replaced: its generator is its own
+            st = self._blocks[key] = _BlockState(module, tsize, args, len(self._history))
         st.tsize, st.args = tsize, args
+        self._catch_up(st)
         self._replay(st, i)
         st.drawn = i + 1                                   # compute_merge itself makes chunk i's draws
         if not args["merge_global"] or i == 0 or self.mode == "allgather":
@@ -418,12 +457,16 @@ class AllGatherExchange(AnchorExchange):
 # wiring into the patched model
 # ----------------------------------------------------------------------------------------------------
 def enable(model: torch.nn.Module, exchange: AnchorExchange) -> None:
-    """Attach ``exchange`` to every patched block; compute_merge consults ``module._vtm_exchange``."""
+    """Attach ``exchange`` to every patched block; compute_merge consults ``module._vtm_exchange``.  The blocks are
+    registered with the exchange, which forks their generators at the first ``begin_step`` (every rank at the same
+    point of the global RNG stream, also the ranks that sit the first step out)."""
     root = model.unet if hasattr(model, "unet") else model
+    exchange.reset()
     for name, m in root.named_modules():
         if m.__class__.__name__ == "ToMeBlock":
             m._vtm_exchange = exchange
             m._vtm_key = name
+            exchange.register(name, m)
 
 
 def disable(model: torch.nn.Module) -> None:

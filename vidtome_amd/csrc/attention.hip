@@ -781,6 +781,9 @@ VTM_EXPORT int vtm_attention_kv(const void *q, int64_t ldq, const void *k, int64
     VTM_REQUIRE(share_groups >= 1 && B % share_groups == 0, "vtm_attention: B %% share_groups != 0");
     VTM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Mk,
                 "vtm_attention: leading dimensions must keep 16-byte alignment (ldvt >= Mk, %% 8)");
+    // K / V^T tiles are addressed with 32-bit byte offsets inside one (sample, head) slice (buffer loads)
+    VTM_REQUIRE((Mkp * ldk + d) * 2 < (1ll << 31) && (d * ldvt + Mkp) * 2 < (1ll << 31),
+                "vtm_attention: a (sample, head) slice of K or V^T must stay below 2 GiB");
     hipStream_t s = vtm::as_stream(stream);
     if (dtype == VTM_F16)
         return dispatch<__half>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws,

@@ -653,6 +653,7 @@ def remove_patch(model: torch.nn.Module):
                 info["hooks"].clear()
             if module.__class__.__name__ == "ToMeBlock":
                 module.__class__ = module._parent
+    _lib.release_workspaces()            # the cached scratch buffers of the patched path (re-created on demand)
     return roots[-1]                     # the reference returns its loop variable: the last tree walked
 
 

@@ -97,13 +97,16 @@ class SiteUNet(ModelMixin):
 
 
 def synthetic_hidden(site: Site, batch: int, frames: int, latent_hw: Tuple[int, int], dtype, device,
-                     seed: int, frame_noise: float = 0.5) -> torch.Tensor:
+                     seed: int, frame_noise: float = 0.5, clip_seed: int = None) -> torch.Tensor:
     """(B*F, N, C) hidden states: per-sample base + frame_noise * N(0,1) per frame (frames of a clip are
-    correlated).  Batch layout [uncond frames | cond frames] like generate.py:245."""
+    correlated).  Batch layout [uncond frames | cond frames] like generate.py:245.  With ``clip_seed`` the base comes
+    from that seed and only the frame noise from ``seed``: different ``seed``s are then different CHUNKS OF ONE CLIP
+    (same content, independent frames) -- what consecutive chunks of a video look like to the global level."""
     h, w = latent_hw[0] // site.downsample, latent_hw[1] // site.downsample
     N = h * w
     g = torch.Generator().manual_seed(seed)
-    base = torch.randn(batch, 1, N, site.channels, generator=g)
+    gb = g if clip_seed is None else torch.Generator().manual_seed(clip_seed)
+    base = torch.randn(batch, 1, N, site.channels, generator=gb)
     x = base + frame_noise * torch.randn(batch, frames, N, site.channels, generator=g)
     return x.reshape(batch * frames, N, site.channels).to(device=device, dtype=dtype)
 

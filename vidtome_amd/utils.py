@@ -1,8 +1,9 @@
 """Patch helpers -- the counterpart of vidtome/utils.py (same names and behaviour).
 
-The reference's closure-composition helpers (`func_warper` / `join_warper` / `split_warper`, vidtome/utils.py:42-60)
-have no counterpart here: a block's merge / unmerge chains are composed into single row maps on the device
-(`vtm_compose`, see patch.compute_merge), and joining / splitting frames are views."""
+The patched block itself does not use the closure-composition helpers (`func_warper` / `join_warper` / `split_warper`,
+vidtome/utils.py:42-60): its merge / unmerge chains are composed into single row maps on the device (`vtm_compose`, see
+patch.compute_merge), and joining / splitting frames are views.  They are kept for code written against the reference
+that imports them."""
 from __future__ import annotations
 
 import torch
@@ -35,3 +36,22 @@ def split_frame(x: torch.Tensor, fsize: int) -> torch.Tensor:
     """vidtome/utils.py:37-40: 'B (F N) C -> (B F) N C'."""
     B, FN, C = x.shape
     return x.reshape(B * fsize, FN // fsize, C)
+
+
+def func_warper(funcs):
+    """vidtome/utils.py:42-48: one callable applying ``funcs`` left to right, keyword arguments passed to each."""
+    def fn(x, **kwarg):
+        for f in funcs:          # the list itself, not a copy: the reference's closure sees later mutations too
+            x = f(x, **kwarg)
+        return x
+    return fn
+
+
+def join_warper(fsize: int):
+    """vidtome/utils.py:50-54."""
+    return lambda x: join_frame(x, fsize)
+
+
+def split_warper(fsize: int):
+    """vidtome/utils.py:56-60."""
+    return lambda x: split_frame(x, fsize)
