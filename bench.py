@@ -70,11 +70,16 @@ def parse():
                          "batch sample and doubled")
     ap.add_argument("--cpu-baseline", choices=["torch", "port"], default="torch",
                     help="torch = plain-PyTorch restatement, timed on full sites; port = the C/OpenMP oracle, row slices")
-    ap.add_argument("--exchange", choices=["neighbour", "allgather", "ring"], default="neighbour",
-                    help="N > 1: how the global level gets its anchor tokens (chunk_parallel.py)")
+    ap.add_argument("--exchange", choices=["neighbour", "allgather", "ring"], default=None,
+                    help="how the global level gets its anchor tokens (chunk_parallel.py); default: neighbour at N > 1, "
+                         "none at N = 1 (the reference's chained anchors).  Given explicitly at N = 1 (neighbour / ring) the "
+                         "single rank runs the same protocol in place -- the N = 1 point of that mode's scaling curve")
     ap.add_argument("--local-only", action="store_true", help="merge_global=False variant (not the headline)")
     ap.add_argument("--chunks", type=int, default=3,
                     help="distinct chunks of the synthetic clip the passes rotate over (anchors come from another chunk)")
+    ap.add_argument("--chunks-per-step", type=int, default=8,
+                    help="N = 1: chunks of a denoising step -- the anchor chain is re-seeded every chunks_per_step - 1 "
+                         "passes with the first chunk's local tokens (the reference resets the anchors after every step)")
     ap.add_argument("--same-chunk", action="store_true",
                     help="rounds 1-2's regime: every pass processes the same chunk (anchors = copies of its own rows)")
     ap.add_argument("--event-every", type=int, default=5,
@@ -411,37 +416,39 @@ def main():
     total_passes = 1 + args.warmup + args.steps
     torch.manual_seed(123)           # the block generators fork this state (default.yaml seed)
     ex = None
-    if world > 1 and not args.local_only:
+    mode = args.exchange or ("neighbour" if world > 1 else None)
+    if mode is not None and not args.local_only:
         # every rank owns one chunk per pass; per merging block the global level takes its anchor tokens from the
         # previous rank's chunk over RCCL / xGMI (chunk_parallel.py).  The whole run is ONE stream of chunks
         # (chunk index = pass * world + rank), so the exchange knows which chunk is the last and leaves no send unmatched.
         from vidtome_amd import chunk_parallel as cp
-        ex = cp.AnchorExchange(args.exchange)
+        if world == 1 and mode == "allgather":
+            raise SystemExit("bench.py: --exchange allgather needs N > 1 (a collective); use neighbour (same semantics)")
+        ex = cp.AnchorExchange(mode, transport=None if world > 1 else cp.LocalTransport.fabric(1)[0])
         cp.enable(unet, ex)
         ex.begin_step([FRAMES] * (total_passes * world))
-    # The run is one stream of chunks of ONE synthetic clip: chunk c = pass * world + rank holds frame set c % K
-    # (per-sample base shared by all sets, independent frame noise), so the anchor tokens a chunk merges against always
-    # come from a different chunk, at every N.  --same-chunk: one set per rank, fed to every pass (rounds 1-2).
-    K = 1 if args.same_chunk else max(2, args.chunks)
+    # The run is one stream of chunks of ONE synthetic clip (sites.ClipStream): chunk c = pass * world + rank holds frame
+    # set c % K, so the anchor tokens a chunk merges against always come from a different chunk, at every N.
+    # N = 1 (no exchange): the reference's chained anchors, re-seeded every chunks_per_step - 1 passes with what the first
+    # chunk of a denoising step would have stored (generate.py:233-236 resets the anchors after every step).
+    # With an exchange the anchors are whatever the exchange mode defines (neighbour / all-gather: the previous chunk's
+    # local tokens, i.e. always a chain of length 1; ring: the exact chain, unbounded over the run).
     site_list = sites.sd15_sites()
-
-    def make_set(j):
-        if args.same_chunk:
-            return [sites.synthetic_hidden(s, BATCH, FRAMES, LATENT, torch.float16, dev, seed=1234 + 97 * rank + i)
-                    for i, s in enumerate(site_list)]
-        return [sites.synthetic_hidden(s, BATCH, FRAMES, LATENT, torch.float16, dev, seed=1234 + 97 * j + i,
-                                       clip_seed=4321 + i) for i, s in enumerate(site_list)]
-
-    sets = {j: make_set(j) for j in sorted({(p_ * world + rank) % K for p_ in range(total_passes)})}
+    K = 1 if args.same_chunk else max(2, args.chunks)
+    stream = sites.ClipStream(unet, site_list, BATCH, FRAMES, LATENT, torch.float16, dev, n_sets=args.chunks,
+                              chunks_per_step=args.chunks_per_step, same_chunk=args.same_chunk, rank=rank,
+                              reseed=ex is None,
+                              sets=None if ex is None else {(p_ * world + rank) % K for p_ in range(total_passes)})
     passes = [0]
 
     def step():
         c = passes[0] * world + rank
-        if ex is not None:
-            ex.begin_chunk(c)
         passes[0] += 1
+        if ex is None:
+            return stream.step(c)
+        ex.begin_chunk(c)
         with torch.no_grad():
-            return sites.run_segment_pass(unet, sets[c % K])
+            return sites.run_segment_pass(unet, stream.sets[c % K])
 
     def fence():
         torch.cuda.synchronize()
@@ -449,7 +456,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step()                            # preceding chunk: populates the anchor tokens (steady state)
+    if ex is None:
+        stream.populate()             # untimed: the first chunk(s) of a step fill the anchor tokens (steady state)
+    else:
+        step()                        # chunk 0 of the stream has no predecessor: it only publishes its tokens
     for _ in range(args.warmup):
         step()
     every = max(1, args.event_every)
@@ -503,7 +513,7 @@ def main():
             par += {"neighbour": ", anchor tokens = the previous rank's local merged tokens, point-to-point over RCCL/xGMI "
                                  "per merging block",
                     "allgather": ", RCCL all-gather of the anchor tokens per merging block",
-                    "ring": ", exact serial anchor chain (ring hand-off over RCCL/xGMI)"}[args.exchange]
+                    "ring": ", exact serial anchor chain (ring hand-off over RCCL/xGMI)"}[mode]
         line = {
             "metric": "denoising steps/sec, 16-frame 512x512 SD-1.5 chunk, ratio=0.5",
             "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
@@ -527,12 +537,16 @@ def main():
                        "regime": ("same chunk fed to every pass (anchors = copies of its own rows; rounds 1-2)"
                                   if args.same_chunk else
                                   f"{K} distinct chunks of one synthetic clip rotate: every pass's anchor tokens come "
-                                  f"from a different chunk (generate.py:215-219)"),
+                                  f"from a different chunk (generate.py:215-219); " +
+                                  (f"anchor chain of 1..{max(1, args.chunks_per_step - 1)} updates, re-seeded with the first "
+                                   f"chunk's local tokens like a denoising step of {args.chunks_per_step} chunks "
+                                   f"(generate.py:233-236)" if ex is None else
+                                   "anchors as the exchange mode defines them")),
                        "sites": 16, "merged_sites": 10, "chunk_frames": FRAMES, "batch": BATCH,
                        "matcher": _merge.MATCH_MODE + (" (fp16-MFMA filter, fp32 refine; global-level index order inside "
                                                        "groups of EXACTLY equal similarity is the stable one, the "
                                                        "reference's is implementation-defined)" if filtered else ""),
-                       "parallelism": par},
+                       "parallelism": par, "exchange": mode if ex is not None else None},
             # dominant single kernel of the step: the merged-token self-attention (MFMA-bound)
             # `achieved` counts EXECUTED flops (4 B Mq Mk C per launch): with a global level the block only computes the
             # attention rows unmerge() reads, so the reference-algorithmic 4 B M^2 C would overstate the kernel

@@ -58,7 +58,7 @@ def test_bench_two_ranks_one_gpu_gloo(exchange):
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
     assert abs(d["ms_per_step"] - max(d["per_rank_ms_per_step"])) < 1e-3
     assert d["roofline"]["achieved"] > 0 and d["matching"]["calls"] > 0
-    assert exchange in d["config"]["parallelism"] or exchange == "neighbour"
+    assert d["config"]["exchange"] == exchange and "chunk-parallel x2" in d["config"]["parallelism"]
     assert "cpu_baseline" not in d
 
 

@@ -42,7 +42,11 @@ constexpr int FBS = 256;      // src rows per workgroup (B operand, registers), 
 constexpr int FBK = 64;       // channels per pipeline step = 4 MFMA k-steps = 8 panels
 constexpr int THREADS = 256;
 constexpr int CAP = 64;       // candidate slots per src row
-constexpr int MAX_SURVIVORS = 8;   // per row after the global-window filter; more -> exact row pass
+// Survivors (candidates inside the window of the row's FINAL approximate maximum) go to the per-pair refine pass however
+// many a row has (<= CAP): the anchor tokens of a global level hold exact copies of matched rows (patch.py:80), so a
+// src row whose best dst row exists m times has m tied survivors -- m ~ 10 after one local-is-src pass -- and the exact
+// row pass (all Nd chains of the row) is ~1000x the cost of its few pairs.  The pair list is sized for the worst case
+// (every list full), so its reservation cannot fail.
 constexpr float SCALE = 1024.0f;
 constexpr float INV_S2 = 1.0f / (1024.0f * 1024.0f);
 // Which products the filter accumulates (the refine pass is exact whatever the filter does; fewer products = less
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const 
     for (int c = 0; c < PRE; ++c) ns += __uint_as_float(pre[c].x) >= thr;   // NaN (not fetched) never counts
     if (n <= CAP)
         for (int c = PRE; c < n; ++c) ns += __uint_as_float(cand[(int64_t)c * rows_out + row].x) >= thr;
-    if (n > CAP || ns > MAX_SURVIVORS) {   // list overflowed / too many survivors: refine_kernel's exact row pass
+    if (n > CAP) {   // the list overflowed (a dst row duplicated more than ~CAP times): refine_kernel's exact row pass
         ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
         ns = 0;
     }
@@ -969,7 +973,7 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     L.flags = take(256);
     L.cand = take((size_t)rows_out * CAP * 8);
     L.ovf = take((size_t)rows_out * 4);
-    L.pairs = take((size_t)rows_out * MAX_SURVIVORS * 8);
+    L.pairs = take((size_t)rows_out * CAP * 8);
     L.total = o;
     return L;
 }
