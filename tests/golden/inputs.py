@@ -52,3 +52,48 @@ def load_fuzz_configs(path):
         cfgs.append(c)
     return cfgs
 
+
+
+def planted_batch(Ns, Nd, C, seed, B=2, lo=0.55, hi=0.99):
+    """`planted_inputs` for a batch whose samples may be matched TOGETHER (align_batch concatenates the samples' scores
+    along the dst axis, merge.py:93-97): sample b draws its planted cosines from the grid
+    linspace(hi, lo, Ns) - b * step / B, so that all B * Ns cosines -- hence the per-row maxima over the samples and the
+    sorted order of those maxima -- are strictly spaced (by step / B) whichever sample wins a row.  Returns
+    src (B, Ns, C), dst (B, Nd, C) fp32 with arbitrary row norms."""
+    rng = np.random.default_rng(seed)
+    step = (hi - lo) / max(Ns - 1, 1)
+    out_a, out_b = [], []
+    for b in range(B):
+        dst = rng.standard_normal((Nd, C))
+        dst /= np.linalg.norm(dst, axis=1, keepdims=True)
+        pi = rng.integers(0, Nd, size=Ns)
+        c = np.linspace(hi, lo, Ns) - b * step / B
+        rng.shuffle(c)
+        e = rng.standard_normal((Ns, C))
+        d = dst[pi]
+        e -= (e * d).sum(1, keepdims=True) * d
+        e /= np.linalg.norm(e, axis=1, keepdims=True)
+        src = c[:, None] * d + np.sqrt(1 - c * c)[:, None] * e
+        src *= rng.uniform(0.5, 2.0, size=(Ns, 1))
+        out_a.append(src.astype(np.float32))
+        out_b.append((dst * rng.uniform(0.5, 2.0, size=(Nd, 1))).astype(np.float32))
+    return np.stack(out_a), np.stack(out_b)
+
+
+def planted_local_chunk(B, F, tnum, unm_pre, C, randf, seed, target_stride=4):
+    """A joined chunk (B, unm_pre + F * tnum, C) for bipartite_soft_matching_randframe whose src / dst partition under
+    `randf` (merge.py:56-69: dst = frames with f % ts == randf, plus the first unm_pre tokens) is a planted matching."""
+    ts = min(target_stride, F)
+    frames = np.arange(F * tnum) // tnum
+    is_dst = np.concatenate([np.ones(unm_pre, bool), frames % ts == randf])
+    Nd, Ns = int(is_dst.sum()), int((~is_dst).sum())
+    a, b = planted_batch(Ns, Nd, C, seed, B)
+    x = np.empty((B, unm_pre + F * tnum, C), np.float32)
+    x[:, is_dst] = b
+    x[:, ~is_dst] = a
+    return x
+
+
+def idx_sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(a).astype(np.int32)).tobytes()).hexdigest()

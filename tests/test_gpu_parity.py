@@ -399,6 +399,71 @@ def test_planted_golden_gpu(L):
         _planted_gpu(c)
 
 
+@pytest.mark.parametrize("mode", ["filtered", "exact"])
+def test_planted_mid_and_full_size_golden_gpu(L, mode, monkeypatch):
+    """tests/golden/planted_mid.npz (REFERENCE runs, make_golden_mid.py): local matcher at 256 / 1 024 tokens per frame,
+    C = 320 / 640, level-2 shape, aligned batches; GLOBAL matcher (`bipartite_soft_matching_2s`) up to the full cfg-2 sizes
+    8 704^2 x 640 and 34 816^2 x 320, both unmerge_chunk values, rectangular, aligned.  The HIP path -- the default
+    filtered matcher AND the exact fp32 kernel -- reproduces the reference's index arrays bit for bit (sha256)."""
+    from inputs import idx_sha, planted_batch, planted_local_chunk
+    from vidtome_amd import merge
+    monkeypatch.setattr(merge, "MATCH_MODE", mode)
+    for c in load_cases("planted_mid.npz"):
+        name = str(c["name"])
+        if mode == "exact" and name == "global_34816_c320":
+            continue                                    # 776 GFLOP on the fp32 MFMA: covered by the filtered run
+        if str(c["kind"]) == "local":
+            x = planted_local_chunk(int(c["B"]), int(c["F"]), int(c["tnum"]), int(c["unm_pre"]), int(c["C"]),
+                                    int(c["randf"]), int(c["seed"]))
+            torch.manual_seed(123)
+            gen = torch.Generator(device="cpu").set_state(torch.get_rng_state())
+            m, u, info = merge.bipartite_soft_matching_randframe(_t(x), int(c["F"]), float(c["ratio"]), int(c["unm_pre"]),
+                                                                 gen, 4, bool(c["align"]))
+        else:
+            a, b = planted_batch(int(c["src_len"]), int(c["dst_len"]), int(c["C"]), int(c["seed"]), int(c["B"]))
+            x = np.concatenate([a, b], axis=1)
+            m, u, info = merge.bipartite_soft_matching_2s(_t(x), int(c["src_len"]), float(c["ratio"]), bool(c["align"]),
+                                                          unmerge_chunk=int(c["unmerge_chunk"]))
+            y = torch.zeros((x.shape[0], info["unm_num"] + int(c["dst_len"]), 8), device=DEV)
+            assert u(y).shape[1] == int(c["unmerged_len"]), name
+        assert info["unm_num"] == int(c["unm_num"]), name
+        for n in ("unm_idx", "src_idx", "dst_idx"):
+            got = info[n].cpu().numpy().astype(np.int32)
+            assert tuple(got.shape) == tuple(c[n + "_shape"]), (name, n, got.shape)
+            assert np.array_equal(got[..., :16], c[n + "_head"]), (name, n)
+            assert idx_sha(got) == str(c[n + "_sha256"]), (name, n)
+
+
+@pytest.mark.parametrize("shape", ["top_l2", "top_g", "mid_g"])
+def test_match_row_slices_vs_oracle_at_full_shapes(L, oracle, shape):
+    """The exact and the filtered HIP matcher against the CPU oracle on ROW SLICES at the full cfg-2 shapes the bench
+    times (top level 2: 12 288 x 28 672 x 320, top global: 34 816^2 x 320, mid global: 8 704^2 x 640): frame-correlated
+    fp16 tokens, slices at the start, across tile boundaries and at the end of the src range; node_max / node_idx
+    bitwise for the slice rows, filtered == exact bitwise for ALL rows."""
+    B, Ns, Nd, C = {"top_l2": (2, 12288, 28672, 320), "top_g": (2, 34816, 34816, 320), "mid_g": (2, 8704, 8704, 640)}[shape]
+    g = torch.Generator().manual_seed(Ns + C)
+    npos = 1024
+    base = torch.randn(B, npos, C, generator=g)
+    x = (base[:, torch.arange(Ns + Nd) % npos] + 0.5 * torch.randn(B, Ns + Nd, C, generator=g)).half()
+    xd = x.to(DEV)
+    ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+    rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+    a_op, _ = L.normalize_gather(xd, None, ra)
+    b_op, _ = L.normalize_gather(xd, None, rb)
+    best_e = L.match(a_op, b_op, Ns, Nd, False)
+    best_f = L.match_filtered(xd, None, ra, rb, False)
+    assert torch.equal(best_e, best_f)
+    nm, ni = L.decode_best(best_f)
+    nm, ni = nm.cpu().numpy(), ni.cpu().numpy()
+    xf = x.float().numpy()
+    an = oracle.normalize_gather(xf, np.arange(Ns)[None])
+    bn = oracle.normalize_gather(xf, np.arange(Ns, Ns + Nd)[None])
+    for r0, r1 in ((0, 96), (Ns // 2 - 40, Ns // 2 + 56), (Ns - 96, Ns)):
+        onm, oni = oracle.match(an, bn, rows=(r0, r1))
+        assert np.array_equal(_bits(onm[:, r0:r1]), _bits(nm[:, r0:r1])), (shape, r0)
+        assert np.array_equal(oni[:, r0:r1], ni[:, r0:r1]), (shape, r0)
+
+
 # ---------------------------------------------------------------------------------------------------
 # apply_patch on the stand-in UNet vs the reference's recorded run
 # ---------------------------------------------------------------------------------------------------
@@ -513,6 +578,132 @@ def test_attention_golden_gpu(L):
             y = vpatch.self_attention(attn, x, M)[:, :M].float().cpu().numpy()
         err = np.abs(y[:, c["rows"], :] - c["y_rows"]).max()
         assert err < 1e-3 * max(1.0, np.abs(c["y_rows"]).max()), (d, err)
+
+
+def _golden_attn(c):
+    from standin import Attention
+    h, d = int(c["heads"]), int(c["d"])
+    attn = Attention(h * d, h)
+    with torch.no_grad():
+        attn.to_q.weight.copy_(torch.from_numpy(c["wq"].astype(np.float32)))
+        attn.to_k.weight.copy_(torch.from_numpy(c["wk"].astype(np.float32)))
+        attn.to_v.weight.copy_(torch.from_numpy(c["wv"].astype(np.float32)))
+        attn.to_out[0].weight.copy_(torch.from_numpy(c["wo"].astype(np.float32)))
+        attn.to_out[0].bias.copy_(torch.from_numpy(c["bo"].astype(np.float32)))
+    return attn.to(DEV).half()
+
+
+def test_attention_golden_gpu_gather_fed_path(L):
+    """The DEFAULT fp16 path of the merged sites (`self_attention_rows`: q / k / v^T / out projections by vtm_linear_rows
+    through a row map, attention core, nothing materialised) against the REFERENCE's recorded sa_forward outputs
+    (attention.npz), 1e-3 of the output scale like the library-GEMM path above.  The tokens are presented the way the
+    patched block presents them: scattered over a pool [x0 | x1] and addressed through a gather map; the non-injected
+    cases also run with a live-query subset (`q_rows`), whose rows must equal the full result's."""
+    from vidtome_amd import patch as vpatch
+    for c in load_cases("attention.npz"):
+        B, M = int(c["B"]), int(c["M"])
+        attn = _golden_attn(c)
+        if c["inject"]:
+            attn.injection_schedule, attn.t, attn.vtm_num_inputs = [500], 500, B
+        x = _t(c["x"]).half()
+        C = x.shape[2]
+        g = torch.Generator().manual_seed(M)
+        perm = torch.stack([torch.randperm(M, generator=g) for _ in range(B)]).to(DEV)        # token i lives at pool row perm[i]
+        P0 = M // 3
+        pool = torch.empty_like(x)
+        pool.scatter_(1, perm[:, :, None].expand(B, M, C), x)
+        x0, x1 = pool[:, :P0].contiguous(), pool[:, P0:].contiguous()
+        rows = perm.to(torch.int32).contiguous()
+        with torch.no_grad():
+            y = vpatch.self_attention_rows(attn, x0, x1, rows)[:, :M].float().cpu().numpy()
+            y_id = vpatch.self_attention_rows(attn, x.contiguous(), None, None)[:, :M].float().cpu().numpy()
+        scale = max(1.0, np.abs(c["y_rows"]).max())
+        for got in (y, y_id):
+            err = np.abs(got[:, c["rows"], :] - c["y_rows"]).max()
+            assert err < 1e-3 * scale, (int(c["d"]), err)
+        if not c["inject"]:
+            q_rows = _t(np.ascontiguousarray(np.broadcast_to(c["rows"].astype(np.int32), (B, len(c["rows"])))))
+            with torch.no_grad():
+                yq = vpatch.self_attention_rows(attn, x0, x1, rows, q_rows)[:, :q_rows.shape[1]].float().cpu().numpy()
+            assert np.abs(yq - c["y_rows"]).max() < 1e-3 * scale
+            assert np.abs(yq - y[:, c["rows"], :]).max() < 2e-3 * scale     # same operands, another query tiling
+
+
+@pytest.mark.parametrize("F,N_side,C,heads,coins", [(8, 16, 320, 8, (0.0, 1.0)), (16, 32, 320, 8, (1.0, 0.0)),
+                                                   (8, 16, 640, 8, (0.0, 1.0))])
+def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, F, N_side, C, heads, coins, monkeypatch):
+    """What bench.py times, end to end, against the pinned oracle: an fp16 site with the bench's channel counts and head
+    dims (C = 320 / d = 40: gather-fed projections + live queries; C = 640 / d = 80 forced onto the same path), three
+    chunks of one clip (first chunk stores its tokens; then one chunk with the local chunk as src, one as dst -- the
+    coin thresholds are switched between chunks).  The oracle starts from OUR norm1 output (vtm_layernorm has its own
+    test against fp32 PyTorch; the matcher works on the fp16-rounded norm output, which is what the fp16 reference
+    model's matcher sees too): merge indices of every level BIT-EQUAL, anchors equal, block output within 1e-3 of the
+    output scale (north_star's fp16 tolerance)."""
+    import vidtome_amd
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import sites
+    monkeypatch.setattr(vpatch, "PROJ_MODE", "rows")          # the C = 640 case too
+    B, latent = 2, (N_side, N_side)
+    site = sites.Site("s", 1, C, heads)
+    unet = sites.SiteUNet([site], seed=3).to(device=DEV, dtype=torch.float16)
+    with torch.no_grad():
+        unet.blocks[0].norm1.weight.copy_(1.0 + 0.1 * torch.randn(C))
+        unet.blocks[0].norm1.bias.copy_(0.1 * torch.randn(C))
+        unet.blocks[0].attn1.to_out[0].bias.copy_(0.1 * torch.randn(C))
+    vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B,
+                            global_rand=0.5)
+    unet.set_size(latent)
+    blk = unet.blocks[0]
+    torch.manual_seed(123)
+    rng_state = torch.get_rng_state()
+    blk.generator = torch.Generator().set_state(rng_state)
+    draws = oracle.RandomDraws.from_torch_generator(torch.Generator().set_state(rng_state))
+    f32 = lambda t: t.detach().float().cpu().numpy()
+    a1 = blk.attn1
+    w = {"wq": f32(a1.to_q.weight), "wk": f32(a1.to_k.weight), "wv": f32(a1.to_v.weight), "wo": f32(a1.to_out[0].weight),
+         "bo": f32(a1.to_out[0].bias)}
+    plans, norms = [], []
+    orig_cm, orig_ln = vpatch.compute_merge, vpatch.layer_norm
+
+    def rec_cm(module, x, info, **kw):
+        kw["want_indices"] = True
+        res = orig_cm(module, x, info, **kw)
+        plans.append(res[0].plan)
+        return res
+
+    def rec_ln(norm, x):
+        y = orig_ln(norm, x)
+        norms.append(y)
+        return y
+    monkeypatch.setattr(vpatch, "compute_merge", rec_cm)
+    monkeypatch.setattr(vpatch, "layer_norm", rec_ln)
+    state = {"global_tokens": None}
+    args = dict(unet._tome_info["args"])
+    seen = set()
+    for ck in range(3):
+        if ck > 0:
+            unet._tome_info["args"]["global_rand"] = args["global_rand"] = coins[ck - 1]
+        hidden = sites.synthetic_hidden(site, B, F, latent, torch.float16, DEV, seed=50 + ck, clip_seed=7)
+        with torch.no_grad():
+            out = sites.run_segment_pass(unet, [hidden])[0]
+        plan, nh = plans[-1], f32(norms[-1])
+        m_o, u_o, merged_o, trace = oracle.compute_merge(nh, latent, args, draws, state)
+        for lv, rl in zip(plan.levels, trace["levels"]):
+            for n in ("unm_idx", "src_idx", "dst_idx"):
+                assert np.array_equal(getattr(lv, n).cpu().numpy(), rl[n]), (ck, n)
+        assert (plan.global_level is None) == (trace["global"] is None) == (ck == 0)
+        if trace["global"] is not None:
+            seen.add(trace["global"]["local_chunk"])
+            assert plan.local_chunk == trace["global"]["local_chunk"]
+            _tie_aware_equal(plan.global_level, trace["global"]["unm_idx"], trace["global"]["src_idx"],
+                             trace["global"]["dst_idx"], False)
+        assert np.array_equal(f32(blk.global_tokens), state["global_tokens"]), ck      # row copies of the fp16 pool
+        attn_o = oracle.self_attention(merged_o, w["wq"], w["wk"], w["wv"], w["wo"], w["bo"], heads)
+        ref = u_o(attn_o) + f32(hidden)
+        err = np.abs(f32(out) - ref).max()
+        assert err < 1e-3 * max(1.0, np.abs(ref).max()), (ck, err)
+    assert seen == {0, 1}
+    vidtome_amd.remove_patch(unet)
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 200, 40), (1, 2, 333, 80), (2, 2, 129, 64), (1, 1, 70, 160), (3, 2, 64, 8)])

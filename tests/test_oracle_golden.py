@@ -205,6 +205,45 @@ def test_attention_golden(oracle):
         np.testing.assert_allclose(y[:, rows, :], c["y_rows"], rtol=1e-3, atol=2e-4)
 
 
+def test_attention_qkv_is_pinned_too(oracle):
+    """`oracle.attention_qkv` (separate query set, double accumulation) is the checker of the full-size tests of the
+    dominant kernel (test_attention_full_size_vs_oracle): pin it to the same reference-recorded outputs as
+    `oracle.attention` -- the attention.npz cases of the reference's sa_forward, through the same projections -- and to
+    `oracle.attention` itself (1e-6), for the full query set and for a subset of query rows."""
+    for c in load_cases("attention.npz"):
+        if c["inject"]:
+            continue                                    # attention_qkv has no shared-probability mode
+        x = c["x"].astype(np.float32)
+        w = {k: c[k].astype(np.float32) for k in ("wq", "wk", "wv", "wo", "bo")}
+        heads, rows = int(c["heads"]), c["rows"]
+        q, k, v = x @ w["wq"].T, x @ w["wk"].T, x @ w["wv"].T
+        o_ref = oracle.attention(q, k, v, heads)
+        o_qkv = oracle.attention_qkv(q, k, v, heads)
+        scale = max(1.0, float(np.abs(o_ref).max()))
+        # `attention` accumulates in fp32 (a few 1e-6 of the output scale of rounding), `attention_qkv` in double
+        assert np.abs(o_qkv - o_ref).max() < 3e-6 * scale
+        sub = oracle.attention_qkv(np.ascontiguousarray(q[:, rows]), k, v, heads)     # queries = the recorded rows
+        assert np.abs(sub - o_qkv[:, rows]).max() < 1e-6 * scale
+        # ... and a float64 numpy softmax says which of the two is the exact one: attention_qkv to 1e-6
+        d_ = q.shape[2] // heads
+        for b_, h_ in ((0, 0), (q.shape[0] - 1, heads - 1)):
+            sl = slice(h_ * d_, (h_ + 1) * d_)
+            s64 = (q[b_, rows][:, sl].astype(np.float64) @ k[b_][:, sl].astype(np.float64).T) * d_ ** -0.5
+            p64 = np.exp(s64 - s64.max(-1, keepdims=True))
+            o64 = (p64 / p64.sum(-1, keepdims=True)) @ v[b_][:, sl].astype(np.float64)
+            assert np.abs(sub[b_][:, sl] - o64).max() < 1e-6 * scale
+        y = sub @ w["wo"].T + w["bo"]
+        np.testing.assert_allclose(y, c["y_rows"], rtol=1e-3, atol=2e-4)           # the reference's own outputs
+        # rectangular: fewer keys than queries
+        Mk = q.shape[1] // 2 + 3
+        part = oracle.attention_qkv(q, np.ascontiguousarray(k[:, :Mk]), np.ascontiguousarray(v[:, :Mk]), heads)
+        d = q.shape[2] // heads
+        b0, h0, i0 = 0, heads - 1, 5
+        s = (q[b0, i0, h0 * d:(h0 + 1) * d] @ k[b0, :Mk, h0 * d:(h0 + 1) * d].T).astype(np.float64) * d ** -0.5
+        p = np.exp(s - s.max()); p /= p.sum()
+        assert np.abs(part[b0, i0, h0 * d:(h0 + 1) * d] - p @ v[b0, :Mk, h0 * d:(h0 + 1) * d]).max() < 1e-5 * scale
+
+
 def _planted_check(oracle, c):
     a, b = planted_inputs(int(c["Ns"]), int(c["Nd"]), int(c["C"]), seed=int(c["seed"]))
     F, randf = int(c["F"]), int(c["randf"])
@@ -233,6 +272,49 @@ def test_planted_full_cfg2_golden(oracle):
     if "planted_cfg2_top_l1" not in cases:
         pytest.skip("full-size planted fixture not generated")
     _planted_check(oracle, cases["planted_cfg2_top_l1"])
+
+
+def _planted_mid_inputs(c):
+    """Inputs of a planted_mid.npz case, regenerated from its seed (tests/golden/inputs.py, numpy only)."""
+    from inputs import planted_batch, planted_local_chunk
+    if str(c["kind"]) == "local":
+        return planted_local_chunk(int(c["B"]), int(c["F"]), int(c["tnum"]), int(c["unm_pre"]), int(c["C"]),
+                                   int(c["randf"]), int(c["seed"]))
+    a, b = planted_batch(int(c["src_len"]), int(c["dst_len"]), int(c["C"]), int(c["seed"]), int(c["B"]))
+    return np.concatenate([a, b], axis=1)
+
+
+def _idx_matches(c, got):
+    from inputs import idx_sha
+    for n in ("unm_idx", "src_idx", "dst_idx"):
+        g = np.asarray(got[n]).astype(np.int32)
+        assert tuple(g.shape) == tuple(c[n + "_shape"]), (str(c["name"]), n, g.shape)
+        assert np.array_equal(g[..., :16], c[n + "_head"]), (str(c["name"]), n)
+        assert idx_sha(g) == str(c[n + "_sha256"]), (str(c["name"]), n)
+
+
+@pytest.mark.parametrize("which", ["local", "global_mid", "global_full"])
+def test_planted_mid_and_full_size_golden(oracle, which):
+    """tests/golden/planted_mid.npz (make_golden_mid.py, REFERENCE runs): the local matcher at 256 / 1 024 tokens per frame
+    with C = 320 / 640 (incl. the level-2 shape with carried-over unmerged tokens, aligned batches) and the GLOBAL
+    matcher up to the full cfg-2 sizes 8 704^2 x 640 and 34 816^2 x 320 (both unmerge_chunk values, rectangular,
+    aligned): the oracle reproduces the reference's three index arrays bit for bit (sha256)."""
+    for c in load_cases("planted_mid.npz"):
+        kind, name = str(c["kind"]), str(c["name"])
+        group = "local" if kind == "local" else ("global_full" if int(c["src_len"]) > 10000 else "global_mid")
+        if group != which:
+            continue
+        x = _planted_mid_inputs(c)
+        if kind == "local":
+            m, u, info = oracle.bipartite_soft_matching_randframe(x, int(c["F"]), float(c["ratio"]), int(c["unm_pre"]),
+                                                                  int(c["randf"]), 4, bool(c["align"]))
+        else:
+            m, u, info = oracle.bipartite_soft_matching_2s(x, int(c["src_len"]), float(c["ratio"]), bool(c["align"]),
+                                                           unmerge_chunk=int(c["unmerge_chunk"]))
+            y = np.zeros((x.shape[0], info["unm_num"] + int(c["dst_len"]), 1), np.float32)
+            assert u(y).shape[1] == int(c["unmerged_len"]), name
+        assert info["unm_num"] == int(c["unm_num"]), name
+        _idx_matches(c, info)
 
 
 def test_oracle_vs_reference_fuzz(oracle):
