@@ -209,7 +209,16 @@ class KernelTimer:
         # attention(q, k, vt, heads, M, scale, share): 4 * B * M^2 * C flops (QK^T + PV, all heads)
         self._wrap("attention", "attention", lambda q, k, vt, heads, M, scale, share=1: 4.0 * q.shape[0] * M * M * q.shape[2])
         # attention_kv(q, k, vt, heads, Mq, Mk, scale): 4 * B * Mq * Mk * C executed flops
-        self._wrap("attention_kv", "attention", lambda q, k, vt, heads, Mq, Mk, scale: 4.0 * q.shape[0] * Mq * Mk * q.shape[2])
+        # (with a device-side query bound the executed rows are the per-sample counts, rounded up to whole query blocks
+        # of 256 (d <= 48) / 512 (d <= 96) / 128 queries: read back AFTER the timed region)
+        def kv_flops(q, k, vt, heads, Mq, Mk, scale, use_workspace=True, q_count=None):
+            if q_count is None:
+                return 4.0 * q.shape[0] * Mq * Mk * q.shape[2]
+            d = q.shape[2] // heads
+            qb = 256 if d <= 48 else 512 if d <= 96 else 128
+            keep = q_count.clone()          # the workspace-free tensor may be recycled by the allocator
+            return lambda: 4.0 * float(((keep.cpu().long() + qb - 1) // qb * qb).clamp(max=Mq).sum()) * Mk * q.shape[2]
+        self._wrap("attention_kv", "attention", kv_flops)
         # match_filtered(x0, x1, a_rows, b_rows, align): 2 * B * Ns * Nd * C algorithmic flops
         self._wrap("match_filtered", "matching",
                    lambda x0, x1, ar, br, align, want_flag=False: 2.0 * x0.shape[0] * ar.shape[1] * br.shape[1] * x0.shape[2])
@@ -231,7 +240,12 @@ class KernelTimer:
         for name, fn in self.orig.items():
             setattr(self.lib_mod, name, fn)
 
+    def _resolve(self):
+        for kind, rec in self.records.items():
+            self.records[kind] = [((r[0]() if callable(r[0]) else r[0]), r[1], r[2]) for r in rec]
+
     def summary(self, kind):
+        self._resolve()
         rec = self.records[kind]
         flops = sum(r[0] for r in rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in rec)
@@ -240,12 +254,14 @@ class KernelTimer:
     def largest(self, kind):
         """(flops, average ms, count) of the launches with the most work -- the top-block launches, whose average
         duration is what the rocprofv3 summary under profiles/ lists for the same kernel instantiation."""
+        self._resolve()
         rec = self.records[kind]
         if not rec:
             return 0.0, 0.0, 0
+        # (launches of the largest shape: a device-side query bound lowers the executed flops of some of them)
         top = max(r[0] for r in rec)
-        sel = [r for r in rec if r[0] == top]
-        return top, sum(r[1].elapsed_time(r[2]) for r in sel) / len(sel), len(sel)
+        sel = [r for r in rec if r[0] >= 0.75 * top]
+        return sum(r[0] for r in sel) / len(sel), sum(r[1].elapsed_time(r[2]) for r in sel) / len(sel), len(sel)
 
 
 def _profile_json(name):

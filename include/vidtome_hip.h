@@ -222,6 +222,24 @@ int vtm_attention_kv(const void *q, int64_t ldq, const void *k, int64_t ldk, con
                      int64_t Mk, int64_t Mkp, int64_t d, float scale, int share_groups, void *ws, size_t ws_bytes,
                      vtm_stream_t stream);
 
+/* vtm_attention_kv with a DEVICE-side query bound: sample b only has q_count[b] <= Mq meaningful query rows (the
+ * compacted live queries of vtm_compact_queries); query blocks that start at or beyond the count exit at once, rows
+ * beyond it are not meaningful.  The launch is sized for the host-known bound Mq -- no host round trip. */
+int vtm_attention_kv_bounded(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+                             void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
+                             int64_t Mk, int64_t Mkp, int64_t d, float scale, const int32_t *q_count, void *ws,
+                             size_t ws_bytes, vtm_stream_t stream);
+
+/* vtm_compact_queries -- which attention outputs a global level with the local chunk on the src side actually needs
+ * (bipartite_soft_matching_2s's unmerge, merge.py:439-460, returns for every merged local token the output row of the
+ * anchor token it merged into: `src = gather(dst, dst_idx)`; several local tokens may share one).  loc (B, Ml): merged
+ * position of every local token (< U: its own row; >= U: anchor row loc - U of Nd).  Outputs: qc (B, Ml) the DISTINCT
+ * positions ([0, U) then the matched anchor rows ascending; entries past the count are 0), tmap (B, Ml) the row of
+ * that list each local token reads, count (B) the number of distinct positions.  ws: vtm_compact_queries_ws_bytes. */
+size_t vtm_compact_queries_ws_bytes(int64_t B, int64_t Nd);
+int vtm_compact_queries(const int32_t *loc, int64_t B, int64_t Ml, int64_t U, int64_t Nd, void *ws, size_t ws_bytes,
+                        int32_t *qc, int32_t *tmap, int32_t *count, vtm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * vtm_cfg_ddim -- the caller-side elementwise tail of a denoising step:
  * classifier-free guidance `eps = uncond + guidance * (cond - uncond)` (generate.py:276-278) fused with the

@@ -1051,6 +1051,47 @@ def _site_pass_checks(unet, sites_list, hiddens, B, F, expected_M):
     return outs, plans
 
 
+@pytest.mark.parametrize("B,Ml,U,Nd", [(2, 1000, 400, 700), (1, 17, 0, 5), (3, 34816, 17408, 34816), (2, 300, 300, 64)])
+def test_compact_queries_vs_torch(L, B, Ml, U, Nd):
+    """vtm_compact_queries against a torch restatement: distinct merged positions ([0, U) then the matched anchor rows
+    ascending), the row each local token reads, the per-sample count; entries past the count are valid indices."""
+    g = torch.Generator().manual_seed(Ml + Nd)
+    loc = torch.empty(B, Ml, dtype=torch.int64)
+    for b in range(B):
+        perm = torch.randperm(Ml, generator=g)
+        pos = torch.empty(Ml, dtype=torch.int64)
+        pos[perm[:U]] = torch.arange(U)                                   # unmerged tokens: one row each
+        hot = torch.randint(0, max(1, Nd // 3), (Ml - U,), generator=g)   # merged ones: many share an anchor row
+        pos[perm[U:]] = U + hot
+        loc[b] = pos
+    qc, tmap, count = L.compact_queries(loc.to(torch.int32).to(DEV), U, Nd)
+    qc, tmap, count = qc.cpu().long(), tmap.cpu().long(), count.cpu().long()
+    for b in range(B):
+        want = torch.cat([torch.arange(U), torch.unique(loc[b][loc[b] >= U])])   # unique() sorts ascending
+        n = int(count[b])
+        assert n == want.numel()
+        assert torch.equal(qc[b, :n], want)
+        assert int(qc[b, n:].min() if n < Ml else 0) >= 0 and int(qc[b].max()) < U + Nd
+        assert torch.equal(qc[b][tmap[b]], loc[b])                        # every token finds its own position
+        assert int(tmap[b].max()) < n
+
+
+def test_attention_bounded_equals_unbounded_prefix(L):
+    """vtm_attention_kv_bounded: rows below the per-sample count equal the plain launch's rows bit for bit (same
+    workgroups, same order); the launch covers counts inside the first block, mid-sequence and the full length."""
+    B, h, d, Mq, Mk = 3, 8, 40, 8448, 9000
+    C = h * d
+    g = torch.Generator(device=DEV).manual_seed(5)
+    q = torch.randn(B, Mq, C, generator=g, device=DEV, dtype=torch.float16)
+    k = torch.randn(B, (Mk + 7) // 8 * 8, C, generator=g, device=DEV, dtype=torch.float16)
+    vt = torch.randn(B, C, (Mk + 7) // 8 * 8, generator=g, device=DEV, dtype=torch.float16)
+    full = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5)
+    count = torch.tensor([100, 5000, Mq], dtype=torch.int32, device=DEV)
+    got = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5, q_count=count)
+    for b, n in enumerate(count.tolist()):
+        assert torch.equal(got[b, :n], full[b, :n]), b
+
+
 @pytest.mark.parametrize("F,global_rand", [(4, 0.0), (4, 1.0), (1, 0.5), (8, 0.5)])
 def test_live_queries_equal_full_attention(L, F, global_rand):
     """With a global level the block computes attention only for the merged rows whose output unmerge() reads

@@ -54,6 +54,10 @@ _SIGNATURES = {
     "vtm_attention_ws_bytes": ([_i64, _i64, _i64, _i64, _i64], ctypes.c_size_t),
     "vtm_attention_kv": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                           _f32, _int, _vp, ctypes.c_size_t, _vp], _int),
+    "vtm_attention_kv_bounded": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                  _f32, _vp, _vp, ctypes.c_size_t, _vp], _int),
+    "vtm_compact_queries_ws_bytes": ([_i64, _i64], ctypes.c_size_t),
+    "vtm_compact_queries": ([_vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp], _int),
     "vtm_cfg_ddim": ([_vp, _vp, _vp, _int, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp], _int),
     "vtm_layernorm": ([_vp, _vp, _vp, _int, _i64, _i64, _f32, _vp, _vp], _int),
     "vtm_geglu": ([_vp, _int, _i64, _i64, _vp, _vp], _int),
@@ -378,9 +382,10 @@ def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[to
 
 @_on_device
 def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, Mq: int, Mk: int, scale: float,
-                 use_workspace: bool = True) -> torch.Tensor:
+                 use_workspace: bool = True, q_count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Cross-attention core (patch.py:178-183): q (B, Mqp, C), k (B, Mkp, C) views contiguous along the last axis,
-    vt (B, C, ldvt >= Mk) = v transposed.  Returns (B, Mqp, C)."""
+    vt (B, C, ldvt >= Mk) = v transposed.  Returns (B, Mqp, C).  ``q_count`` (B,) int32 on the device: only the first
+    q_count[b] query rows of sample b are meaningful (compact_queries); the other rows of the result are undefined."""
     B, Mqp, C = q.shape
     Mkp = k.shape[1]
     d = C // heads
@@ -391,10 +396,33 @@ def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
     out = torch.zeros((B, Mqp, C), dtype=q.dtype, device=q.device) if Mqp != Mq else \
         torch.empty((B, Mqp, C), dtype=q.dtype, device=q.device)
     ws, nb = _attention_ws(B, heads, Mq, Mk, d, q.device) if use_workspace else (None, 0)
+    if q_count is not None:
+        if q_count.dtype != torch.int32 or q_count.numel() != B or not q_count.is_cuda:
+            raise RuntimeError("attention_kv: q_count must be a (B,) int32 device tensor")
+        _check(lib().vtm_attention_kv_bounded(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(),
+                                              vt.stride(1), out.data_ptr(), C, dtype_code(q), B, heads, Mq, Mqp, Mk, Mkp,
+                                              d, float(scale), _ptr(q_count), _ptr(ws), nb, _stream()),
+               "vtm_attention_kv_bounded")
+        return out
     _check(lib().vtm_attention_kv(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(), vt.stride(1),
                                   out.data_ptr(), C, dtype_code(q), B, heads, Mq, Mqp, Mk, Mkp, d, float(scale), 1,
                                   _ptr(ws), nb, _stream()), "vtm_attention_kv")
     return out
+
+
+@_on_device
+def compact_queries(loc: torch.Tensor, U: int, Nd: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """loc (B, Ml) merged position of every local token -> (qc (B, Ml) distinct positions, tmap (B, Ml) row of qc each
+    local token reads, count (B,) number of distinct positions); see include/vidtome_hip.h."""
+    _req(loc, "loc")
+    B, Ml = loc.shape
+    i32 = dict(dtype=torch.int32, device=loc.device)
+    qc, tmap, count = torch.empty((B, Ml), **i32), torch.empty((B, Ml), **i32), torch.empty((B,), **i32)
+    nb = int(lib().vtm_compact_queries_ws_bytes(B, Nd))
+    ws = _workspace("compact", nb, loc.device)
+    _check(lib().vtm_compact_queries(_ptr(loc), B, Ml, U, Nd, _ptr(ws), nb, _ptr(qc), _ptr(tmap), _ptr(count), _stream()),
+           "vtm_compact_queries")
+    return qc, tmap, count
 
 
 @_on_device

@@ -196,7 +196,7 @@ __device__ __forceinline__ void write_output16(const f32x4 (&o)[(D + 16) / 16][2
 template <typename T, int D>
 __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
     const float *__restrict__ partial, T *__restrict__ out, int64_t ldo, int64_t H, int64_t M, int64_t Mp, int64_t nqb,
-    int64_t id0, int nsplit, int xcd_groups) {
+    int64_t id0, int nsplit, int xcd_groups, const int32_t *__restrict__ q_count) {
     constexpr int WAVES = waves_for(D), NT = WAVES * 64, QB = WAVES * QW, DV = (D + 31) / 32;
     constexpr bool PV16 = pv16_for(D);
     constexpr int NA = acc_floats(D), NM = max_floats(D), REC = rec_floats(D);
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
     const int64_t lin = item_of(id0 + blockIdx.x, nqb, xcd_groups);
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
+    if (q_count != nullptr && (lin % nqb) * QB >= (int64_t)q_count[b]) return;   // its partial records were never written
     float acc[NA], m[NM], l = 0.0f;
 #pragma unroll
     for (int r = 0; r < NA; ++r) acc[r] = 0.0f;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
     int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t nwhole,
-    int nsplit_tail, float *__restrict__ partial_base, int xcd_groups) {
+    int nsplit_tail, float *__restrict__ partial_base, int xcd_groups, const int32_t *__restrict__ q_count) {
     // M / Mp: queries per sample and their row stride; Mk / Mkp: keys per sample and the row stride of k
     // (self-attention passes the same values; cross-attention, patch.py:178-183, has Mk = 77).
     // Work decomposition: work item = (query block, head, sample), query blocks fastest.  Workgroups [0, nwhole) take
@@ -296,6 +297,9 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const int64_t bq = b % src_batch;  // PnP injection: q/k of the source sample (pnp_utils.py:57-67)
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
     const int64_t C = H * D;
+    // device-side query bound (compacted live queries, vtm_compact_queries): the launch is sized for the host-known
+    // upper bound M; a query block that starts at or beyond its sample's count has nothing anybody reads
+    if (q_count != nullptr && (lin % nqb) * QB >= (int64_t)q_count[b]) return;
 
     // one-time LDS init: K pad columns = 0 (they meet Q's zero padding; garbage could be NaN), V^T pad rows
     // = 0 except row D = 1 (denominator row) -- tile loads never touch these
@@ -693,7 +697,7 @@ TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk) {
 template <typename T, int D>
 int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt, void *out,
            int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale, int share_groups,
-           void *ws, size_t ws_bytes, hipStream_t s) {
+           void *ws, size_t ws_bytes, const int32_t *q_count, hipStream_t s) {
     constexpr int DK = (D + 15) / 16;
     constexpr size_t lds = (size_t)2 * (KV * (DK * 16 + 8) + vrows_for(D) * VT_STRIDE) * 2;
     if (lds > 64 * 1024) {   // opt in to > 64 KB of dynamic LDS once per (kernel instantiation, device)
@@ -728,27 +732,27 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
 #endif
     hipLaunchKernelGGL((attention_kernel<T, D>), dim3((unsigned)(p.full + rem * p.nsplit)), dim3(WAVES * 64), lds, s,
                        (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
-                       scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws, xcd_groups);
+                       scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws, xcd_groups, q_count);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem), dim3(WAVES * 64), 0, s,
-                           (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups);
+                           (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups, q_count);
     return vtm::launch_status("vtm_attention");
 }
 
 template <typename T>
 int dispatch(int64_t d, const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
              void *out, int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale, int sg,
-             void *ws, size_t ws_bytes, hipStream_t s) {
+             void *ws, size_t ws_bytes, const int32_t *q_count, hipStream_t s) {
     switch (d) {
-        case 40: return launch<T, 40>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
-        case 64: return launch<T, 64>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
-        case 80: return launch<T, 80>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
-        case 160: return launch<T, 160>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
-        case 8: return launch<T, 8>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
-        case 16: return launch<T, 16>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
-        case 32: return launch<T, 32>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
-        case 96: return launch<T, 96>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
-        case 128: return launch<T, 128>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, s);
+        case 40: return launch<T, 40>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, q_count, s);
+        case 64: return launch<T, 64>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, q_count, s);
+        case 80: return launch<T, 80>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, q_count, s);
+        case 160: return launch<T, 160>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, q_count, s);
+        case 8: return launch<T, 8>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, q_count, s);
+        case 16: return launch<T, 16>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, q_count, s);
+        case 32: return launch<T, 32>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, q_count, s);
+        case 96: return launch<T, 96>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, q_count, s);
+        case 128: return launch<T, 128>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, M, Mp, Mk, Mkp, scale, sg, ws, ws_bytes, q_count, s);
     }
     return vtm::fail(VTM_EINVAL, "vtm_attention: unsupported head dim %lld (have 8,16,32,40,64,80,96,128,160)",
                      (long long)d);
@@ -772,10 +776,10 @@ VTM_EXPORT size_t vtm_attention_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64
     return 0;
 }
 
-VTM_EXPORT int vtm_attention_kv(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
-                                void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp, int64_t Mk,
-                                int64_t Mkp, int64_t d, float scale, int share_groups, void *ws, size_t ws_bytes,
-                                vtm_stream_t stream) {
+static int attention_any(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+                         void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp, int64_t Mk,
+                         int64_t Mkp, int64_t d, float scale, int share_groups, void *ws, size_t ws_bytes,
+                         const int32_t *q_count, vtm_stream_t stream) {
     VTM_REQUIRE(q && k && vt && out, "vtm_attention: null pointer");
     VTM_REQUIRE(B > 0 && h > 0 && Mq > 0 && Mk > 0 && d > 0 && Mqp >= Mq && Mkp >= Mk, "vtm_attention: bad sizes");
     VTM_REQUIRE(share_groups >= 1 && B % share_groups == 0, "vtm_attention: B %% share_groups != 0");
@@ -787,11 +791,28 @@ VTM_EXPORT int vtm_attention_kv(const void *q, int64_t ldq, const void *k, int64
     hipStream_t s = vtm::as_stream(stream);
     if (dtype == VTM_F16)
         return dispatch<__half>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws,
-                                ws_bytes, s);
+                                ws_bytes, q_count, s);
     if (dtype == VTM_BF16)
         return dispatch<vtm_bf16>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws,
-                                  ws_bytes, s);
+                                  ws_bytes, q_count, s);
     return vtm::fail(VTM_EINVAL, "vtm_attention: dtype must be VTM_F16 or VTM_BF16");
+}
+
+VTM_EXPORT int vtm_attention_kv(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+                                void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp, int64_t Mk,
+                                int64_t Mkp, int64_t d, float scale, int share_groups, void *ws, size_t ws_bytes,
+                                vtm_stream_t stream) {
+    return attention_any(q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, Mq, Mqp, Mk, Mkp, d, scale, share_groups, ws,
+                         ws_bytes, nullptr, stream);
+}
+
+VTM_EXPORT int vtm_attention_kv_bounded(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+                                        void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
+                                        int64_t Mk, int64_t Mkp, int64_t d, float scale, const int32_t *q_count, void *ws,
+                                        size_t ws_bytes, vtm_stream_t stream) {
+    VTM_REQUIRE(q_count, "vtm_attention_kv_bounded: null q_count");
+    return attention_any(q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, Mq, Mqp, Mk, Mkp, d, scale, 1, ws, ws_bytes,
+                         q_count, stream);
 }
 
 VTM_EXPORT int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt,

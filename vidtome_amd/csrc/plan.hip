@@ -135,7 +135,91 @@ __global__ __launch_bounds__(256) void decode_best_kernel(const uint64_t *__rest
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)vtm::cdiv(n, 256); }
 
+// Distinct attention queries of a global level whose src side is the local chunk (merge.py:439-460 + patch.py:59-82).
+// `loc[b, t]` is the merged position of local token t: an unmerged token has a position of its own in [0, U), a merged
+// one the position U + j of the anchor row j it merged into -- and several local tokens may have merged into the same
+// anchor row, whose attention output would then be computed once per token.  One workgroup per sample builds
+//   qc[b, :]   the DISTINCT merged positions: [0 .. U) then U + j for every matched j, ascending; entries past the
+//              count repeat position 0 (valid rows for the projection GEMM that nobody reads)
+//   tmap[b, t] the row of that compact list local token t reads its attention output from
+//   count[b]   number of distinct queries
+// with a presence bitmap + a block-wide prefix sum (Nd <= ~10^5 per sample: tens of microseconds, no host round trip).
+constexpr int CQ_THREADS = 1024;
+
+__global__ __launch_bounds__(CQ_THREADS) void compact_queries_kernel(const int32_t *__restrict__ loc, int64_t Ml, int64_t U,
+                                                                    int64_t Nd, int32_t *__restrict__ flag,
+                                                                    int32_t *__restrict__ qc, int32_t *__restrict__ tmap,
+                                                                    int32_t *__restrict__ count) {
+    __shared__ int32_t wave_sum[CQ_THREADS / 64];
+    __shared__ int32_t total_s;
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *lb = loc + b * Ml;
+    int32_t *fb = flag + b * Nd, *qb = qc + b * Ml, *tb = tmap + b * Ml;
+    for (int64_t j = tid; j < Nd; j += CQ_THREADS) fb[j] = 0;
+    __syncthreads();
+    for (int64_t t = tid; t < Ml; t += CQ_THREADS) {
+        const int32_t p = lb[t];
+        if (p >= U) fb[p - U] = 1;                    // benign race: every writer stores 1
+    }
+    __syncthreads();
+    // exclusive prefix sum of the presence flags; thread i owns the contiguous slice [i * per, (i + 1) * per)
+    const int64_t per = (Nd + CQ_THREADS - 1) / CQ_THREADS;
+    const int64_t j0 = (int64_t)tid * per, j1 = j0 + per < Nd ? j0 + per : Nd;
+    int32_t mine = 0;
+    for (int64_t j = j0; j < j1; ++j) mine += fb[j];
+    int32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t run = 0;
+        for (int w = 0; w < CQ_THREADS / 64; ++w) {
+            const int32_t v = wave_sum[w];
+            wave_sum[w] = run;
+            run += v;
+        }
+        total_s = run;
+    }
+    __syncthreads();
+    int32_t rank = wave_sum[wave] + incl - mine;
+    for (int64_t j = j0; j < j1; ++j) {
+        const int32_t f = fb[j];
+        fb[j] = rank;                                  // flag -> rank of anchor row j among the matched ones
+        if (f) qb[U + rank] = (int32_t)(U + j);
+        rank += f;
+    }
+    const int64_t cnt = U + total_s;
+    if (tid == 0) count[b] = (int32_t)cnt;
+    for (int64_t t = tid; t < U; t += CQ_THREADS) qb[t] = (int32_t)t;
+    for (int64_t t = cnt + tid; t < Ml; t += CQ_THREADS) qb[t] = 0;
+    __syncthreads();
+    for (int64_t t = tid; t < Ml; t += CQ_THREADS) {
+        const int32_t p = lb[t];
+        tb[t] = p < U ? p : (int32_t)(U + fb[p - U]);
+    }
+}
+
 }  // namespace
+
+VTM_EXPORT size_t vtm_compact_queries_ws_bytes(int64_t B, int64_t Nd) { return (size_t)(B > 0 && Nd > 0 ? B * Nd * 4 : 0); }
+
+VTM_EXPORT int vtm_compact_queries(const int32_t *loc, int64_t B, int64_t Ml, int64_t U, int64_t Nd, void *ws,
+                                   size_t ws_bytes, int32_t *qc, int32_t *tmap, int32_t *count, vtm_stream_t stream) {
+    VTM_REQUIRE(loc && ws && qc && tmap && count, "vtm_compact_queries: null pointer");
+    VTM_REQUIRE(B > 0 && Ml > 0 && U >= 0 && U <= Ml && Nd > 0, "vtm_compact_queries: bad sizes");
+    VTM_REQUIRE(U + Nd < (1ll << 31), "vtm_compact_queries: index space overflow");
+    if (ws_bytes < vtm_compact_queries_ws_bytes(B, Nd))
+        return vtm::fail(VTM_EWORKSPACE, "vtm_compact_queries: workspace %zu < %zu bytes", ws_bytes,
+                         vtm_compact_queries_ws_bytes(B, Nd));
+    hipLaunchKernelGGL(compact_queries_kernel, dim3((unsigned)B), dim3(CQ_THREADS), 0, vtm::as_stream(stream), loc, Ml, U, Nd,
+                       static_cast<int32_t *>(ws), qc, tmap, count);
+    return vtm::launch_status("vtm_compact_queries");
+}
 
 VTM_EXPORT int vtm_partition_counts(int64_t N_in, int64_t unm_pre, int64_t tnum, int64_t ts,
                                     int64_t randf, int64_t *Ns, int64_t *Nd) {

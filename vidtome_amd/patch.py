@@ -35,6 +35,11 @@ from .utils import init_generator, isinstance_str, join_frame, split_frame
 # Attention over the merged sequence computes outputs only for the rows unmerge() reads (see MergePlan.q_rows);
 # VIDTOME_LIVE_QUERIES=0 computes every row like the reference does (same block output, more work).
 LIVE_QUERIES = os.environ.get("VIDTOME_LIVE_QUERIES", "1") != "0"
+# With the local chunk on the src side of the global level several local tokens may have merged into the SAME anchor
+# token; its attention output is then computed once and shared (device-side compaction of the live queries, no host
+# sync: the attention launch is sized for the upper bound and query blocks past the per-sample count exit).
+# VIDTOME_COMPACT_QUERIES=0 computes one query per local token (round 2's behaviour; same block output).
+COMPACT_QUERIES = os.environ.get("VIDTOME_COMPACT_QUERIES", "1") != "0"
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -44,7 +49,7 @@ class MergePlan:
     """What ``compute_merge`` produces for one block call: composed maps + the merged tokens."""
 
     __slots__ = ("fsize", "L", "M", "gather_map", "inv", "_merged", "levels", "global_level", "local_chunk",
-                 "x_joined", "anchors_in", "q_rows", "inv_q", "pad_to")
+                 "x_joined", "anchors_in", "q_rows", "inv_q", "q_count", "pad_to")
 
     def __init__(self):
         self.levels = []
@@ -58,8 +63,12 @@ class MergePlan:
         # sequence also contains the other chunk's tokens; they are keys / values, but nobody reads their
         # attention OUTPUT (merge.py:459 returns the local part only), so the block computes attention for
         # the q_rows queries only -- a third fewer at global_merge_ratio 0.5, same block output.
+        # q_count (B,) int32 on the device, or None: with the local chunk on the src side q_rows lists every DISTINCT
+        # merged position once (several local tokens may share an anchor row) and only its first q_count[b] entries
+        # are queries; inv_q then maps through that compact list.
         self.q_rows = None
         self.inv_q = None
+        self.q_count = None
         self._merged = None
         self.pad_to = 8
 
@@ -155,7 +164,12 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 # patch.py:80: new anchors = u(merged) = the local tokens with every merged local src row
                 # replaced by its matched global row -> one gather from [chunk | old anchors]
                 anchors_out = _lib.gather_rows(xj, gt, _lib.compose(loc, gl.new_cur, Ml))
-                plan.q_rows, plan.inv_q = loc, inv
+                if local_is_src and COMPACT_QUERIES:
+                    qc, tmap, plan.q_count = _lib.compact_queries(loc, gl.Ns - gl.r, gl.Nd)
+                    plan.q_rows = qc
+                    plan.inv_q = _lib.compose(inv, tmap, L) if inv is not None else tmap
+                else:
+                    plan.q_rows, plan.inv_q = loc, inv
                 inv = _lib.compose(inv, loc, L) if inv is not None else loc
                 cur = gl.new_cur
                 n_cur = cur.shape[1]
@@ -326,7 +340,8 @@ def _weight(m: torch.nn.Module, dtype) -> torch.Tensor:
 
 
 def self_attention_rows(attn: torch.nn.Module, x0: torch.Tensor, x1: Optional[torch.Tensor],
-                        rows: Optional[torch.Tensor], q_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+                        rows: Optional[torch.Tensor], q_rows: Optional[torch.Tensor] = None,
+                        q_count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``attn1(merged)`` (patch.py:157-162; arithmetic of pnp_utils.py:47-95) with ``merged[b, i] = pool[b, rows[b, i]]``
     never materialised: every projection is a vtm_linear_rows GEMM that fetches its A rows through the composed merge
     map (pool = x0 | x1, ``rows`` None = the rows of x0 as they are), k and v for all M rows (v channel-major, what the
@@ -353,13 +368,13 @@ def self_attention_rows(attn: torch.nn.Module, x0: torch.Tensor, x1: Optional[to
         Mq = q_rows.shape[1]
         k_op = _lib.linear_rows(x0, x1, rows, None, M, wqk[C:], None if bqk is None else bqk[C:])
         q_op = _lib.linear_rows(x0, x1, rows, q_rows, Mq, wqk[:C], None if bqk is None else bqk[:C])
-        o = _lib.attention_kv(q_op, k_op, vt, heads, Mq, M, scale)
+        o = _lib.attention_kv(q_op, k_op, vt, heads, Mq, M, scale, q_count=q_count)
     to_out = _out_linear(attn)
     return _lib.linear_rows(o, None, None, None, Mq, _weight(to_out, dt), None if to_out.bias is None else to_out.bias.to(dt))
 
 
 def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = None,
-                   q_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   q_rows: Optional[torch.Tensor] = None, q_count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``attn1(x)`` for self-attention without mask (patch.py:157-162), arithmetic of pnp_utils.py:47-95:
     q,k,v projections -> softmax(q k^T * scale) v per head -> to_out[0] (+ dropout(0)), on MATERIALISED tokens with
     library GEMMs (torch -> hipBLASLt) for the projections: the path of fp32 models, of channel counts the
@@ -409,7 +424,9 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
     if q_rows is None:
         o = _lib.attention(q_op, k_op, vt, heads, M, scale, share)
     else:
-        o = _lib.attention_kv(q_op, k_op, vt, heads, q_rows.shape[1], M, scale)
+        o = _lib.attention_kv(q_op, k_op, vt, heads, q_rows.shape[1], M, scale, q_count=q_count)
+        # (q_count: rows past the count are undefined; the output projection is row-wise, so they stay confined to
+        # rows unmerge() never reads)
     to_out = _out_linear(attn)
     o = o.to(x.dtype)
     return F.linear(o, to_out.weight.to(o.dtype), None if to_out.bias is None else to_out.bias.to(o.dtype))
@@ -483,13 +500,15 @@ def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.
         live = (plan is not None and plan.q_rows is not None and gate_msa is None and LIVE_QUERIES
                 and _pnp_share_groups(block.attn1) == 1)
         q_rows = plan.q_rows if live else None
+        q_count = plan.q_count if live else None
         if by_rows:
             if plan is None:                                              # block does not merge: per-frame attention
                 attn_output = self_attention_rows(block.attn1, norm_hidden_states.contiguous(), None, None)
             else:
-                attn_output = self_attention_rows(block.attn1, plan.x_joined, plan.anchors_in, plan.gather_map, q_rows)
+                attn_output = self_attention_rows(block.attn1, plan.x_joined, plan.anchors_in, plan.gather_map, q_rows,
+                                                  q_count)
         else:
-            attn_output = self_attention(block.attn1, merged, plan.M if plan is not None else None, q_rows)
+            attn_output = self_attention(block.attn1, merged, plan.M if plan is not None else None, q_rows, q_count)
         if live:
             # rows are the chunk's local merged tokens: unmerge with the local levels' map alone
             # (= the global level's unmerge, merge.py:439-460, folded into the choice of queries)
