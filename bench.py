@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--chunks-per-step", type=int, default=8,
                     help="N = 1: chunks of a denoising step -- the anchor chain is re-seeded every chunks_per_step - 1 "
                          "passes with the first chunk's local tokens (the reference resets the anchors after every step)")
+    ap.add_argument("--full-block", action="store_true",
+                    help="secondary measurement (NOT the headline): every pass runs the WHOLE patched block at the 16 sites -- "
+                         "the hot-path segment plus the cross-attention over 77 text tokens and the GEGLU feed-forward "
+                         "(patch.py:171-199)")
     ap.add_argument("--same-chunk", action="store_true",
                     help="rounds 1-2's regime: every pass processes the same chunk (anchors = copies of its own rows)")
     ap.add_argument("--event-every", type=int, default=5,
@@ -187,7 +191,7 @@ class KernelTimer:
         self.lib_mod = lib_mod
         self.orig = {}
         self.records = {"attention": [], "matching": [], "layernorm": [], "gather_rows": [], "unmerge_add": [],
-                        "projections": []}
+                        "projections": [], "ff_geglu": [], "linear_panels": [], "layernorm_panels": []}
         self.enabled = False
 
     def _wrap(self, name, kind, flops_of):
@@ -232,6 +236,10 @@ class KernelTimer:
         self._wrap("linear_rows", "projections",
                    lambda x0, x1, rows, rows2, n, weight, bias=None, transposed=False, pad_to=8, out=None:
                    2.0 * x0.shape[0] * n * weight.shape[0] * weight.shape[1])
+        # panel GEMMs of the full block (csrc/ff.hip): flops = 2 n K (rows of the weight operand)
+        self._wrap("ff_geglu", "ff_geglu", lambda xp, n, w1, D, bias: 2.0 * n * xp.shape[0] * 8 * 2 * D)
+        self._wrap("linear_panels", "linear_panels", lambda xp, n, w, N, bias, resid=None: 2.0 * n * xp.shape[0] * 8 * N)
+        self._wrap("layernorm_panels", "layernorm_panels", lambda x, w, b, eps: 2.0 * x.numel() * esz(x))
         self._wrap("unmerge_add", "unmerge_add",
                    lambda y, inv, resid: (2.0 + (resid is not None)) * inv.numel() * y.shape[2] * esz(y))
         return self
@@ -425,7 +433,7 @@ def main():
     import vidtome_amd
     from vidtome_amd import _lib, sites
 
-    unet = sites.SiteUNet(sites.sd15_sites(), seed=0).to(device=dev, dtype=torch.float16)
+    unet = sites.SiteUNet(sites.sd15_sites(), seed=0, full=args.full_block).to(device=dev, dtype=torch.float16)
     vidtome_amd.apply_patch(unet, local_merge_ratio=LOCAL_RATIO, merge_global=not args.local_only,
                             global_merge_ratio=GLOBAL_RATIO, batch_size=BATCH, target_stride=4, global_rand=0.5)
     unet.set_size(LATENT)
@@ -454,7 +462,9 @@ def main():
     stream = sites.ClipStream(unet, site_list, BATCH, FRAMES, LATENT, torch.float16, dev, n_sets=args.chunks,
                               chunks_per_step=args.chunks_per_step, same_chunk=args.same_chunk, rank=rank,
                               reseed=ex is None,
-                              sets=None if ex is None else {(p_ * world + rank) % K for p_ in range(total_passes)})
+                              sets=None if ex is None else {(p_ * world + rank) % K for p_ in range(total_passes)},
+                              cond=(torch.randn(BATCH * FRAMES, 77, 768, generator=torch.Generator().manual_seed(77))
+                                    .to(device=dev, dtype=torch.float16) if args.full_block else None))
     passes = [0]
 
     def step():
@@ -464,7 +474,7 @@ def main():
             return stream.step(c)
         ex.begin_chunk(c)
         with torch.no_grad():
-            return sites.run_segment_pass(unet, stream.sets[c % K])
+            return stream._run(stream.sets[c % K])
 
     def fence():
         torch.cuda.synchronize()
@@ -531,7 +541,8 @@ def main():
                     "allgather": ", RCCL all-gather of the anchor tokens per merging block",
                     "ring": ", exact serial anchor chain (ring hand-off over RCCL/xGMI)"}[mode]
         line = {
-            "metric": "denoising steps/sec, 16-frame 512x512 SD-1.5 chunk, ratio=0.5",
+            "metric": "denoising steps/sec, 16-frame 512x512 SD-1.5 chunk, ratio=0.5" +
+                      (" -- FULL transformer blocks (secondary measurement, not the headline)" if args.full_block else ""),
             "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
@@ -558,6 +569,7 @@ def main():
                                    f"chunk's local tokens like a denoising step of {args.chunks_per_step} chunks "
                                    f"(generate.py:233-236)" if ex is None else
                                    "anchors as the exchange mode defines them")),
+                       "full_block": bool(args.full_block),
                        "sites": 16, "merged_sites": 10, "chunk_frames": FRAMES, "batch": BATCH,
                        "matcher": _merge.MATCH_MODE + (" (fp16-MFMA filter, fp32 refine; global-level index order inside "
                                                        "groups of EXACTLY equal similarity is the stable one, the "
@@ -601,7 +613,22 @@ def main():
                             "gather_rows": hbm("gather_rows"), "unmerge_add": hbm("unmerge_add"),
                             "pmc": pmc_gather_path()},
         }
-        if not args.no_cpu_baseline and world == 1:           # reported on rank 0 at N = 1 only
+        if args.full_block:
+            def gemm(kind):
+                f, ms, n = mt.summary(kind)
+                lf, lms, ln = mt.largest(kind)
+                return {"launches": n, "ms_per_step": round(ms / timed_passes, 3),
+                        "tflops": round(f / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0,
+                        "frac_of_fp16_mfma_peak": round(f / (ms * 1e-3) / 1e12 / FP16_PEAK_TFLOPS, 4) if ms > 0 else 0.0,
+                        "largest": {"launches": ln, "avg_us": round(lms * 1e3, 1),
+                                    "tflops": round(lf / (lms * 1e-3) / 1e12, 1) if lms > 0 else 0.0}}
+            line["full_block"] = {
+                "what": "the whole patched block per site: hot-path segment + norm2 / attn2 (77 text tokens) + norm3 / GEGLU "
+                        "feed-forward (patch.py:171-199); panel GEMMs of csrc/ff.hip unless VIDTOME_FF=blas",
+                "ff_mode": __import__("vidtome_amd.patch", fromlist=["FF_MODE"]).FF_MODE,
+                "ff_geglu": gemm("ff_geglu"), "linear_panels": gemm("linear_panels"),
+                "layernorm_panels": hbm("layernorm_panels")}
+        if not args.no_cpu_baseline and world == 1 and not args.full_block:   # rank 0 at N = 1 only; the CPU leg times the segment
             line["cpu_baseline"] = (cpu_baseline_torch if args.cpu_baseline == "torch" else cpu_baseline_port)(
                 args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -241,6 +241,32 @@ int vtm_compact_queries(const int32_t *loc, int64_t B, int64_t Ml, int64_t U, in
                         int32_t *qc, int32_t *tmap, int32_t *count, vtm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Panel GEMMs -- the rest of the patched block around the hot path (vidtome/patch.py:171-199): the feed-forward
+ * `self.ff(self.norm3(hidden_states)) + hidden_states` (Diffusers FeedForward of SD blocks: GEGLU(Linear C -> 8C), Linear
+ * 4C -> C) and the query projection of the cross-attention `self.attn2(self.norm2(hidden_states), ...)`.
+ * Operands are k-panels: [K / 8][rows_pad][8 elements], rows_pad = vtm_panel_rows(rows) (a multiple of 256); padding
+ * rows may hold anything.  Token operands come from vtm_layernorm_panels (or vtm_to_panels), weights are packed once
+ * with vtm_to_panels (`order` = the row permutation below, or NULL).
+ *   vtm_layernorm_panels  torch.nn.LayerNorm with its result written as panels (norm3 / norm2).
+ *   vtm_ff_geglu          out = value * gelu(gate) of  x W1^T + b1  (erf gelu), written as panels [D / 8][n_pad][8] -- the
+ *                         2D-wide projection is never written.  W1 is packed in TILE order: 128-row tile t = the value rows of
+ *                         output channels 64 t .. 64 t + 63 followed by their gate rows (rows D + 64 t ..); bias (2 D fp32) in
+ *                         the same order.  D % 64 == 0, K % 64 == 0.
+ *   vtm_linear_panels     out (n, ldo) token rows = x W^T (+ bias fp32 (N)) (+ resid (n, ldo)), rounded like torch's Linear
+ *                         followed by the residual add.  N % 8 == 0, K % 64 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t vtm_panel_rows(int64_t n);
+int vtm_to_panels(const void *x, int dtype, int64_t rows, int64_t C, const int32_t *order, void *out, int64_t rows_pad,
+                  vtm_stream_t stream);
+int vtm_layernorm_panels(const void *x, const void *gamma, const void *beta, int dtype, int64_t rows, int64_t C, float eps,
+                         void *out, int64_t panel_rows, vtm_stream_t stream);
+int vtm_ff_geglu(const void *x_panels, int64_t n, int64_t n_pad, const void *w1_panels, int64_t D, int64_t w_rows_pad,
+                 int64_t K, const float *bias, int dtype, void *out_panels, vtm_stream_t stream);
+int vtm_linear_panels(const void *x_panels, int64_t n, int64_t n_pad, const void *w_panels, int64_t N, int64_t w_rows_pad,
+                      int64_t K, const float *bias, const void *resid, int dtype, void *out, int64_t ldo,
+                      vtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * vtm_cfg_ddim -- the caller-side elementwise tail of a denoising step:
  * classifier-free guidance `eps = uncond + guidance * (cond - uncond)` (generate.py:276-278) fused with the
  * closed-form DDIM update of `pred_next_x` (generate.py:281-311):

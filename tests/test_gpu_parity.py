@@ -855,6 +855,89 @@ def test_cross_attention_and_ff_vs_torch_fp32(L, B, N, Mk, C, heads):
         assert (z - r).abs().max() < 4e-3 * max(1.0, float(r.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(300, 320), (1000, 640), (70, 1280), (512, 64)])
+def test_layernorm_panels_and_to_panels(L, rows, C, dtype):
+    """vtm_layernorm_panels == vtm_layernorm bit for bit, laid out as k-panels [C / 8][rows_pad][8]; vtm_to_panels with and
+    without a row order."""
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g).to(dtype).to(DEV)
+    w, b = (1 + 0.1 * torch.randn(C, generator=g)).to(dtype).to(DEV), (0.1 * torch.randn(C, generator=g)).to(dtype).to(DEV)
+    y = L.layernorm(x, w, b, 1e-5)
+    yp = L.layernorm_panels(x, w, b, 1e-5)
+    assert yp.shape == (C // 8, L.panel_rows(rows), 8)
+    assert torch.equal(yp[:, :rows].permute(1, 0, 2).reshape(rows, C), y)
+    xp = L.to_panels(x)
+    assert torch.equal(xp[:, :rows].permute(1, 0, 2).reshape(rows, C), x) and not xp[:, rows:].any()
+    order = torch.randperm(rows, generator=g)[: rows // 2].to(torch.int32)
+    order[3] = -1
+    op = L.to_panels(x, order.to(DEV))
+    want = x[order.long().clamp(min=0)]
+    want[3] = 0
+    assert torch.equal(op[:, :rows // 2].permute(1, 0, 2).reshape(rows // 2, C), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,C,bias", [(300, 320, True), (1000, 640, True), (70, 1280, False), (4096, 320, True), (513, 64, True)])
+def test_ff_panels_vs_torch_fp32(L, rows, C, bias, dtype, monkeypatch):
+    """`ff(norm3(h)) + h` (patch.py:187-199) as LayerNorm -> panels, GEGLU projection with the gated activation in the
+    GEMM's epilogue, output Linear + bias + residual -- against plain PyTorch fp32 on the same rounded inputs / weights, and
+    against the unfused library path of round 2 (same roundings of the projection, gelu and product)."""
+    from vidtome_amd import patch as vpatch
+    torch.manual_seed(rows + C)
+    ff = _FeedForward(C).eval()
+    norm = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.1 * torch.randn(C))
+        norm.bias.copy_(0.1 * torch.randn(C))
+        if not bias:
+            ff.net[0].proj.bias = None
+            ff.net[2].bias = None
+    ff, norm = ff.to(dtype), norm.to(dtype)
+    h = (1.5 * torch.randn(2, rows // 2 if rows % 2 == 0 else rows, C)).to(dtype)
+    with torch.no_grad():
+        ref_ff, ref_norm = _FeedForward(C).eval(), torch.nn.LayerNorm(C)
+        if not bias:
+            ref_ff.net[0].proj.bias = None
+            ref_ff.net[2].bias = None
+        ref_ff.load_state_dict({k_: v_.float() for k_, v_ in ff.state_dict().items()})
+        ref_norm.load_state_dict({k_: v_.float() for k_, v_ in norm.state_dict().items()})
+        ref = ref_ff(ref_norm(h.float())) + h.float()
+        ffd, nd, hd = ff.to(DEV), norm.to(DEV), h.to(DEV)
+        assert vpatch.fused_ff_ok(nd, ffd, hd)
+        y = vpatch.norm_feed_forward_residual(nd, ffd, hd)
+        z = vpatch.feed_forward(ffd, vpatch.layer_norm(nd, hd)) + hd                # library GEMMs + vtm_geglu
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    scale = max(1.0, float(ref.abs().max()))
+    assert y.shape == h.shape
+    assert (y.float().cpu() - ref).abs().max() < tol * scale
+    assert (y.float() - z.float()).abs().max().item() < (2e-3 if dtype == torch.float16 else 2e-2) * scale
+
+
+@pytest.mark.parametrize("B,N,Mk,C,heads", [(4, 256, 77, 320, 8), (2, 104, 77, 640, 8), (16, 64, 77, 1280, 8)])
+def test_cross_attention_panels_vs_torch_fp32(L, B, N, Mk, C, heads):
+    """`attn2(norm2(h), enc) + h` (patch.py:171-185) with the query and output projections as panel GEMMs."""
+    from standin import Attention
+    from vidtome_amd import patch as vpatch
+    torch.manual_seed(N + C)
+    attn = Attention(C, heads).eval().half()
+    norm = torch.nn.LayerNorm(C).half()
+    h = torch.randn(B, N, C).half()
+    enc = torch.randn(B, Mk, C).half()
+    with torch.no_grad():
+        w = lambda m: m.weight.float()
+        nh = torch.nn.functional.layer_norm(h.float(), (C,), norm.weight.float(), norm.bias.float(), norm.eps).half().float()
+        q, k, v = nh @ w(attn.to_q).t(), enc.float() @ w(attn.to_k).t(), enc.float() @ w(attn.to_v).t()
+        q, k, v = (t.half().float().reshape(B, -1, heads, C // heads).transpose(1, 2) for t in (q, k, v))
+        p = torch.softmax(q @ k.transpose(-1, -2) * attn.scale, dim=-1)
+        o = (p @ v).transpose(1, 2).reshape(B, N, C)
+        ref = o @ w(attn.to_out[0]).t() + attn.to_out[0].bias.float() + h.float()
+        ad, nd, hd, ed = attn.to(DEV), norm.to(DEV), h.to(DEV), enc.to(DEV)
+        assert vpatch.fused_cross_ok(nd, ad, hd, ed, None, {})
+        y = vpatch.norm_cross_attention_residual(nd, ad, hd, ed).float().cpu()
+    assert (y - ref).abs().max() < 3e-3 * max(1.0, float(ref.abs().max()))
+
+
 def test_attention_fuzz_vs_torch_fp32(L):
     """Random (B, h, d, Mq, Mk) incl. every supported head dim, ragged lengths and Mq != Mk, against a plain PyTorch
     fp32 softmax attention of the same fp16 inputs."""

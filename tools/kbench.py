@@ -6,6 +6,7 @@
     python tools/kbench.py sort   [--n 49152]
     python tools/kbench.py sites  --shape cfg2|cfg3|cfg4|cfg5            (a hot-path pass at the other BASELINE configurations)
     python tools/kbench.py gather|unmerge|layernorm [--B 4 --n 147456 --C 320]   (HBM-bound kernels beyond the MALL)
+    python tools/kbench.py ff     [--n 131072 --C 320]                       (panel GEMMs of the feed-forward vs library GEMMs)
 """
 import argparse
 import os
@@ -137,6 +138,45 @@ def main():
             med, best = timeit(lambda: [fn() for _ in range(REP)], a.iters)
             med, best = med / REP, best / REP
             print(f"linear {name} B={B} M={M} Mq={Mq} C={C}: median {med * 1e3:.1f} us ({fl / med / 1e9:.1f} TFLOP/s), best {best * 1e3:.1f} us")
+    elif a.what == "ff":
+        # the feed-forward of one site: LayerNorm -> GEGLU projection -> gated activation -> output Linear + residual,
+        # as panel GEMMs (csrc/ff.hip) and as round 2's library GEMMs around vtm_geglu
+        import torch.nn.functional as F
+        from vidtome_amd import patch as vpatch
+        from vidtome_amd import sites
+        n, C = a.n, a.C
+        ff = sites.FeedForward(C).to(device=dev, dtype=torch.float16).eval()
+        norm = torch.nn.LayerNorm(C).to(device=dev, dtype=torch.float16)
+        h = torch.randn(n // 4096 if n >= 4096 else 1, min(n, 4096), C, generator=g, device=dev, dtype=torch.float16)
+        n = h.shape[0] * h.shape[1]
+        D = 4 * C
+        with torch.no_grad():
+            vpatch.norm_feed_forward_residual(norm, ff, h)          # packs the weights
+            proj, out = ff.net[0].proj, ff.net[2]
+            w1, b1 = proj.__dict__["_vtm_packed"]["geglu"][1]
+            w2, b2 = out.__dict__["_vtm_packed"]["rows"][1]
+            xp = _lib.layernorm_panels(h, norm.weight, norm.bias, norm.eps)
+            hp = _lib.ff_geglu(xp, n, w1, D, b1)
+            xn = _lib.layernorm(h, norm.weight, norm.bias, norm.eps)
+            p8 = proj(xn)
+            gg = _lib.geglu(p8)
+            rows = [
+                ("layernorm_panels      ", lambda: _lib.layernorm_panels(h, norm.weight, norm.bias, norm.eps), 0.0, 2.0 * n * C * 2),
+                ("ff_geglu (GEMM1+act)  ", lambda: _lib.ff_geglu(xp, n, w1, D, b1), 2.0 * n * C * 2 * D, n * (C + D) * 2.0),
+                ("linear_panels (GEMM2) ", lambda: _lib.linear_panels(hp, n, w2, C, b2, resid=h.view(n, C)), 2.0 * n * D * C, n * (D + 2 * C) * 2.0),
+                ("panels: whole ff      ", lambda: vpatch.norm_feed_forward_residual(norm, ff, h), 2.0 * n * C * 3 * D, 0.0),
+                ("blas: layernorm       ", lambda: _lib.layernorm(h, norm.weight, norm.bias, norm.eps), 0.0, 2.0 * n * C * 2),
+                ("blas: GEMM1 (C -> 8C) ", lambda: proj(xn), 2.0 * n * C * 2 * D, n * (C + 2 * D) * 2.0),
+                ("blas: vtm_geglu       ", lambda: _lib.geglu(p8), 0.0, n * 3 * D * 2.0),
+                ("blas: GEMM2 + residual", lambda: out(gg) + h, 2.0 * n * D * C, 0.0),
+                ("blas: whole ff        ", lambda: vpatch.feed_forward(ff, _lib.layernorm(h, norm.weight, norm.bias, norm.eps)) + h,
+                 2.0 * n * C * 3 * D, 0.0)]
+            for name, fn, fl, by in rows:
+                REP = 4
+                med, best = timeit(lambda: [fn() for _ in range(REP)], a.iters)
+                med, best = med / REP, best / REP
+                print(f"ff n={n} C={C} {name}: median {med * 1e3:8.1f} us  best {best * 1e3:8.1f} us"
+                      + (f"  {fl / med / 1e9:7.1f} TFLOP/s" if fl else "") + (f"  {by / med / 1e6:7.0f} GB/s" if by else ""))
     elif a.what == "sites":
         # one hot-path pass over all 16 block sites for the BASELINE.json configurations other than the bench's cfg-2
         # (steady state: anchors populated by a preceding chunk): ms per chunk-step

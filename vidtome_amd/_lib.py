@@ -58,6 +58,11 @@ _SIGNATURES = {
                                   _f32, _vp, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_compact_queries_ws_bytes": ([_i64, _i64], ctypes.c_size_t),
     "vtm_compact_queries": ([_vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp], _int),
+    "vtm_panel_rows": ([_i64], _i64),
+    "vtm_to_panels": ([_vp, _int, _i64, _i64, _vp, _vp, _i64, _vp], _int),
+    "vtm_layernorm_panels": ([_vp, _vp, _vp, _int, _i64, _i64, _f32, _vp, _i64, _vp], _int),
+    "vtm_ff_geglu": ([_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _int, _vp, _vp], _int),
+    "vtm_linear_panels": ([_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _i64, _vp], _int),
     "vtm_cfg_ddim": ([_vp, _vp, _vp, _int, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp], _int),
     "vtm_layernorm": ([_vp, _vp, _vp, _int, _i64, _i64, _f32, _vp, _vp], _int),
     "vtm_geglu": ([_vp, _int, _i64, _i64, _vp, _vp], _int),
@@ -466,4 +471,61 @@ def linear_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], rows: Optional[tor
                                  0 if rows is None else rows.shape[1], _ptr(rows2), n, _ptr(weight),
                                  _ptr(bias.contiguous() if bias is not None else None), N, out.data_ptr(), out.stride(1),
                                  out.stride(0), int(transposed), _stream()), "vtm_linear_rows")
+    return out
+
+
+# ---- panel GEMMs (csrc/ff.hip): the feed-forward and the cross-attention query projection of the patched block ----
+def panel_rows(n: int) -> int:
+    return (n + ROW_PAD - 1) // ROW_PAD * ROW_PAD
+
+
+@_on_device
+def to_panels(x: torch.Tensor, order: Optional[torch.Tensor] = None, rows: Optional[int] = None) -> torch.Tensor:
+    """(rows, C) row-major -> k-panels (C / 8, rows_pad, 8); ``order`` (n,) int32: output row r = x[order[r]] (-1 = zeros)."""
+    _req(x, "x")
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    n = x2.shape[0] if order is None else order.numel()
+    n = n if rows is None else rows
+    out = torch.empty((C // 8, panel_rows(n), 8), dtype=x.dtype, device=x.device)
+    _check(lib().vtm_to_panels(_ptr(x2), dtype_code(x2), n, C, _ptr(order), _ptr(out), out.shape[1], _stream()),
+           "vtm_to_panels")
+    return out
+
+
+@_on_device
+def layernorm_panels(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float) -> torch.Tensor:
+    """torch.nn.LayerNorm over the last axis, result as k-panels (C / 8, rows_pad, 8) (rows = all leading axes flattened)."""
+    _req(x, "x")
+    C = x.shape[-1]
+    xc = x.contiguous()
+    rows = xc.numel() // C
+    out = torch.empty((C // 8, panel_rows(rows), 8), dtype=x.dtype, device=x.device)
+    _check(lib().vtm_layernorm_panels(_ptr(xc), _ptr(weight), _ptr(bias), dtype_code(xc), rows, C, float(eps), _ptr(out),
+                                      out.shape[1], _stream()), "vtm_layernorm_panels")
+    return out
+
+
+@_on_device
+def ff_geglu(x_panels: torch.Tensor, n: int, w1_panels: torch.Tensor, D: int, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """value * gelu(gate) of the GEGLU projection, panels in, panels (D / 8, n_pad, 8) out; see include/vidtome_hip.h."""
+    K = x_panels.shape[0] * 8
+    out = torch.empty((D // 8, x_panels.shape[1], 8), dtype=x_panels.dtype, device=x_panels.device)
+    _check(lib().vtm_ff_geglu(_ptr(x_panels), n, x_panels.shape[1], _ptr(w1_panels), D, w1_panels.shape[1], K, _ptr(bias),
+                              dtype_code(x_panels), _ptr(out), _stream()), "vtm_ff_geglu")
+    return out
+
+
+@_on_device
+def linear_panels(x_panels: torch.Tensor, n: int, w_panels: torch.Tensor, N: int, bias: Optional[torch.Tensor],
+                  resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(n, N) token rows = x W^T (+ bias) (+ resid), panels in; see include/vidtome_hip.h."""
+    K = x_panels.shape[0] * 8
+    out = torch.empty((n, N), dtype=x_panels.dtype, device=x_panels.device)
+    if resid is not None:
+        _req(resid, "resid")
+        if resid.numel() != out.numel() or resid.dtype != out.dtype:
+            raise RuntimeError("linear_panels: residual shape / dtype mismatch")
+    _check(lib().vtm_linear_panels(_ptr(x_panels), n, x_panels.shape[1], _ptr(w_panels), N, w_panels.shape[1], K, _ptr(bias),
+                                   _ptr(resid), dtype_code(x_panels), _ptr(out), N, _stream()), "vtm_linear_panels")
     return out

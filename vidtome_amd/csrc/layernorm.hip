@@ -60,7 +60,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <typename T, int NCH, int R>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_kernel(const T *__restrict__ x, const T *__restrict__ gamma,
                                                                          const T *__restrict__ beta, int64_t rows, int C,
-                                                                         float eps, T *__restrict__ out) {
+                                                                         float eps, T *__restrict__ out, int64_t panel_rows) {
     const int lane = threadIdx.x & 63;
     const int64_t row0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
@@ -122,7 +122,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_kernel(const T
                         const float n = (v[r][i][j] - mean[r]) * rstd[r];
                         y[j] = gamma ? (beta ? __builtin_fmaf(n, g[j], b[j]) : n * g[j]) : (beta ? n + b[j] : n);
                     }
-                    store8(out + (row0 + r) * C + c * 8, y);
+                    // panel_rows > 0: the k-panel layout [C / 8][panel_rows][8] of the panel GEMMs (ff.hip)
+                    store8(panel_rows ? out + ((int64_t)c * panel_rows + (row0 + r)) * 8 : out + (row0 + r) * C + c * 8, y);
                 }
             }
         }
@@ -147,7 +148,7 @@ __device__ __forceinline__ float group_sum(float v) {
 template <typename T, int LPR, int R>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_rows_kernel(const T *__restrict__ x, const T *__restrict__ gamma,
                                                                               const T *__restrict__ beta, int64_t rows, float eps,
-                                                                              T *__restrict__ out) {
+                                                                              T *__restrict__ out, int64_t panel_rows) {
     constexpr int NCH = 5, C = 8 * NCH * LPR, RPW = 64 / LPR;   // pieces per lane, channels, rows per wave and round
     const int lane = threadIdx.x & 63, g = lane % LPR, sub = lane / LPR;
     const int64_t row0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * (RPW * R) + sub;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_rows_kernel(co
                     const float n = (v[r][i][j] - mean[r]) * rstd[r];
                     y[j] = gamma ? (beta ? __builtin_fmaf(n, gm[j], bt[j]) : n * gm[j]) : (beta ? n + bt[j] : n);
                 }
-                store8(out + row * C + c * 8, y);
+                store8(panel_rows ? out + ((int64_t)c * panel_rows + row) * 8 : out + row * C + c * 8, y);
             }
         }
     }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_rows_kernel(co
 
 template <typename T>
 void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_t rows, int64_t C, float eps, void *out,
-                      hipStream_t s) {
+                      int64_t panel_rows, hipStream_t s) {
 #ifndef VTM_OLD_LN   // (A/B build switch)
     // measured (profiles/r02_sweeps.txt): +24 % HBM rate at C = 320 beyond the Infinity Cache; no gain at 640 / 1280, where a
     // wave per row already uses all its lanes -- those keep the kernel above
@@ -216,7 +217,7 @@ void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_
         const dim3 g((unsigned)vtm::cdiv(rows, (int64_t)WAVES_PER_BLOCK * (64 / lpr) * R)), b(WAVES_PER_BLOCK * 64);
 #define VTM_LNR(LPR)                                                                                                   \
     hipLaunchKernelGGL((layernorm_rows_kernel<T, LPR, R>), g, b, 0, s, (const T *)x, (const T *)gamma, (const T *)beta, rows, \
-                       eps, (T *)out)
+                       eps, (T *)out, panel_rows)
         if (lpr == 8) VTM_LNR(8); else if (lpr == 16) VTM_LNR(16); else VTM_LNR(32);
 #undef VTM_LNR
         return;
@@ -227,7 +228,7 @@ void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_
     const dim3 grid((unsigned)vtm::cdiv(rows, (int64_t)WAVES_PER_BLOCK * R)), block(WAVES_PER_BLOCK * 64);
 #define VTM_LN(NCH, RR)                                                                                               \
     hipLaunchKernelGGL((layernorm_kernel<T, NCH, RR>), grid, block, 0, s, (const T *)x, (const T *)gamma, (const T *)beta, \
-                       rows, (int)C, eps, (T *)out)
+                       rows, (int)C, eps, (T *)out, panel_rows)
     switch (nch) {
         case 1: VTM_LN(1, 4); break;
         case 2: VTM_LN(2, 2); break;
@@ -247,10 +248,28 @@ VTM_EXPORT int vtm_layernorm(const void *x, const void *gamma, const void *beta,
     if (rows == 0) return VTM_OK;
     hipStream_t s = vtm::as_stream(stream);
     switch (dtype) {
-        case VTM_F32: launch_layernorm<float>(x, gamma, beta, rows, C, eps, out, s); break;
-        case VTM_F16: launch_layernorm<__half>(x, gamma, beta, rows, C, eps, out, s); break;
-        case VTM_BF16: launch_layernorm<vtm_bf16>(x, gamma, beta, rows, C, eps, out, s); break;
+        case VTM_F32: launch_layernorm<float>(x, gamma, beta, rows, C, eps, out, 0, s); break;
+        case VTM_F16: launch_layernorm<__half>(x, gamma, beta, rows, C, eps, out, 0, s); break;
+        case VTM_BF16: launch_layernorm<vtm_bf16>(x, gamma, beta, rows, C, eps, out, 0, s); break;
         default: return vtm::fail(VTM_EINVAL, "vtm_layernorm: unsupported dtype %d", dtype);
     }
     return vtm::launch_status("vtm_layernorm");
+}
+
+// The same LayerNorm with its result written in the k-panel layout [C / 8][panel_rows][8] -- the token operand of the panel
+// GEMMs of ff.hip (norm3 -> GEGLU projection, norm2 -> to_q of the cross-attention: patch.py:171-199); rows >= `rows` of
+// the panels are not written.
+VTM_EXPORT int vtm_layernorm_panels(const void *x, const void *gamma, const void *beta, int dtype, int64_t rows, int64_t C,
+                                    float eps, void *out, int64_t panel_rows, vtm_stream_t stream) {
+    VTM_REQUIRE(x && out && rows > 0, "vtm_layernorm_panels: null pointer");
+    VTM_REQUIRE(C > 0 && C % 8 == 0 && C <= 64 * 8 * MAX_CHUNKS, "vtm_layernorm_panels: C must be a multiple of 8, <= %d",
+                64 * 8 * MAX_CHUNKS);
+    VTM_REQUIRE(panel_rows >= rows, "vtm_layernorm_panels: panel_rows < rows");
+    hipStream_t s = vtm::as_stream(stream);
+    switch (dtype) {
+        case VTM_F16: launch_layernorm<__half>(x, gamma, beta, rows, C, eps, out, panel_rows, s); break;
+        case VTM_BF16: launch_layernorm<vtm_bf16>(x, gamma, beta, rows, C, eps, out, panel_rows, s); break;
+        default: return vtm::fail(VTM_EINVAL, "vtm_layernorm_panels: dtype must be VTM_F16 or VTM_BF16");
+    }
+    return vtm::launch_status("vtm_layernorm_panels");
 }

@@ -432,6 +432,51 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
     return F.linear(o, to_out.weight.to(o.dtype), None if to_out.bias is None else to_out.bias.to(o.dtype))
 
 
+def norm_cross_attention_residual(norm: torch.nn.Module, attn: torch.nn.Module, hidden_states: torch.Tensor,
+                                  encoder_hidden_states: torch.Tensor) -> torch.Tensor:
+    """patch.py:171-185 for the plain case: ``attn2(norm2(hidden_states), encoder_hidden_states) + hidden_states`` with the
+    query projection as a panel GEMM fed by the LayerNorm (vtm_layernorm_panels -> vtm_linear_panels: the normalised
+    tokens are only ever read by to_q, so they are written once, as panels), k / v^T of the (few) conditioning tokens by the
+    library, the attention core on vtm_attention_kv and the output projection + bias + residual as a panel GEMM too.
+    The caller has checked ``fused_cross_ok``."""
+    B, N, C = hidden_states.shape
+    heads = attn.heads
+    scale = getattr(attn, "scale", None) or (C // heads) ** -0.5
+    dt = hidden_states.dtype
+    enc = encoder_hidden_states.to(dt)
+    Mk = enc.shape[1]
+    Mkp = (Mk + 7) // 8 * 8
+    if Mkp != Mk:
+        enc = F.pad(enc, (0, 0, 0, Mkp - Mk))
+    hs = hidden_states.contiguous()
+    n = B * N
+    wq, bq = _packed(attn.to_q, "rows", lambda: (_lib.to_panels(attn.to_q.weight.detach().contiguous()),
+                                                None if attn.to_q.bias is None else attn.to_q.bias.detach().float().contiguous()))
+    to_out = _out_linear(attn)
+    wo, bo = _packed(to_out, "rows", lambda: (_lib.to_panels(to_out.weight.detach().contiguous()),
+                                              None if to_out.bias is None else to_out.bias.detach().float().contiguous()))
+    xp = _lib.layernorm_panels(hs, norm.weight, norm.bias, norm.eps)
+    q = _lib.linear_panels(xp, n, wq, C, bq).view(B, N, C)
+    lin = lambda m, t: F.linear(t, m.weight.to(t.dtype), None if m.bias is None else m.bias.to(t.dtype))
+    k = lin(attn.to_k, enc)
+    vt = lin(attn.to_v, enc).transpose(1, 2).contiguous()               # (B, C, Mkp): 77 keys, negligible
+    if N % 8:
+        raise RuntimeError("norm_cross_attention_residual: token count must be a multiple of 8")
+    o = _lib.attention_kv(q, k, vt, heads, N, Mk, scale)
+    op = _lib.to_panels(o.view(n, C))
+    return _lib.linear_panels(op, n, wo, C, bo, resid=hs.view(n, C)).view(B, N, C)
+
+
+def fused_cross_ok(norm: torch.nn.Module, attn: torch.nn.Module, x: torch.Tensor, encoder_hidden_states,
+                   attention_mask, kwargs) -> bool:
+    return (FF_MODE == "panels" and encoder_hidden_states is not None and attention_mask is None and not kwargs
+            and encoder_hidden_states.dim() == 3 and x.dim() == 3 and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)
+            and type(norm) is torch.nn.LayerNorm and len(norm.normalized_shape) == 1
+            and norm.normalized_shape[0] == x.shape[-1] and x.shape[-1] % 64 == 0 and x.shape[1] % 8 == 0
+            and (norm.weight is None or norm.weight.dtype == x.dtype) and (norm.bias is None or norm.bias.dtype == x.dtype)
+            and attn.to_q.weight.dtype == x.dtype and fused_attention_ok(attn, x, self_attn=False))
+
+
 def cross_attention(attn: torch.nn.Module, x: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor],
                     attention_mask=None, **kwargs) -> torch.Tensor:
     """`self.attn2(norm_hidden_states, encoder_hidden_states=..., attention_mask=...)` (patch.py:178-183) -- the
@@ -458,6 +503,79 @@ def cross_attention(attn: torch.nn.Module, x: torch.Tensor, encoder_hidden_state
     vt = lin(attn.to_v, enc).transpose(1, 2).contiguous()               # (B, C, Mkp): 77 keys, negligible
     o = _lib.attention_kv(q, k, vt, heads, N, Mk, scale)
     return lin(_out_linear(attn), o)[:, :N]
+
+
+# ----------------------------------------------------------------------------------------------------
+# the rest of the block as panel GEMMs (csrc/ff.hip)
+# ----------------------------------------------------------------------------------------------------
+# VIDTOME_FF: "panels" (default) = norm3 -> GEGLU projection with the gated activation in the GEMM's epilogue -> output
+# Linear with bias and residual, all hand-written (vtm_layernorm_panels, vtm_ff_geglu, vtm_linear_panels: the 8C-wide
+# projection is never written); "blas" = library GEMMs around vtm_geglu (rounds 1-2).  The same switch covers the
+# cross-attention's query projection (norm2 -> panels -> vtm_linear_panels).
+FF_MODE = os.environ.get("VIDTOME_FF", "panels")
+
+
+def _packed(module: torch.nn.Module, key: str, build):
+    """Weights repacked for the panel GEMMs, cached on the module and rebuilt when the parameter changes."""
+    cache = module.__dict__.setdefault("_vtm_packed", {})
+    params = [p for p in module.parameters()]
+    tag = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+    hit = cache.get(key)
+    if hit is None or hit[0] != tag:
+        hit = cache[key] = (tag, build())
+    return hit[1]
+
+
+def _geglu_ff(ff: torch.nn.Module):
+    """(GEGLU projection Linear, output Linear) of a Diffusers FeedForward [GEGLU, Dropout, Linear], else None."""
+    net = getattr(ff, "net", None)
+    if (net is not None and len(net) == 3 and net[0].__class__.__name__ == "GEGLU" and hasattr(net[0], "proj")
+            and _plain_linear(net[0].proj) and _plain_linear(net[2])
+            and (not ff.training or getattr(net[1], "p", 0.0) == 0.0)):      # Dropout(0.0) is the identity in any mode
+        return net[0].proj, net[2]
+    return None
+
+
+def fused_ff_ok(norm: torch.nn.Module, ff: torch.nn.Module, x: torch.Tensor) -> bool:
+    if FF_MODE != "panels" or not x.is_cuda or x.dtype not in (torch.float16, torch.bfloat16):
+        return False
+    lin = _geglu_ff(ff)
+    if lin is None or type(norm) is not torch.nn.LayerNorm or len(norm.normalized_shape) != 1:
+        return False
+    proj, out = lin
+    C = x.shape[-1]
+    D = proj.out_features // 2
+    return (norm.normalized_shape[0] == C and C % 64 == 0 and C <= 2048 and proj.in_features == C and D % 64 == 0
+            and out.in_features == D and out.out_features == C and proj.weight.dtype == x.dtype
+            and out.weight.dtype == x.dtype and (norm.weight is None or norm.weight.dtype == x.dtype)
+            and (norm.bias is None or norm.bias.dtype == x.dtype))
+
+
+def norm_feed_forward_residual(norm: torch.nn.Module, ff: torch.nn.Module, hidden_states: torch.Tensor) -> torch.Tensor:
+    """patch.py:187-199 for the plain-LayerNorm block: ``ff(norm3(hidden_states)) + hidden_states`` as three launches:
+    LayerNorm -> k-panels, GEGLU projection with the gated activation in its epilogue -> k-panels, output Linear + bias +
+    residual -> token rows.  The caller has checked ``fused_ff_ok``."""
+    proj, out = _geglu_ff(ff)
+    C = hidden_states.shape[-1]
+    D = proj.out_features // 2
+
+    def pack_w1():
+        t = torch.arange(D // 64, device=proj.weight.device)[:, None] * 64 + torch.arange(64, device=proj.weight.device)[None, :]
+        order = torch.cat([t, t + D], dim=1).reshape(-1).to(torch.int32)       # tile t: 64 value rows, then their gate rows
+        b = None if proj.bias is None else proj.bias.detach().float()[order.long()].contiguous()
+        return _lib.to_panels(proj.weight.detach().contiguous(), order), b
+
+    def pack_w2():
+        b = None if out.bias is None else out.bias.detach().float().contiguous()
+        return _lib.to_panels(out.weight.detach().contiguous()), b
+
+    w1, b1 = _packed(proj, "geglu", pack_w1)
+    w2, b2 = _packed(out, "rows", pack_w2)
+    hs = hidden_states.contiguous()
+    n = hs.numel() // C
+    xp = _lib.layernorm_panels(hs, norm.weight, norm.bias, norm.eps)
+    hp = _lib.ff_geglu(xp, n, w1, D, b1)
+    return _lib.linear_panels(hp, n, w2, C, b2, resid=hs.view(n, C)).view(hidden_states.shape)
 
 
 def feed_forward(ff: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
@@ -562,13 +680,21 @@ def make_diffusers_tome_block(block_class: Type[torch.nn.Module]) -> Type[torch.
 
             cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
             if self.attn2 is not None:                                             # patch.py:171-185
-                norm_hidden_states = (self.norm2(hidden_states, timestep) if self.use_ada_layer_norm
-                                      else layer_norm(self.norm2, hidden_states))
-                attn_output = cross_attention(self.attn2, norm_hidden_states, encoder_hidden_states,
-                                              encoder_attention_mask, **cross_attention_kwargs)
-                hidden_states = attn_output + hidden_states
+                if not self.use_ada_layer_norm and fused_cross_ok(self.norm2, self.attn2, hidden_states,
+                                                                  encoder_hidden_states, encoder_attention_mask,
+                                                                  cross_attention_kwargs):
+                    hidden_states = norm_cross_attention_residual(self.norm2, self.attn2, hidden_states,
+                                                                  encoder_hidden_states)
+                else:
+                    norm_hidden_states = (self.norm2(hidden_states, timestep) if self.use_ada_layer_norm
+                                          else layer_norm(self.norm2, hidden_states))
+                    attn_output = cross_attention(self.attn2, norm_hidden_states, encoder_hidden_states,
+                                                  encoder_attention_mask, **cross_attention_kwargs)
+                    hidden_states = attn_output + hidden_states
 
-            norm_hidden_states = layer_norm(self.norm3, hidden_states)             # patch.py:187-199
+            if not self.use_ada_layer_norm_zero and fused_ff_ok(self.norm3, self.ff, hidden_states):   # patch.py:187-199
+                return norm_feed_forward_residual(self.norm3, self.ff, hidden_states)
+            norm_hidden_states = layer_norm(self.norm3, hidden_states)
             if self.use_ada_layer_norm_zero:
                 norm_hidden_states = norm_hidden_states * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
             ff_output = feed_forward(self.ff, norm_hidden_states)

@@ -61,16 +61,54 @@ class Attention(torch.nn.Module):
         self.to_out = torch.nn.ModuleList([torch.nn.Linear(C, C), torch.nn.Dropout(0.0)])
 
 
-class BasicTransformerBlock(torch.nn.Module):
-    """Only the self-attention segment's members; the rest of a real block is outside the hot path."""
+class CrossAttention(Attention):
+    """attn2 of an SD block: queries from the tokens, keys / values from the text conditioning (77 x 768 in SD-1.5)."""
 
-    def __init__(self, site: Site):
+    def __init__(self, C: int, heads: int, cond_dim: int):
+        super().__init__(C, heads)
+        self.to_k = torch.nn.Linear(cond_dim, C, bias=False)
+        self.to_v = torch.nn.Linear(cond_dim, C, bias=False)
+
+
+class GEGLU(torch.nn.Module):
+    def __init__(self, C: int, D: int):
+        super().__init__()
+        self.proj = torch.nn.Linear(C, 2 * D)
+
+    def forward(self, x):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * torch.nn.functional.gelu(gate)
+
+
+class FeedForward(torch.nn.Module):
+    """Diffusers' FeedForward of SD blocks: [GEGLU(C -> 4C, from a C -> 8C projection), Dropout, Linear 4C -> C]."""
+
+    def __init__(self, C: int):
+        super().__init__()
+        self.net = torch.nn.ModuleList([GEGLU(C, 4 * C), torch.nn.Dropout(0.0), torch.nn.Linear(4 * C, C)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+class BasicTransformerBlock(torch.nn.Module):
+    """The self-attention segment's members; with ``full`` also the rest of an SD block (norm2 / attn2 over the text
+    conditioning, norm3 / GEGLU feed-forward: vidtome/patch.py:171-199) for the secondary full-block measurement."""
+
+    def __init__(self, site: Site, full: bool = False, cond_dim: int = 768):
         super().__init__()
         self.site = site
         self.norm1 = torch.nn.LayerNorm(site.channels)
         self.attn1 = Attention(site.channels, site.heads)
         self.attn2 = None
         self.only_cross_attention = False
+        if full:
+            self.norm2 = torch.nn.LayerNorm(site.channels)
+            self.attn2 = CrossAttention(site.channels, site.heads, cond_dim)
+            self.norm3 = torch.nn.LayerNorm(site.channels)
+            self.ff = FeedForward(site.channels)
 
 
 class ModelMixin(torch.nn.Module):
@@ -78,9 +116,9 @@ class ModelMixin(torch.nn.Module):
 
 
 class SiteUNet(ModelMixin):
-    def __init__(self, sites: List[Site], seed: int = 0):
+    def __init__(self, sites: List[Site], seed: int = 0, full: bool = False):
         super().__init__()
-        self.blocks = torch.nn.ModuleList([BasicTransformerBlock(s) for s in sites])
+        self.blocks = torch.nn.ModuleList([BasicTransformerBlock(s, full) for s in sites])
         g = torch.Generator().manual_seed(seed)
         with torch.no_grad():
             for p in self.parameters():
@@ -90,6 +128,13 @@ class SiteUNet(ModelMixin):
                 b.norm1.weight.fill_(1.0)
                 b.norm1.bias.zero_()
                 b.attn1.to_out[0].bias.zero_()
+                if full:
+                    for n in (b.norm2, b.norm3):
+                        n.weight.fill_(1.0)
+                        n.bias.zero_()
+                    b.attn2.to_out[0].bias.zero_()
+                    b.ff.net[0].proj.bias.zero_()
+                    b.ff.net[2].bias.zero_()
 
     def set_size(self, latent_hw: Tuple[int, int]) -> None:
         """What hook_tome_model records from the latent (patch.py:208-210)."""
@@ -122,6 +167,12 @@ def run_segment_pass(unet: SiteUNet, hiddens: List[torch.Tensor]) -> List[torch.
     return outs
 
 
+def run_block_pass(unet: SiteUNet, hiddens: List[torch.Tensor], cond: torch.Tensor) -> List[torch.Tensor]:
+    """One FULL-block pass (secondary measurement): the patched block's whole forward (patch.py:128-201) at every site --
+    the hot-path segment, then the cross-attention over ``cond`` (B*F, 77, 768) and the GEGLU feed-forward."""
+    return [blk(h, encoder_hidden_states=cond) for blk, h in zip(unet.blocks, hiddens)]
+
+
 class ClipStream:
     """The chunk stream bench.py (and tools / tests) feed the patched sites with: chunk c of the run holds frame set
     c % n_sets of ONE synthetic clip (per-sample base shared by all sets, independent frame noise), so the anchor tokens a
@@ -138,8 +189,9 @@ class ClipStream:
 
     def __init__(self, unet: "SiteUNet", site_list: List[Site], batch: int, frames: int, latent_hw: Tuple[int, int], dtype,
                  device, n_sets: int = 3, chunks_per_step: int = 8, same_chunk: bool = False, rank: int = 0,
-                 reseed: bool = True, sets=None):
+                 reseed: bool = True, sets=None, cond: torch.Tensor = None):
         self.unet, self.site_list = unet, site_list
+        self.cond = cond                      # not None: full-block passes (run_block_pass)
         self.K = 1 if same_chunk else max(2, n_sets)
         self.same_chunk = same_chunk
         self.reseed_every = 0 if (same_chunk or not reseed) else max(1, chunks_per_step - 1)
@@ -160,7 +212,7 @@ class ClipStream:
         for b in self.unet.blocks:
             b.global_tokens = None
         with torch.no_grad():
-            run_segment_pass(self.unet, self.sets[j])
+            self._run(self.sets[j])
         self.seeds[j] = [getattr(b, "global_tokens", None) for b in self.unet.blocks]
 
     def populate(self) -> None:
@@ -182,4 +234,7 @@ class ClipStream:
                 b.global_tokens = a
         self.steady += 1
         with torch.no_grad():
-            return run_segment_pass(self.unet, self.sets[j])
+            return self._run(self.sets[j])
+
+    def _run(self, hiddens):
+        return run_segment_pass(self.unet, hiddens) if self.cond is None else run_block_pass(self.unet, hiddens, self.cond)
