@@ -247,19 +247,27 @@ int vtm_compact_queries(const int32_t *loc, int64_t B, int64_t Ml, int64_t U, in
  * Operands are k-panels: [K / 8][rows_pad][8 elements], rows_pad = vtm_panel_rows(rows) (a multiple of 256); padding
  * rows may hold anything.  Token operands come from vtm_layernorm_panels (or vtm_to_panels), weights are packed once
  * with vtm_to_panels (`order` = the row permutation below, or NULL).
- *   vtm_layernorm_panels  torch.nn.LayerNorm with its result written as panels (norm3 / norm2).
+ *   vtm_layernorm_panels  torch.nn.LayerNorm with its result written as panels (norm3 / norm2; norm1 of the un-merged sites).
+ *   vtm_gather_panels     the composed merge closure (merge.py:119-133 / 423-437) writing panels: row b * rows_per_sample + i
+ *                         = pool[b, map[b, map2[b, i]]] (either map may be NULL), padding rows zero -- the token operand of
+ *                         attn1's projections (patch.py:157-162) at the sites where the panel GEMM is used.
  *   vtm_ff_geglu          out = value * gelu(gate) of  x W1^T + b1  (erf gelu), written as panels [D / 8][n_pad][8] -- the
  *                         2D-wide projection is never written.  W1 is packed in TILE order: 128-row tile t = the value rows of
  *                         output channels 64 t .. 64 t + 63 followed by their gate rows (rows D + 64 t ..); bias (2 D fp32) in
  *                         the same order.  D % 64 == 0, K % 64 == 0.
  *   vtm_linear_panels     out (n, ldo) token rows = x W^T (+ bias fp32 (N)) (+ resid (n, ldo)), rounded like torch's Linear
- *                         followed by the residual add.  N % 8 == 0, K % 64 == 0.
+ *                         followed by the residual add.  N % 8 == 0, K % 64 == 0.  n_pad / w_rows_pad are the ROW STRIDES of the
+ *                         two panel operands (either may be a row range of a larger panel tensor, e.g. one sample's rows:
+ *                         V^T = W_v X^T is this call with the weight as "token" operand and the sample's tokens as "weight").
  * ---------------------------------------------------------------------------------------------- */
 int64_t vtm_panel_rows(int64_t n);
 int vtm_to_panels(const void *x, int dtype, int64_t rows, int64_t C, const int32_t *order, void *out, int64_t rows_pad,
                   vtm_stream_t stream);
 int vtm_layernorm_panels(const void *x, const void *gamma, const void *beta, int dtype, int64_t rows, int64_t C, float eps,
                          void *out, int64_t panel_rows, vtm_stream_t stream);
+int vtm_gather_panels(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B, int64_t C,
+                      const int32_t *map, int64_t map_ld, const int32_t *map2, int64_t n, void *out, int64_t rows_per_sample,
+                      vtm_stream_t stream);
 int vtm_ff_geglu(const void *x_panels, int64_t n, int64_t n_pad, const void *w1_panels, int64_t D, int64_t w_rows_pad,
                  int64_t K, const float *bias, int dtype, void *out_panels, vtm_stream_t stream);
 int vtm_linear_panels(const void *x_panels, int64_t n, int64_t n_pad, const void *w_panels, int64_t N, int64_t w_rows_pad,

@@ -629,11 +629,13 @@ def test_attention_golden_gpu_gather_fed_path(L):
             assert np.abs(yq - y[:, c["rows"], :]).max() < 2e-3 * scale     # same operands, another query tiling
 
 
-@pytest.mark.parametrize("F,N_side,C,heads,coins", [(8, 16, 320, 8, (0.0, 1.0)), (16, 32, 320, 8, (1.0, 0.0)),
-                                                   (8, 16, 640, 8, (0.0, 1.0))])
-def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, F, N_side, C, heads, coins, monkeypatch):
+@pytest.mark.parametrize("F,N_side,C,heads,coins,proj", [(8, 16, 320, 8, (0.0, 1.0), "auto"), (16, 32, 320, 8, (1.0, 0.0), "auto"),
+                                                        (8, 16, 640, 8, (0.0, 1.0), "auto"), (8, 16, 640, 8, (1.0, 0.0), "rows"),
+                                                        (8, 16, 320, 8, (0.0, 1.0), "panels")])
+def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, F, N_side, C, heads, coins, proj, monkeypatch):
     """What bench.py times, end to end, against the pinned oracle: an fp16 site with the bench's channel counts and head
-    dims (C = 320 / d = 40: gather-fed projections + live queries; C = 640 / d = 80 forced onto the same path), three
+    dims (C = 320 / d = 40: gather-fed projections + live / compacted queries; C = 640 / d = 80: panel-GEMM projections; and
+    each of them forced onto the other path), three
     chunks of one clip (first chunk stores its tokens; then one chunk with the local chunk as src, one as dst -- the
     coin thresholds are switched between chunks).  The oracle starts from OUR norm1 output (vtm_layernorm has its own
     test against fp32 PyTorch; the matcher works on the fp16-rounded norm output, which is what the fp16 reference
@@ -642,7 +644,7 @@ def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, F, N_side, C, heads,
     import vidtome_amd
     from vidtome_amd import patch as vpatch
     from vidtome_amd import sites
-    monkeypatch.setattr(vpatch, "PROJ_MODE", "rows")          # the C = 640 case too
+    monkeypatch.setattr(vpatch, "PROJ_MODE", proj)            # auto: gather-fed GEMMs at C = 320, panel GEMMs at C = 640
     B, latent = 2, (N_side, N_side)
     site = sites.Site("s", 1, C, heads)
     unet = sites.SiteUNet([site], seed=3).to(device=DEV, dtype=torch.float16)
@@ -1212,9 +1214,11 @@ def test_live_queries_equal_full_attention(L, F, global_rand):
 
 
 def test_projection_paths_agree(L):
-    """The patched segment with its projections fed through the composed merge map (vtm_linear_rows, the default) equals
-    the same segment over materialised merged tokens with library GEMMs (VIDTOME_PROJ=blas) -- two chunks, local + global
-    levels, live queries, merged and un-merged sites."""
+    """The patched segment with its projections fed through the composed merge map (vtm_linear_rows), as panel GEMMs
+    (vtm_gather_panels / vtm_layernorm_panels + vtm_linear_panels) and in the default mix of the two ("auto": rows at
+    C <= 320, panels above -- no library GEMM anywhere) equals the same segment over materialised merged tokens with library
+    GEMMs (VIDTOME_PROJ=blas) -- three chunks, local + global levels, both coin outcomes with live / compacted queries,
+    merged and un-merged sites."""
     import vidtome_amd
     from vidtome_amd import patch as vpatch
     from vidtome_amd import sites
@@ -1222,8 +1226,8 @@ def test_projection_paths_agree(L):
     B, F, latent = 2, 4, (16, 16)
     outs = {}
     saved = vpatch.PROJ_MODE
-    for mode in (True, False):
-        vpatch.FUSED_PROJ, vpatch.PROJ_MODE = mode, "rows"       # "rows": every site through vtm_linear_rows
+    for mode in ("blas", "rows", "panels", "auto"):
+        vpatch.FUSED_PROJ, vpatch.PROJ_MODE = mode != "blas", mode
         try:
             unet = sites.SiteUNet(sl, seed=0).to(device=DEV, dtype=torch.float16)
             vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B)
@@ -1231,17 +1235,19 @@ def test_projection_paths_agree(L):
             torch.manual_seed(123)
             res = []
             with torch.no_grad():
-                for ck in range(2):
+                for ck in range(3):
+                    unet._tome_info["args"]["global_rand"] = [0.5, 0.0, 1.0][ck]      # chunk 1: local = src, chunk 2: dst
                     hs = [sites.synthetic_hidden(s_, B, F, latent, torch.float16, DEV, seed=10 * ck + i)
                           for i, s_ in enumerate(sl)]
                     res.append([o.float() for o in sites.run_segment_pass(unet, hs)])
             outs[mode] = res
         finally:
             vpatch.FUSED_PROJ, vpatch.PROJ_MODE = True, saved
-    for a, b in zip(outs[True], outs[False]):
-        for x, y in zip(a, b):
-            assert torch.isfinite(x).all()
-            assert (x - y).abs().max().item() < 4e-3 * max(1.0, y.abs().max().item())
+    for mode in ("rows", "panels", "auto"):
+        for a, b in zip(outs[mode], outs["blas"]):
+            for x, y in zip(a, b):
+                assert torch.isfinite(x).all()
+                assert (x - y).abs().max().item() < 4e-3 * max(1.0, y.abs().max().item()), mode
 
 
 def test_cfg5_sd21_768_full_size(L):

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "vtm_panel_rows": ([_i64], _i64),
     "vtm_to_panels": ([_vp, _int, _i64, _i64, _vp, _vp, _i64, _vp], _int),
     "vtm_layernorm_panels": ([_vp, _vp, _vp, _int, _i64, _i64, _f32, _vp, _i64, _vp], _int),
+    "vtm_gather_panels": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp], _int),
     "vtm_ff_geglu": ([_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _int, _vp, _vp], _int),
     "vtm_linear_panels": ([_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _i64, _vp], _int),
     "vtm_cfg_ddim": ([_vp, _vp, _vp, _int, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp], _int),
@@ -518,14 +519,39 @@ def ff_geglu(x_panels: torch.Tensor, n: int, w1_panels: torch.Tensor, D: int, bi
 
 @_on_device
 def linear_panels(x_panels: torch.Tensor, n: int, w_panels: torch.Tensor, N: int, bias: Optional[torch.Tensor],
-                  resid: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """(n, N) token rows = x W^T (+ bias) (+ resid), panels in; see include/vidtome_hip.h."""
+                  resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(n, N) token rows = x W^T (+ bias) (+ resid), panels in; see include/vidtome_hip.h.  Either operand may be a row
+    range of a larger panel tensor (a view ``p[:, r0:r1]``: the panel stride is taken from the view); ``out`` may be a
+    preallocated (n, N) view with a row stride >= N."""
     K = x_panels.shape[0] * 8
-    out = torch.empty((n, N), dtype=x_panels.dtype, device=x_panels.device)
+    if x_panels.stride(2) != 1 or x_panels.stride(1) != 8 or w_panels.stride(2) != 1 or w_panels.stride(1) != 8 \
+            or w_panels.shape[0] * 8 != K:
+        raise RuntimeError("linear_panels: operands must be (K / 8, rows, 8) panel tensors (or row ranges of one)")
+    if out is None:
+        out = torch.empty((n, N), dtype=x_panels.dtype, device=x_panels.device)
+    if out.stride(1) != 1 or out.shape[0] < n or out.shape[1] < N:
+        raise RuntimeError("linear_panels: out must be an (n, N) view, contiguous along its rows")
     if resid is not None:
         _req(resid, "resid")
-        if resid.numel() != out.numel() or resid.dtype != out.dtype:
+        if resid.numel() != n * N or resid.dtype != out.dtype or out.stride(0) != N:
             raise RuntimeError("linear_panels: residual shape / dtype mismatch")
-    _check(lib().vtm_linear_panels(_ptr(x_panels), n, x_panels.shape[1], _ptr(w_panels), N, w_panels.shape[1], K, _ptr(bias),
-                                   _ptr(resid), dtype_code(x_panels), _ptr(out), N, _stream()), "vtm_linear_panels")
+    _check(lib().vtm_linear_panels(_ptr(x_panels), n, x_panels.stride(0) // 8, _ptr(w_panels), N, w_panels.stride(0) // 8, K,
+                                   _ptr(bias), _ptr(resid), dtype_code(x_panels), out.data_ptr(), out.stride(0), _stream()),
+           "vtm_linear_panels")
+    return out
+
+
+@_on_device
+def gather_panels(x0: torch.Tensor, x1: Optional[torch.Tensor], rows: Optional[torch.Tensor], rows2: Optional[torch.Tensor],
+                  n: int) -> torch.Tensor:
+    """Panels (C / 8, B * n_pad, 8) of pool[b, rows[b, rows2[b, i]]], i < n, sample b at rows b * n_pad (n_pad = n rounded up
+    to 256, padding rows zero); pool = x0 | x1 as for gather_rows."""
+    _req(x0, "x0")
+    B, P0, C = x0.shape
+    P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
+    n_pad = panel_rows(n)
+    out = torch.empty((C // 8, B * n_pad, 8), dtype=x0.dtype, device=x0.device)
+    _check(lib().vtm_gather_panels(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(rows),
+                                   0 if rows is None else rows.shape[1], _ptr(rows2), n, _ptr(out), n_pad, _stream()),
+           "vtm_gather_panels")
     return out

@@ -339,12 +339,37 @@ __global__ __launch_bounds__(256) void to_panels_kernel(const T *__restrict__ x,
     out[g * rows_pad + r] = v;
 }
 
+// gather -> panels: the merged tokens of a block (a row selection of the pool [x0 | x1] through the composed merge map,
+// optionally through a second map: the live-query rows) written straight in the panel layout, sample b's rows at
+// b * rows_per_sample (a multiple of 256), padding rows zero.  thread = (sample, row, panel): 16-byte reads along a token
+// row, 16-byte panel writes.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_panels_kernel(const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1,
+                                                            int64_t P1, int64_t B, int64_t C, const int32_t *__restrict__ map,
+                                                            int64_t map_ld, const int32_t *__restrict__ map2, int64_t n,
+                                                            int64_t rows_per_sample, int64_t stride, uint4 *__restrict__ out) {
+    const int64_t G = C / 8;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * rows_per_sample * G) return;
+    const int64_t g = i % G, r = (i / G) % rows_per_sample, b = i / (G * rows_per_sample);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < n) {
+        int64_t p = map2 ? map2[b * n + r] : r;
+        if (map) p = map[b * map_ld + p];
+        const T *row = p < P0 ? x0 + (b * P0 + p) * C : x1 + (b * P1 + (p - P0)) * C;
+        v = *reinterpret_cast<const uint4 *>(row + g * 8);
+    }
+    out[g * stride + b * rows_per_sample + r] = v;
+}
+
 inline int64_t pad256(int64_t n) { return vtm::cdiv(n, FBS) * FBS; }
 
 template <typename T, int EPI>
 int launch_panel_gemm(const void *tok, int64_t n, int64_t n_pad, const void *w, int64_t Nw, int64_t Nw_pad, int64_t K,
                       const Epi &E, hipStream_t s) {
-    const int ns_tiles = (int)(n_pad / FBS), nd_tiles = (int)vtm::cdiv(Nw, FBD);
+    // n_pad / Nw_pad are the ROW STRIDES of the two panel operands (an operand may be a row range of a larger panel
+    // tensor); the tiles cover the valid rows only
+    const int ns_tiles = (int)vtm::cdiv(n, FBS), nd_tiles = (int)vtm::cdiv(Nw, FBD);
     const int total_src_tiles = ns_tiles;
     const int max_patch = (int64_t)16 * FBS * K * 2 <= (3 << 20) ? 16 : 8;
     const int tiles_per_xcd = (int)vtm::cdiv(total_src_tiles, 8);
@@ -381,6 +406,22 @@ VTM_EXPORT int vtm_to_panels(const void *x, int dtype, int64_t rows, int64_t C, 
     return vtm::launch_status("vtm_to_panels");
 }
 
+VTM_EXPORT int vtm_gather_panels(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B, int64_t C,
+                                 const int32_t *map, int64_t map_ld, const int32_t *map2, int64_t n, void *out,
+                                 int64_t rows_per_sample, vtm_stream_t stream) {
+    VTM_REQUIRE(x0 && out && B > 0 && C > 0 && C % 8 == 0 && n > 0, "vtm_gather_panels: bad arguments");
+    VTM_REQUIRE(P1 == 0 || x1, "vtm_gather_panels: x1 is null but P1 > 0");
+    VTM_REQUIRE(map || map2 || n <= P0 + P1, "vtm_gather_panels: identity rows must lie inside the pool");
+    VTM_REQUIRE(!map || map_ld > 0, "vtm_gather_panels: map_ld");
+    VTM_REQUIRE(rows_per_sample >= n && rows_per_sample % FBS == 0, "vtm_gather_panels: rows_per_sample must be a multiple of 256 >= n");
+    VTM_REQUIRE(dtype == VTM_F16 || dtype == VTM_BF16, "vtm_gather_panels: dtype must be VTM_F16 or VTM_BF16");
+    const int64_t total = B * rows_per_sample * (C / 8);
+    hipLaunchKernelGGL(gather_panels_kernel<__half>, dim3((unsigned)vtm::cdiv(total, 256)), dim3(256), 0, vtm::as_stream(stream),
+                       (const __half *)x0, P0, (const __half *)x1, P1, B, C, map, map_ld, map2, n, rows_per_sample,
+                       B * rows_per_sample, (uint4 *)out);
+    return vtm::launch_status("vtm_gather_panels");
+}
+
 VTM_EXPORT int vtm_ff_geglu(const void *x_panels, int64_t n, int64_t n_pad, const void *w1_panels, int64_t D, int64_t w_rows_pad,
                             int64_t K, const float *bias, int dtype, void *out_panels, vtm_stream_t stream) {
     VTM_REQUIRE(x_panels && w1_panels && out_panels, "vtm_ff_geglu: null pointer");
@@ -398,8 +439,8 @@ VTM_EXPORT int vtm_linear_panels(const void *x_panels, int64_t n, int64_t n_pad,
                                  int64_t K, const float *bias, const void *resid, int dtype, void *out, int64_t ldo,
                                  vtm_stream_t stream) {
     VTM_REQUIRE(x_panels && w_panels && out, "vtm_linear_panels: null pointer");
-    VTM_REQUIRE(n > 0 && n_pad >= n && n_pad % FBS == 0, "vtm_linear_panels: token rows must be padded to 256");
-    VTM_REQUIRE(N > 0 && N % 8 == 0 && w_rows_pad >= N && w_rows_pad % FBS == 0, "vtm_linear_panels: N %% 8, weight rows padded to 256");
+    VTM_REQUIRE(n > 0 && n_pad >= vtm::cdiv(n, FBS) * FBS, "vtm_linear_panels: token rows must be padded to 256");
+    VTM_REQUIRE(N > 0 && N % 8 == 0 && w_rows_pad >= vtm::cdiv(N, FBD) * FBD, "vtm_linear_panels: N %% 8, weight rows padded to 128");
     VTM_REQUIRE(K > 0 && K % FBK == 0, "vtm_linear_panels: K must be a multiple of 64");
     VTM_REQUIRE(ldo >= N && ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(resid) & 15) == 0, "vtm_linear_panels: output rows must be 16-byte aligned");

@@ -324,6 +324,10 @@ def fused_attention_ok(attn: torch.nn.Module, x: torch.Tensor, self_attn: bool =
 # at C >= 640, where its 256 x 256 macro-tiles move half the operand bytes of the 128 x 160 tiles of linear.hip.
 PROJ_MODE = os.environ.get("VIDTOME_PROJ", "auto")
 FUSED_PROJ = PROJ_MODE != "blas"                      # (tests toggle this to compare the two paths)
+# Round 3: at C >= 640 "auto" no longer leaves the C ABI either -- the projections are PANEL GEMMs (csrc/ff.hip: the merged
+# rows are gathered straight into the k-panel layout, vtm_gather_panels, and k / v^T / q / out are vtm_linear_panels
+# launches; the un-merged C = 1280 sites take their panels from the LayerNorm itself).  VIDTOME_PROJ=panels forces that
+# path everywhere, "blas" keeps the library GEMMs of rounds 1-2.
 
 
 def fused_projections_ok(attn: torch.nn.Module, x: torch.Tensor) -> bool:
@@ -331,7 +335,116 @@ def fused_projections_ok(attn: torch.nn.Module, x: torch.Tensor) -> bool:
     if not FUSED_PROJ or x.dtype not in (torch.float16, torch.bfloat16) or x.shape[-1] % 32 \
             or attn.to_q.weight.dtype != x.dtype:
         return False
-    return PROJ_MODE == "rows" or x.shape[-1] <= 320
+    return PROJ_MODE == "rows" or (PROJ_MODE == "auto" and x.shape[-1] <= 320)
+
+
+def panel_projections_ok(attn: torch.nn.Module, x: torch.Tensor) -> bool:
+    """The panel-GEMM projections (vtm_gather_panels / vtm_layernorm_panels + vtm_linear_panels): fp16 / bf16 tokens,
+    C % 64 == 0, no bias on to_v (V^T = W_v X^T is computed with the roles of the operands swapped)."""
+    return (PROJ_MODE in ("auto", "panels") and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 64 == 0
+            and attn.to_q.weight.dtype == x.dtype and getattr(attn.to_v, "bias", None) is None)
+
+
+def _panel_weight(lin: torch.nn.Module):
+    """(weight as k-panels, fp32 bias or None) of a Linear, cached on the module."""
+    return _packed(lin, "rows", lambda: (_lib.to_panels(lin.weight.detach().contiguous()),
+                                        None if lin.bias is None else lin.bias.detach().float().contiguous()))
+
+
+def self_attention_panels(attn: torch.nn.Module, x0: torch.Tensor, x1: Optional[torch.Tensor], rows: Optional[torch.Tensor],
+                          q_rows: Optional[torch.Tensor] = None, q_count: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``attn1(merged)`` like self_attention_rows, with the projections as panel GEMMs: the merged rows (and the live-query
+    rows) are gathered ONCE into the k-panel layout, sample b at rows b * Mpad (Mpad = M rounded up to 256), and
+        k    = X W_k^T                     one launch over all samples  -> (B, Mpad, C)
+        v^T  = W_v X_b^T                   one launch per sample, the weight as "token" operand -> (B, C, Mpad): no transpose
+        q    = X_q W_q^T, out = O W_o^T + b
+    Returns (B, Mq rounded up to 256, C); rows >= Mq (or the per-sample q_count) are not meaningful."""
+    B, _, C = x0.shape
+    M = x0.shape[1] if rows is None else rows.shape[1]
+    heads = attn.heads
+    scale = getattr(attn, "scale", None) or (C // heads) ** -0.5
+    share = _pnp_share_groups(attn)
+    if q_rows is not None and share != 1:
+        raise RuntimeError("q_rows cannot be combined with the PnP shared-probability mode")
+    Mpad = _lib.panel_rows(M)
+    xp = _lib.gather_panels(x0, x1, rows, None, M)                       # (C / 8, B * Mpad, 8)
+    wq, bq = _panel_weight(attn.to_q)
+    wk, bk = _panel_weight(attn.to_k)
+    wv, _ = _panel_weight(attn.to_v)
+    k_op = _lib.linear_panels(xp, B * Mpad, wk, C, bk).view(B, Mpad, C)
+    vt = torch.empty((B, C, Mpad), dtype=x0.dtype, device=x0.device)
+    M8 = (M + 7) // 8 * 8
+    for b in range(B):
+        _lib.linear_panels(wv, C, xp[:, b * Mpad:(b + 1) * Mpad], M8, None, out=vt[b])
+    if q_rows is None:
+        q_op = _lib.linear_panels(xp, B * Mpad, wq, C, bq).view(B, Mpad, C)
+        o = _lib.attention(q_op, k_op, vt, heads, M, scale, share)
+        Mq, Mqpad = M, Mpad
+    else:
+        Mq = q_rows.shape[1]
+        Mqpad = _lib.panel_rows(Mq)
+        qp = _lib.gather_panels(x0, x1, rows, q_rows, Mq)
+        q_op = _lib.linear_panels(qp, B * Mqpad, wq, C, bq).view(B, Mqpad, C)
+        o = _lib.attention_kv(q_op, k_op, vt, heads, Mq, M, scale, q_count=q_count)
+    wo, bo = _panel_weight(_out_linear(attn))
+    op = _lib.to_panels(o.view(B * Mqpad, C))
+    return _lib.linear_panels(op, B * Mqpad, wo, C, bo).view(B, Mqpad, C)
+
+
+def unmerged_site(block: torch.nn.Module, x: torch.Tensor) -> bool:
+    """patch.py:15-17,27: the block is too deep in the UNet to merge (downsample > max_downsample)."""
+    info = block._tome_info
+    if info["size"] is None:
+        return False
+    downsample = int(math.ceil(math.sqrt((info["size"][0] * info["size"][1]) // x.shape[1])))
+    return downsample > info["args"]["max_downsample"]
+
+
+def unmerged_self_attention_ok(block: torch.nn.Module, x: torch.Tensor) -> bool:
+    norm, attn = block.norm1, block.attn1
+    return (x.is_cuda and x.dim() == 3 and x.shape[1] % 8 == 0 and type(norm) is torch.nn.LayerNorm and len(norm.normalized_shape) == 1
+            and norm.normalized_shape[0] == x.shape[-1] and (norm.weight is None or norm.weight.dtype == x.dtype)
+            and (norm.bias is None or norm.bias.dtype == x.dtype) and fused_attention_ok(attn, x)
+            and panel_projections_ok(attn, x) and not fused_projections_ok(attn, x) and _pnp_share_groups(attn) == 1
+            and unmerged_site(block, x))
+
+
+def unmerged_self_attention_residual(block: torch.nn.Module, hidden_states: torch.Tensor) -> torch.Tensor:
+    """patch.py:139-169 at a site that does not merge (per-frame attention): ``attn1(norm1(h)) + h`` with norm1 writing
+    k-panels (its output is only read by the three projections), ONE GEMM for q | k | v over all frames, the attention core
+    per frame, and the output projection with bias and residual in its epilogue.  The caller checked
+    ``unmerged_self_attention_ok``."""
+    attn, norm = block.attn1, block.norm1
+    BF, N, C = hidden_states.shape
+    heads = attn.heads
+    scale = getattr(attn, "scale", None) or (C // heads) ** -0.5
+    hs = hidden_states.contiguous()
+    n = BF * N
+
+    def pack_qkv():
+        w = torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], dim=0).detach().contiguous()
+        bs = [getattr(m, "bias", None) for m in (attn.to_q, attn.to_k, attn.to_v)]
+        b = None if all(x is None for x in bs) else torch.cat(
+            [torch.zeros(C, device=w.device) if x is None else x.detach().float() for x in bs]).contiguous()
+        return _lib.to_panels(w), b
+    wqkv, bqkv = _packed(attn, "qkv", pack_qkv)
+    xp = _lib.layernorm_panels(hs, norm.weight, norm.bias, norm.eps)
+    qkv = _lib.linear_panels(xp, n, wqkv, 3 * C, bqkv).view(BF, N, 3 * C)
+    vt = qkv[:, :, 2 * C:].transpose(1, 2).contiguous()                  # (BF, C, N): small (un-merged sites are the deep ones)
+    o = _lib.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], vt, heads, N, scale, 1)
+    wo, bo = _panel_weight(_out_linear(attn))
+    op = _lib.to_panels(o.view(n, C))
+    return _lib.linear_panels(op, n, wo, C, bo, resid=hs.view(n, C)).view(BF, N, C)
+
+
+def self_attention_segment(block: torch.nn.Module, hidden_states: torch.Tensor, encoder_hidden_states=None,
+                           attention_mask=None, cross_attention_kwargs=None) -> torch.Tensor:
+    """patch.py:146-169 for the plain-LayerNorm block: norm1 -> compute_merge -> attn1 -> unmerge -> + residual."""
+    if (encoder_hidden_states is None or not block.only_cross_attention) and attention_mask is None \
+            and not cross_attention_kwargs and unmerged_self_attention_ok(block, hidden_states):
+        return unmerged_self_attention_residual(block, hidden_states)
+    return patched_self_attention_segment(block, hidden_states, layer_norm(block.norm1, hidden_states),
+                                          encoder_hidden_states, attention_mask, cross_attention_kwargs, None)
 
 
 def _weight(m: torch.nn.Module, dtype) -> torch.Tensor:
@@ -457,11 +570,18 @@ def norm_cross_attention_residual(norm: torch.nn.Module, attn: torch.nn.Module, 
                                               None if to_out.bias is None else to_out.bias.detach().float().contiguous()))
     xp = _lib.layernorm_panels(hs, norm.weight, norm.bias, norm.eps)
     q = _lib.linear_panels(xp, n, wq, C, bq).view(B, N, C)
-    lin = lambda m, t: F.linear(t, m.weight.to(t.dtype), None if m.bias is None else m.bias.to(t.dtype))
-    k = lin(attn.to_k, enc)
-    vt = lin(attn.to_v, enc).transpose(1, 2).contiguous()               # (B, C, Mkp): 77 keys, negligible
     if N % 8:
         raise RuntimeError("norm_cross_attention_residual: token count must be a multiple of 8")
+    if enc.shape[2] % 64 == 0 and attn.to_k.weight.dtype == dt and attn.to_v.weight.dtype == dt:
+        ep = _lib.to_panels(enc.reshape(B * Mkp, enc.shape[2]))          # the (few) conditioning tokens: 77 per frame in SD
+        wk, bk = _panel_weight(attn.to_k)
+        wv, bv = _panel_weight(attn.to_v)
+        k = _lib.linear_panels(ep, B * Mkp, wk, C, bk).view(B, Mkp, C)
+        vt = _lib.linear_panels(ep, B * Mkp, wv, C, bv).view(B, Mkp, C).transpose(1, 2).contiguous()   # (B, C, Mkp)
+    else:
+        lin = lambda m, t: F.linear(t, m.weight.to(t.dtype), None if m.bias is None else m.bias.to(t.dtype))
+        k = lin(attn.to_k, enc)
+        vt = lin(attn.to_v, enc).transpose(1, 2).contiguous()
     o = _lib.attention_kv(q, k, vt, heads, N, Mk, scale)
     op = _lib.to_panels(o.view(n, C))
     return _lib.linear_panels(op, n, wo, C, bo, resid=hs.view(n, C)).view(B, N, C)
@@ -603,7 +723,8 @@ def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.
     fused = not (custom or attention_mask is not None or cross_attention_kwargs) \
         and fused_attention_ok(block.attn1, norm_hidden_states)
     by_rows = fused and fused_projections_ok(block.attn1, norm_hidden_states)
-    m_a, u_a, merged = compute_merge(block, norm_hidden_states, block._tome_info, materialize=not by_rows)
+    by_panels = fused and not by_rows and panel_projections_ok(block.attn1, norm_hidden_states)
+    m_a, u_a, merged = compute_merge(block, norm_hidden_states, block._tome_info, materialize=not (by_rows or by_panels))
     plan = getattr(m_a, "plan", None)
     if not fused:
         # not the hot path (SD never masks self-attention nor makes attn1 a cross-attention; LoRA'd / custom
@@ -619,12 +740,12 @@ def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.
                 and _pnp_share_groups(block.attn1) == 1)
         q_rows = plan.q_rows if live else None
         q_count = plan.q_count if live else None
-        if by_rows:
+        if by_rows or by_panels:
+            sa = self_attention_rows if by_rows else self_attention_panels
             if plan is None:                                              # block does not merge: per-frame attention
-                attn_output = self_attention_rows(block.attn1, norm_hidden_states.contiguous(), None, None)
+                attn_output = sa(block.attn1, norm_hidden_states.contiguous(), None, None)
             else:
-                attn_output = self_attention_rows(block.attn1, plan.x_joined, plan.anchors_in, plan.gather_map, q_rows,
-                                                  q_count)
+                attn_output = sa(block.attn1, plan.x_joined, plan.anchors_in, plan.gather_map, q_rows, q_count)
         else:
             attn_output = self_attention(block.attn1, merged, plan.M if plan is not None else None, q_rows, q_count)
         if live:
@@ -671,12 +792,16 @@ def make_diffusers_tome_block(block_class: Type[torch.nn.Module]) -> Type[torch.
                 norm_hidden_states, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(
                     hidden_states, timestep, class_labels, hidden_dtype=hidden_states.dtype)
             else:
-                norm_hidden_states = layer_norm(self.norm1, hidden_states)
+                norm_hidden_states = None
 
             # 1. self-attention on merged tokens (the hot path)                    # patch.py:148-169
-            hidden_states = patched_self_attention_segment(
-                self, hidden_states, norm_hidden_states, encoder_hidden_states, attention_mask,
-                cross_attention_kwargs, gate_msa)
+            if norm_hidden_states is None:
+                hidden_states = self_attention_segment(self, hidden_states, encoder_hidden_states, attention_mask,
+                                                       cross_attention_kwargs)
+            else:
+                hidden_states = patched_self_attention_segment(
+                    self, hidden_states, norm_hidden_states, encoder_hidden_states, attention_mask,
+                    cross_attention_kwargs, gate_msa)
 
             cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
             if self.attn2 is not None:                                             # patch.py:171-185

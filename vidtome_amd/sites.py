@@ -163,7 +163,7 @@ def run_segment_pass(unet: SiteUNet, hiddens: List[torch.Tensor]) -> List[torch.
     for blk, h in zip(unet.blocks, hiddens):
         if not hasattr(blk, "generator"):
             blk.generator = patch.init_generator(h.device)        # what hook_tome_module does
-        outs.append(patch.patched_self_attention_segment(blk, h, patch.layer_norm(blk.norm1, h)))
+        outs.append(patch.self_attention_segment(blk, h))
     return outs
 
 
