@@ -238,7 +238,7 @@ class KernelTimer:
                    2.0 * x0.shape[0] * n * weight.shape[0] * weight.shape[1])
         # panel GEMMs of the full block (csrc/ff.hip): flops = 2 n K (rows of the weight operand)
         self._wrap("ff_geglu", "ff_geglu", lambda xp, n, w1, D, bias: 2.0 * n * xp.shape[0] * 8 * 2 * D)
-        self._wrap("linear_panels", "linear_panels", lambda xp, n, w, N, bias, resid=None: 2.0 * n * xp.shape[0] * 8 * N)
+        self._wrap("linear_panels", "linear_panels", lambda xp, n, w, N, bias, resid=None, out=None: 2.0 * n * xp.shape[0] * 8 * N)
         self._wrap("layernorm_panels", "layernorm_panels", lambda x, w, b, eps: 2.0 * x.numel() * esz(x))
         self._wrap("unmerge_add", "unmerge_add",
                    lambda y, inv, resid: (2.0 + (resid is not None)) * inv.numel() * y.shape[2] * esz(y))

@@ -4,6 +4,8 @@
 // level: vidtome/merge.py:52-74, 98-117, 119-155; vidtome/patch.py:44-85).
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 // number of dst frames among frames [0, f): frames g with g % ts == randf
@@ -138,36 +140,45 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)vtm::cdiv(n, 256); }
 // Distinct attention queries of a global level whose src side is the local chunk (merge.py:439-460 + patch.py:59-82).
 // `loc[b, t]` is the merged position of local token t: an unmerged token has a position of its own in [0, U), a merged
 // one the position U + j of the anchor row j it merged into -- and several local tokens may have merged into the same
-// anchor row, whose attention output would then be computed once per token.  One workgroup per sample builds
+// anchor row, whose attention output would then be computed once per token.  Outputs
 //   qc[b, :]   the DISTINCT merged positions: [0 .. U) then U + j for every matched j, ascending; entries past the
 //              count repeat position 0 (valid rows for the projection GEMM that nobody reads)
 //   tmap[b, t] the row of that compact list local token t reads its attention output from
 //   count[b]   number of distinct queries
-// with a presence bitmap + a block-wide prefix sum (Nd <= ~10^5 per sample: tens of microseconds, no host round trip).
+// Two wide launches around a presence BITMAP of the anchor rows (Nd bits per sample: 4 KB at the cfg-2 top block): the
+// first sets the bits; in the second every workgroup loads its sample's whole bitmap into LDS, scans the word popcounts
+// (rank(j) = words before j's word + bits below j inside it) and writes its slice of qc / tmap.  (One workgroup per
+// sample walking flags and ranks through global memory took 50-95 us; no host round trip either way.)
 constexpr int CQ_THREADS = 1024;
+constexpr int CQ_MAX_WORDS = 4096;      // Nd <= 131 072 anchors per sample (cfg-5: 90 319)
+
+__global__ __launch_bounds__(256) void compact_mark_kernel(const int32_t *__restrict__ loc, int64_t B, int64_t Ml, int64_t U,
+                                                           int64_t words, uint32_t *__restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Ml) return;
+    const int64_t b = i / Ml;
+    const int32_t p = loc[i];
+    if (p >= U) atomicOr(&bits[b * words + ((p - U) >> 5)], 1u << ((p - U) & 31));
+}
 
 __global__ __launch_bounds__(CQ_THREADS) void compact_queries_kernel(const int32_t *__restrict__ loc, int64_t Ml, int64_t U,
-                                                                    int64_t Nd, int32_t *__restrict__ flag,
+                                                                    int64_t Nd, int64_t words, const uint32_t *__restrict__ bits,
                                                                     int32_t *__restrict__ qc, int32_t *__restrict__ tmap,
                                                                     int32_t *__restrict__ count) {
+    __shared__ uint32_t sbits[CQ_MAX_WORDS];
+    __shared__ int32_t spre[CQ_MAX_WORDS];        // matched anchor rows in the words before this one
     __shared__ int32_t wave_sum[CQ_THREADS / 64];
     __shared__ int32_t total_s;
-    const int64_t b = blockIdx.x;
+    const int64_t b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t *lb = loc + b * Ml;
-    int32_t *fb = flag + b * Nd, *qb = qc + b * Ml, *tb = tmap + b * Ml;
-    for (int64_t j = tid; j < Nd; j += CQ_THREADS) fb[j] = 0;
+    const uint32_t *bb = bits + b * words;
+    for (int64_t w = tid; w < words; w += CQ_THREADS) sbits[w] = bb[w];
     __syncthreads();
-    for (int64_t t = tid; t < Ml; t += CQ_THREADS) {
-        const int32_t p = lb[t];
-        if (p >= U) fb[p - U] = 1;                    // benign race: every writer stores 1
-    }
-    __syncthreads();
-    // exclusive prefix sum of the presence flags; thread i owns the contiguous slice [i * per, (i + 1) * per)
-    const int64_t per = (Nd + CQ_THREADS - 1) / CQ_THREADS;
-    const int64_t j0 = (int64_t)tid * per, j1 = j0 + per < Nd ? j0 + per : Nd;
+    // exclusive prefix sum of the word popcounts; thread i owns the contiguous words [i * per, (i + 1) * per)
+    const int per = (int)((words + CQ_THREADS - 1) / CQ_THREADS);
+    const int64_t w0 = (int64_t)tid * per, w1 = w0 + per < words ? w0 + per : words;
     int32_t mine = 0;
-    for (int64_t j = j0; j < j1; ++j) mine += fb[j];
+    for (int64_t w = w0; w < w1; ++w) mine += __popc(sbits[w]);
     int32_t incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -186,27 +197,33 @@ __global__ __launch_bounds__(CQ_THREADS) void compact_queries_kernel(const int32
         total_s = run;
     }
     __syncthreads();
-    int32_t rank = wave_sum[wave] + incl - mine;
-    for (int64_t j = j0; j < j1; ++j) {
-        const int32_t f = fb[j];
-        fb[j] = rank;                                  // flag -> rank of anchor row j among the matched ones
-        if (f) qb[U + rank] = (int32_t)(U + j);
-        rank += f;
+    int32_t run = wave_sum[wave] + incl - mine;
+    for (int64_t w = w0; w < w1; ++w) {
+        spre[w] = run;
+        run += __popc(sbits[w]);
     }
-    const int64_t cnt = U + total_s;
-    if (tid == 0) count[b] = (int32_t)cnt;
-    for (int64_t t = tid; t < U; t += CQ_THREADS) qb[t] = (int32_t)t;
-    for (int64_t t = cnt + tid; t < Ml; t += CQ_THREADS) qb[t] = 0;
     __syncthreads();
-    for (int64_t t = tid; t < Ml; t += CQ_THREADS) {
+    const int64_t cnt = U + total_s;
+    if (blockIdx.x == 0 && tid == 0) count[b] = (int32_t)cnt;
+    const int32_t *lb = loc + b * Ml;
+    int32_t *qb = qc + b * Ml, *tb = tmap + b * Ml;
+    const int64_t gsz = (int64_t)gridDim.x * CQ_THREADS, g0 = (int64_t)blockIdx.x * CQ_THREADS + tid;
+    auto rank_of = [&](int64_t j) { return spre[j >> 5] + __popc(sbits[j >> 5] & ((1u << (j & 31)) - 1u)); };
+    for (int64_t j = g0; j < Nd; j += gsz)                      // matched anchor rows -> their slot of the compact list
+        if (sbits[j >> 5] >> (j & 31) & 1u) qb[U + rank_of(j)] = (int32_t)(U + j);
+    for (int64_t t = g0; t < Ml; t += gsz) {
+        if (t < U) qb[t] = (int32_t)t;
+        else if (t >= cnt) qb[t] = 0;
         const int32_t p = lb[t];
-        tb[t] = p < U ? p : (int32_t)(U + fb[p - U]);
+        tb[t] = p < U ? p : (int32_t)(U + rank_of(p - U));
     }
 }
 
 }  // namespace
 
-VTM_EXPORT size_t vtm_compact_queries_ws_bytes(int64_t B, int64_t Nd) { return (size_t)(B > 0 && Nd > 0 ? B * Nd * 4 : 0); }
+VTM_EXPORT size_t vtm_compact_queries_ws_bytes(int64_t B, int64_t Nd) {
+    return (size_t)(B > 0 && Nd > 0 ? B * vtm::cdiv(Nd, 32) * 4 : 0);
+}
 
 VTM_EXPORT int vtm_compact_queries(const int32_t *loc, int64_t B, int64_t Ml, int64_t U, int64_t Nd, void *ws,
                                    size_t ws_bytes, int32_t *qc, int32_t *tmap, int32_t *count, vtm_stream_t stream) {
@@ -216,8 +233,16 @@ VTM_EXPORT int vtm_compact_queries(const int32_t *loc, int64_t B, int64_t Ml, in
     if (ws_bytes < vtm_compact_queries_ws_bytes(B, Nd))
         return vtm::fail(VTM_EWORKSPACE, "vtm_compact_queries: workspace %zu < %zu bytes", ws_bytes,
                          vtm_compact_queries_ws_bytes(B, Nd));
-    hipLaunchKernelGGL(compact_queries_kernel, dim3((unsigned)B), dim3(CQ_THREADS), 0, vtm::as_stream(stream), loc, Ml, U, Nd,
-                       static_cast<int32_t *>(ws), qc, tmap, count);
+    const int64_t words = vtm::cdiv(Nd, 32);
+    VTM_REQUIRE(words <= CQ_MAX_WORDS, "vtm_compact_queries: more than %d anchor rows per sample", CQ_MAX_WORDS * 32);
+    hipStream_t s = vtm::as_stream(stream);
+    uint32_t *bits = static_cast<uint32_t *>(ws);
+    const hipError_t e = hipMemsetAsync(bits, 0, (size_t)(B * words * 4), s);
+    if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_compact_queries: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(compact_mark_kernel, dim3((unsigned)vtm::cdiv(B * Ml, 256)), dim3(256), 0, s, loc, B, Ml, U, words, bits);
+    const unsigned per_sample = (unsigned)std::min<int64_t>(vtm::cdiv(std::max(Ml, Nd), CQ_THREADS * 2), 64);
+    hipLaunchKernelGGL(compact_queries_kernel, dim3(per_sample, (unsigned)B), dim3(CQ_THREADS), 0, s, loc, Ml, U, Nd, words,
+                       (const uint32_t *)bits, qc, tmap, count);
     return vtm::launch_status("vtm_compact_queries");
 }
 

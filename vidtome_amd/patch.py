@@ -164,7 +164,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 # patch.py:80: new anchors = u(merged) = the local tokens with every merged local src row
                 # replaced by its matched global row -> one gather from [chunk | old anchors]
                 anchors_out = _lib.gather_rows(xj, gt, _lib.compose(loc, gl.new_cur, Ml))
-                if local_is_src and COMPACT_QUERIES:
+                if local_is_src and COMPACT_QUERIES and gl.Nd <= 131072:      # (vtm_compact_queries' bitmap lives in LDS)
                     qc, tmap, plan.q_count = _lib.compact_queries(loc, gl.Ns - gl.r, gl.Nd)
                     plan.q_rows = qc
                     plan.inv_q = _lib.compose(inv, tmap, L) if inv is not None else tmap
