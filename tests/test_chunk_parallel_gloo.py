@@ -68,12 +68,25 @@ def _free_port():
     return p
 
 
+def _map_of(like, local):
+    """(B, M_local) int32 rows of ``like`` (B, L, C) that ``local`` (B, M_local, C) -- row copies of them -- came from:
+    what patch.compute_merge hands the exchange as the composed local merge map."""
+    like = like.numpy() if hasattr(like, "numpy") else like
+    if local.shape[1] == like.shape[1]:
+        return None                                    # no local level (single-frame chunk): the tokens ARE the chunk
+    out = np.empty(local.shape[:2], np.int32)
+    for b in range(like.shape[0]):
+        index = {row.tobytes(): j for j, row in enumerate(like[b])}
+        out[b] = [index[row.tobytes()] for row in local[b]]
+    return torch.from_numpy(out)
+
+
 class _Module:                     # what the exchange needs from a patched block: its generator
     def __init__(self, gen):
         self.generator = gen
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, early=True):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -84,6 +97,7 @@ def _worker(rank, world, port, mode, q):
         ref, ref_end = _reference(oracle, mode, steps)
         tpf = HW[0] * HW[1]
         ex = cp.AnchorExchange(mode)
+        ex.early = early
         mods = [_Module(_fork()) for _ in range(NBLK)]
         ok, why = True, []
 
@@ -110,7 +124,7 @@ def _worker(rank, world, port, mode, q):
                         def get(self, k, d=None):
                             if k != "global_tokens":
                                 return dict.get(self, k, d)
-                            got = ex.anchors_for(key, lambda: torch.from_numpy(local), like)
+                            got = ex.anchors_for(key, lambda: torch.from_numpy(local), like, _map_of(like, local))
                             return None if got is None else got.numpy()
                     state = State()
                     m, u, merged, trace = oracle.compute_merge(h, HW, ARGS, oracle.RandomDraws.from_torch_generator(mod.generator), state)
@@ -140,12 +154,16 @@ def _worker(rank, world, port, mode, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["ring", "neighbour", "allgather"])
+@pytest.mark.parametrize("mode", ["ring", "neighbour", "neighbour-single-message", "allgather"])
 def test_two_rank_exchange_gloo(oracle, mode):
+    """neighbour: the early hand-over (joined chunk when the block starts, composed map after the local levels, the
+    receiver gathers) and the single-message form (merged tokens after the local levels) give the same anchors."""
+    early = mode != "neighbour-single-message"
+    mode = mode.split("-")[0]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q, early)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
@@ -183,7 +201,7 @@ def test_fake_ranks_in_process(oracle, W):
 
                     class State(dict):
                         def get(self, k, d=None):
-                            got = ex.anchors_for(key, lambda: torch.from_numpy(local), like)
+                            got = ex.anchors_for(key, lambda: torch.from_numpy(local), like, _map_of(like, local))
                             return None if got is None else got.numpy()
                     state = State()
                     merged = oracle.compute_merge(h, HW, ARGS, oracle.RandomDraws.from_torch_generator(mod.generator), state)[2]
@@ -242,7 +260,7 @@ def test_long_stream_releases_finished_sends(oracle):
 
             class State(dict):
                 def get(self, k, d=None):
-                    got = ex.anchors_for(key, lambda: torch.from_numpy(local), like)
+                    got = ex.anchors_for(key, lambda: torch.from_numpy(local), like, _map_of(like, local))
                     return None if got is None else got.numpy()
             state = State()
             oracle.compute_merge(h, HW, ARGS, oracle.RandomDraws.from_torch_generator(mod.generator), state)
@@ -295,7 +313,7 @@ def test_idle_ranks_keep_the_sequential_draw_stream(oracle, mode):
 
                 class State(dict):
                     def get(self, k, d=None):
-                        got = ex.anchors_for(key, lambda: torch.from_numpy(local), like)
+                        got = ex.anchors_for(key, lambda: torch.from_numpy(local), like, _map_of(like, local))
                         return None if got is None else got.numpy()
                 state = State()
                 merged = oracle.compute_merge(h, HW, ARGS, oracle.RandomDraws.from_torch_generator(mod.generator), state)[2]

@@ -10,9 +10,16 @@ per chunk; only this hand-off couples ranks.  Three exchange modes, one class (`
                        chunk i+1 -- rank W-1 hands over to rank 0 for the next round, so a step may have any number
                        of chunks.  A wavefront pipeline whose skew is one compute_merge per hop.  Reproduces the
                        sequential run bit for bit.
-``neighbour``          every chunk merges against the LOCAL merged tokens of chunk i-1 (sent by its rank as soon as
-                       its local levels are done).  No serial chain: all ranks of a round run concurrently.  A
-                       documented semantic deviation (anchors are "parallel", not chained).
+``neighbour``          every chunk merges against the LOCAL merged tokens of chunk i-1.  No serial chain: all ranks of a
+                       round run concurrently.  A documented semantic deviation (anchors are "parallel", not chained).
+                       The hand-over is split so that the bytes move WHILE the local levels run: when a block starts, every
+                       rank ships its joined chunk (B, F N, C) to its successor and posts the receive of its predecessor's;
+                       when its local levels are done it ships the composed local merge MAP
+                       (B, M_local int32, a few hundred KB) the same way, and the receiver gathers the predecessor's local
+                       tokens out of the pool it already holds.  Twice the bytes of sending the merged tokens -- on a link
+                       that is otherwise idle -- but nothing is waited for where the anchors are consumed (sending the
+                       merged tokens after the local levels leaves the whole transfer, 0.45 ms per cfg-2 top block, exposed).
+                       VIDTOME_NEIGHBOUR_EARLY=0 selects that single-message form.
 ``allgather``          the same semantics through one RCCL all-gather per merging block (north_star's wording); each
                        rank uses only its predecessor's shard, so ``neighbour`` moves 1/(W-1) of the bytes.
 
@@ -202,7 +209,7 @@ class LocalTransport:
 # the exchange
 # ----------------------------------------------------------------------------------------------------
 class _BlockState:
-    __slots__ = ("module", "tsize", "args", "drawn", "lens", "recv", "carry", "steps_done")
+    __slots__ = ("module", "tsize", "args", "drawn", "lens", "recv", "carry", "steps_done", "pool")
 
     def __init__(self, module, tsize, args, steps_done=0):
         self.module, self.tsize, self.args = module, tsize, args
@@ -211,6 +218,7 @@ class _BlockState:
         self.lens: Dict[int, int] = {}    # chunk index -> merged local length (simulated or own)
         self.recv = None        # pending receive of the predecessor's tokens
         self.carry = None       # tokens of this rank's previous chunk (world == 1 / all-gather wrap-around)
+        self.pool = None        # neighbour mode, early hand-over: the predecessor's joined chunk on its way here
 
 
 class AnchorExchange:
@@ -239,6 +247,8 @@ class AnchorExchange:
         # the chunk count varies, generate.py:176-178).  A block it has not run yet has no _BlockState -- its token
         # count per frame is only known once the model reaches it -- so the schedules of the finished steps are kept
         # and a block replays the ones it missed when it first appears (begin_block).
+        import os
+        self.early = os.environ.get("VIDTOME_NEIGHBOUR_EARLY", "1") != "0"   # neighbour mode: joined chunk first, map later
         self._history: List[List[int]] = []
         self._modules: Dict[str, object] = {}                      # patched blocks registered by enable()
 
@@ -255,7 +265,7 @@ class AnchorExchange:
             raise ValueError("the all-gather mode is a collective per round: the step needs a multiple of "
                              f"{self.world} chunks (got {len(self._frames)}); use 'neighbour' or 'ring'")
         for st in self._blocks.values():
-            st.drawn, st.lens, st.recv, st.carry = 0, {}, None, None
+            st.drawn, st.lens, st.recv, st.carry, st.pool = 0, {}, None, None, None
         # The sequential run forks every block generator at the block's first forward of the FIRST step
         # (patch.py:215-231), i.e. right after that step's schedule was drawn.  A rank whose first chunk comes later
         # would fork later -- after further draws from the global generator (the next steps' schedules) -- and its
@@ -338,7 +348,17 @@ class AnchorExchange:
         self._catch_up(st)
         self._replay(st, i)
         st.drawn = i + 1                                   # compute_merge itself makes chunk i's draws
-        if not args["merge_global"] or i == 0 or self.mode == "allgather":
+        if not args["merge_global"] or self.mode == "allgather":
+            return
+        if self.mode == "neighbour":
+            if self.world > 1 and self.early:
+                # ship the joined chunk now, receive the predecessor's: both overlap this block's local levels
+                n = len(self._frames)
+                send = like if i + 1 < n else None
+                spec = ((like.shape[0], self._frames[i - 1] * tsize, like.shape[2]), like.dtype, like.device) if i > 0 else None
+                st.pool = self._exchange(send, self._owner(i + 1), spec, self._owner(i - 1))
+            return                                         # (single-message form: everything happens in anchors_for)
+        if i == 0:
             return
         src = self._owner(i - 1)
         if src == self.rank:                               # world == 1: the predecessor ran here
@@ -346,10 +366,11 @@ class AnchorExchange:
         B = like.shape[0]
         st.recv = self.t.irecv((B, st.lens[i - 1], like.shape[2]), like.dtype, like.device, src)
 
-    def anchors_for(self, key: str, local_tokens_fn: Callable[[], torch.Tensor], like: torch.Tensor
-                    ) -> Optional[torch.Tensor]:
+    def anchors_for(self, key: str, local_tokens_fn: Callable[[], torch.Tensor], like: torch.Tensor,
+                    local_map: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """The tokens chunk i merges against at this block (None for the first chunk of a step).  The parallel modes
-        first publish this chunk's own local merged tokens (``local_tokens_fn()``)."""
+        first publish this chunk's own local merged tokens (``local_tokens_fn()``; ``local_map`` (B, M_local) int32 = the
+        rows of ``like`` they are, None when the chunk has no local level -- what the early hand-over ships instead)."""
         i, st = self._cur, self._blocks[key]
         n = len(self._frames)
         if self.mode == "ring":
@@ -360,19 +381,37 @@ class AnchorExchange:
             got, st.recv = st.recv.wait(), None
             self.bytes_received += got.numel() * got.element_size()
             return got
+        if self.mode == "neighbour" and self.world > 1:
+            B, C = like.shape[0], like.shape[2]
+            nxt, prv = self._owner(i + 1), self._owner(i - 1)
+            if self.early:
+                # second half of the hand-over: the composed local merge map (None: the chunk has no local level, its
+                # local tokens ARE its joined chunk -- the receiver knows that from the schedule)
+                prev_has_map = i > 0 and self._has_local_levels(self._frames[i - 1], st.args)
+                send = local_map.contiguous() if (i + 1 < n and local_map is not None) else None
+                spec = ((B, st.lens[i - 1]), torch.int32, like.device) if prev_has_map else None
+                maps = self._exchange(send, nxt, spec, prv)
+                st.lens[i] = like.shape[1] if local_map is None else local_map.shape[1]
+                pool, st.pool = (st.pool.wait() if st.pool is not None else None), None
+                got_map = maps.wait() if maps is not None else None
+                if i == 0:
+                    return None
+                self.bytes_received += pool.numel() * pool.element_size() + (0 if got_map is None else got_map.numel() * 4)
+                return pool if got_map is None else _lib.gather_rows(pool, None, got_map) if pool.is_cuda else \
+                    torch.gather(pool, 1, got_map.long()[:, :, None].expand(-1, -1, C))
+            local = local_tokens_fn().contiguous()
+            st.lens[i] = local.shape[1]
+            spec = ((B, st.lens[i - 1], C), like.dtype, like.device) if i > 0 else None
+            h = self._exchange(local if i + 1 < n else None, nxt, spec, prv)
+            got = h.wait() if h is not None else None
+            if got is not None:
+                self.bytes_received += got.numel() * got.element_size()
+            return got
         local = local_tokens_fn().contiguous()
         st.lens[i] = local.shape[1]
-        if self.mode == "neighbour":
-            if i + 1 < n:
-                self._send(local, self._owner(i + 1), st)
-            if self.world == 1:                            # the predecessor ran here: hand over in place
-                got, st.carry = st.carry, local
-                return got if i > 0 else None
-            if i == 0:
-                return None
-            got, st.recv = st.recv.wait(), None
-            self.bytes_received += got.numel() * got.element_size()
-            return got
+        if self.mode == "neighbour":                       # world == 1: the predecessor ran here, hand over in place
+            got, st.carry = st.carry, local
+            return got if i > 0 else None
         # all-gather: chunk lengths differ between ranks -> pad to the round's maximum (known from the replay)
         first = i - self.rank
         st_lens = dict(st.lens)
@@ -417,6 +456,23 @@ class AnchorExchange:
             st.carry = anchors
             return
         self._send(anchors.contiguous(), dst, st)
+
+    @staticmethod
+    def _has_local_levels(frames: int, args: Dict) -> bool:
+        """patch.py:44-54: a chunk builds a local merge map iff it has more than one frame and a positive ratio."""
+        return frames > 1 and args["local_merge_ratio"] > 0
+
+    def _exchange(self, send: Optional[torch.Tensor], dst: int, recv_spec, src: int):
+        """An asynchronous send and an asynchronous receive (either may be absent), INDEPENDENT of each other: the send
+        to the successor and the receive from the predecessor travel on different communicators (torch keeps one per
+        pair of ranks, each with its own stream), so a send that has to wait for its receiver -- rank W-1's successor is
+        rank 0's chunk of the NEXT round -- never holds up this rank's receive.  (Grouping the two into one
+        ncclGroup would couple them and deadlock on exactly that wrap-around.)  Returns the receive handle or None."""
+        if send is not None:
+            self._send(send, dst, None)
+        if recv_spec is None:
+            return None
+        return self.t.irecv(recv_spec[0], recv_spec[1], recv_spec[2], src)
 
     def _send(self, tensor: torch.Tensor, dst: int, st: _BlockState) -> None:
         if dst == self.rank:

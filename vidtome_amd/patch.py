@@ -144,7 +144,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
         anchors_out = None
         if args["merge_global"]:                                                   # patch.py:59-82
             if exchange is not None:
-                gt = exchange.anchors_for(xkey, lambda: xj if cur is None else _lib.gather_rows(xj, None, cur), xj)
+                gt = exchange.anchors_for(xkey, lambda: xj if cur is None else _lib.gather_rows(xj, None, cur), xj, cur)
             else:
                 gt = getattr(module, "global_tokens", None)
             if gt is not None:
