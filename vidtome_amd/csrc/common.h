@@ -55,6 +55,31 @@ inline int device_cus() {
     return n;
 }
 
+// 16-byte global accesses with an optional streaming (non-temporal) policy.  Measured on the HBM-bound kernels
+// (profiles/r03_hbm_nt.txt): beyond the 256 MB Infinity Cache non-temporal loads / stores are +5 ... +15 % (no line is
+// kept that nobody will read again before it is evicted); for working sets the cache holds they are -10 % (the next
+// kernel finds its input in the cache only if the producer left it there).  Callers pick by working-set size.
+typedef uint32_t vtm_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int64_t STREAM_BYTES = 256ll << 20;       // working sets above this are streamed
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const void *p) {
+    if constexpr (NT) {
+        const vtm_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const vtm_u32x4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return *reinterpret_cast<const uint4 *>(p);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void st16(void *p, uint4 v) {
+    if constexpr (NT) {
+        const vtm_u32x4 w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<vtm_u32x4 *>(p));
+    } else {
+        *reinterpret_cast<uint4 *>(p) = v;
+    }
+}
+
 }  // namespace vtm
 
 #define VTM_REQUIRE(cond, ...)                                   \

@@ -15,6 +15,7 @@ __device__ __forceinline__ const char *pool_row_bytes(const char *x0, int64_t P0
     return r < P0 ? x0 + (b * P0 + r) * row_bytes : x1 + (b * P1 + (r - P0)) * row_bytes;
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const char *__restrict__ x0, int64_t P0,
                                                           const char *__restrict__ x1, int64_t P1,
                                                           int64_t B, int64_t row_bytes,
@@ -28,8 +29,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char *__restrict
         const int64_t row = idx / chunks;  // b * M + p
         const int64_t b = row / M;
         const char *src = pool_row_bytes(x0, P0, x1, P1, b, map[row], row_bytes);
-        *reinterpret_cast<uint4 *>(out + (b * out_rows + row % M) * row_bytes + c * 16) =
-            *reinterpret_cast<const uint4 *>(src + c * 16);
+        vtm::st16<NT>(out + (b * out_rows + row % M) * row_bytes + c * 16, vtm::ld16<NT>(src + c * 16));
     }
 }
 
@@ -64,7 +64,7 @@ template <> struct Add16<vtm_bf16> {
     }
 };
 
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void unmerge_add_kernel(const char *__restrict__ y, int64_t M,
                                                           const int32_t *__restrict__ inv,
                                                           const char *__restrict__ resid, int64_t B,
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256) void unmerge_add_kernel(const char *__restrict
         const int64_t c = idx % chunks;
         const int64_t row = idx / chunks;  // b * L + i
         const int64_t b = row / L;
-        uint4 v = *reinterpret_cast<const uint4 *>(y + (b * M + inv[row]) * row_bytes + c * 16);
+        uint4 v = vtm::ld16<NT>(y + (b * M + inv[row]) * row_bytes + c * 16);
         if (resid) {
-            const uint4 r = *reinterpret_cast<const uint4 *>(resid + row * row_bytes + c * 16);
+            const uint4 r = vtm::ld16<NT>(resid + row * row_bytes + c * 16);
             v = Add16<T>::apply(v, r);
         }
-        *reinterpret_cast<uint4 *>(out + row * row_bytes + c * 16) = v;
+        vtm::st16<NT>(out + row * row_bytes + c * 16, v);
     }
 }
 
@@ -108,8 +108,12 @@ VTM_EXPORT int vtm_gather_rows(const void *x0, int64_t P0, const void *x1, int64
                 "vtm_gather_rows: row size %lld B must be a multiple of 16", (long long)(C * es));
     if (M == 0) return VTM_OK;
     const int64_t total = B * M * (C * es / 16);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(256), 0, vtm::as_stream(stream),
-                       (const char *)x0, P0, (const char *)x1, P1, B, C * es, map, M, (char *)out, out_rows);
+    if (2 * total * 16 > vtm::STREAM_BYTES)     // rows read + rows written do not fit the Infinity Cache: stream them
+        hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(grid_for(total)), dim3(256), 0, vtm::as_stream(stream),
+                           (const char *)x0, P0, (const char *)x1, P1, B, C * es, map, M, (char *)out, out_rows);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(grid_for(total)), dim3(256), 0, vtm::as_stream(stream),
+                           (const char *)x0, P0, (const char *)x1, P1, B, C * es, map, M, (char *)out, out_rows);
     return vtm::launch_status("vtm_gather_rows");
 }
 
@@ -123,18 +127,15 @@ VTM_EXPORT int vtm_unmerge_add(const void *y, int64_t M, const int32_t *inv, con
     const int64_t total = B * L * (C * es / 16);
     hipStream_t s = vtm::as_stream(stream);
     const unsigned g = grid_for(total);
+    const bool nt = (B * M * C * es + (resid ? 2 : 1) * total * 16) > vtm::STREAM_BYTES;
+#define VTM_UNMERGE(T, NT_)                                                                                            \
+    hipLaunchKernelGGL((unmerge_add_kernel<T, NT_>), dim3(g), dim3(256), 0, s, (const char *)y, M, inv, (const char *)resid, B, \
+                       L, C * es, (char *)out)
     switch (dtype) {
-        case VTM_F32:
-            hipLaunchKernelGGL(unmerge_add_kernel<float>, dim3(g), dim3(256), 0, s, (const char *)y, M, inv,
-                               (const char *)resid, B, L, C * es, (char *)out);
-            break;
-        case VTM_F16:
-            hipLaunchKernelGGL(unmerge_add_kernel<__half>, dim3(g), dim3(256), 0, s, (const char *)y, M, inv,
-                               (const char *)resid, B, L, C * es, (char *)out);
-            break;
-        default:
-            hipLaunchKernelGGL(unmerge_add_kernel<vtm_bf16>, dim3(g), dim3(256), 0, s, (const char *)y, M,
-                               inv, (const char *)resid, B, L, C * es, (char *)out);
+        case VTM_F32: if (nt) VTM_UNMERGE(float, true); else VTM_UNMERGE(float, false); break;
+        case VTM_F16: if (nt) VTM_UNMERGE(__half, true); else VTM_UNMERGE(__half, false); break;
+        default: if (nt) VTM_UNMERGE(vtm_bf16, true); else VTM_UNMERGE(vtm_bf16, false);
     }
+#undef VTM_UNMERGE
     return vtm::launch_status("vtm_unmerge_add");
 }

@@ -10,13 +10,13 @@ namespace {
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MAX_CHUNKS = 4;       // 8-channel chunks per lane: C <= 64 * 8 * 4 = 2048
 
-template <typename T>
+template <typename T, bool NT = false>
 __device__ __forceinline__ void load8(const T *p, float (&f)[8]) {
     if constexpr (sizeof(T) == 4) {
         const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
         f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
     } else {
-        const uint4 v = *reinterpret_cast<const uint4 *>(p);
+        const uint4 v = vtm::ld16<NT>(p);
         const T *e = reinterpret_cast<const T *>(&v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = vtm::to_f32(e[j]);
@@ -28,7 +28,7 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
 template <> __device__ __forceinline__ vtm_bf16 from_f32<vtm_bf16>(float v) { return __float2bfloat16(v); }
 
-template <typename T>
+template <typename T, bool NT = false>
 __device__ __forceinline__ void store8(T *p, const float (&f)[8]) {
     if constexpr (sizeof(T) == 4) {
         *reinterpret_cast<float4 *>(p) = make_float4(f[0], f[1], f[2], f[3]);
@@ -38,7 +38,7 @@ __device__ __forceinline__ void store8(T *p, const float (&f)[8]) {
         T *e = reinterpret_cast<T *>(&v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) e[j] = from_f32<T>(f[j]);
-        *reinterpret_cast<uint4 *>(p) = v;
+        vtm::st16<NT>(p, v);
     }
 }
 
@@ -57,7 +57,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // NCH: 8-channel chunks per lane (C <= 512 NCH); R: rows per wave, all loaded before the first reduction so that
 // a wave keeps R rows of HBM traffic in flight (one row per wave leaves the kernel latency-bound: 2.4 TB/s)
-template <typename T, int NCH, int R>
+template <typename T, int NCH, int R, bool NT>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_kernel(const T *__restrict__ x, const T *__restrict__ gamma,
                                                                          const T *__restrict__ beta, int64_t rows, int C,
                                                                          float eps, T *__restrict__ out, int64_t panel_rows) {
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_kernel(const T
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
-            if (c < chunks) load8(xr + c * 8, v[r][i]);
+            if (c < chunks) load8<T, NT>(xr + c * 8, v[r][i]);
         }
     }
 #pragma unroll
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_kernel(const T
                         y[j] = gamma ? (beta ? __builtin_fmaf(n, g[j], b[j]) : n * g[j]) : (beta ? n + b[j] : n);
                     }
                     // panel_rows > 0: the k-panel layout [C / 8][panel_rows][8] of the panel GEMMs (ff.hip)
-                    store8(panel_rows ? out + ((int64_t)c * panel_rows + (row0 + r)) * 8 : out + (row0 + r) * C + c * 8, y);
+                    store8<T, NT>(panel_rows ? out + ((int64_t)c * panel_rows + (row0 + r)) * 8 : out + (row0 + r) * C + c * 8, y);
                 }
             }
         }
@@ -145,7 +145,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // The SD channel counts (C = 40 LPR, LPR = 8 / 16 / 32 for 320 / 640 / 1280): LPR lanes per row, every lane 5 pieces of
 // 16 bytes at a stride of LPR pieces -- all 64 lanes busy (a wave per 320-channel row keeps 24 of them idle), a load
 // instruction covers 64 / LPR rows with 16 LPR contiguous bytes each, and a wave keeps R * 64 / LPR rows in flight.
-template <typename T, int LPR, int R>
+template <typename T, int LPR, int R, bool NT>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_rows_kernel(const T *__restrict__ x, const T *__restrict__ gamma,
                                                                               const T *__restrict__ beta, int64_t rows, float eps,
                                                                               T *__restrict__ out, int64_t panel_rows) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_rows_kernel(co
         if (row >= rows) row = rows - 1;                        // surplus rows recompute the last one, unstored
         const T *xr = x + row * C;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) load8(xr + (g + LPR * i) * 8, v[r][i]);
+        for (int i = 0; i < NCH; ++i) load8<T, NT>(xr + (g + LPR * i) * 8, v[r][i]);
     }
     float mean[R], rstd[R];
 #pragma unroll
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_rows_kernel(co
                     const float n = (v[r][i][j] - mean[r]) * rstd[r];
                     y[j] = gamma ? (beta ? __builtin_fmaf(n, gm[j], bt[j]) : n * gm[j]) : (beta ? n + bt[j] : n);
                 }
-                store8(panel_rows ? out + ((int64_t)c * panel_rows + row) * 8 : out + row * C + c * 8, y);
+                store8<T, NT>(panel_rows ? out + ((int64_t)c * panel_rows + row) * 8 : out + row * C + c * 8, y);
             }
         }
     }
@@ -211,14 +211,16 @@ void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_
 #ifndef VTM_OLD_LN   // (A/B build switch)
     // measured (profiles/r02_sweeps.txt): +24 % HBM rate at C = 320 beyond the Infinity Cache; no gain at 640 / 1280, where a
     // wave per row already uses all its lanes -- those keep the kernel above
+    // input + output beyond the Infinity Cache: streaming loads / stores (common.h)
+    const bool nt = 2 * rows * C * (int64_t)sizeof(T) > vtm::STREAM_BYTES;
     if (C == 320) {
         constexpr int R = 2;
         const int lpr = (int)(C / 40);
         const dim3 g((unsigned)vtm::cdiv(rows, (int64_t)WAVES_PER_BLOCK * (64 / lpr) * R)), b(WAVES_PER_BLOCK * 64);
-#define VTM_LNR(LPR)                                                                                                   \
-    hipLaunchKernelGGL((layernorm_rows_kernel<T, LPR, R>), g, b, 0, s, (const T *)x, (const T *)gamma, (const T *)beta, rows, \
+#define VTM_LNR(LPR, NT_)                                                                                              \
+    hipLaunchKernelGGL((layernorm_rows_kernel<T, LPR, R, NT_>), g, b, 0, s, (const T *)x, (const T *)gamma, (const T *)beta, rows, \
                        eps, (T *)out, panel_rows)
-        if (lpr == 8) VTM_LNR(8); else if (lpr == 16) VTM_LNR(16); else VTM_LNR(32);
+        if (nt) VTM_LNR(8, true); else VTM_LNR(8, false);
 #undef VTM_LNR
         return;
     }
@@ -227,8 +229,14 @@ void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_
     const int R = nch == 1 ? 4 : 2;
     const dim3 grid((unsigned)vtm::cdiv(rows, (int64_t)WAVES_PER_BLOCK * R)), block(WAVES_PER_BLOCK * 64);
 #define VTM_LN(NCH, RR)                                                                                               \
-    hipLaunchKernelGGL((layernorm_kernel<T, NCH, RR>), grid, block, 0, s, (const T *)x, (const T *)gamma, (const T *)beta, \
-                       rows, (int)C, eps, (T *)out, panel_rows)
+    do {                                                                                                              \
+        if (nt)                                                                                                       \
+            hipLaunchKernelGGL((layernorm_kernel<T, NCH, RR, true>), grid, block, 0, s, (const T *)x, (const T *)gamma,   \
+                               (const T *)beta, rows, (int)C, eps, (T *)out, panel_rows);                              \
+        else                                                                                                          \
+            hipLaunchKernelGGL((layernorm_kernel<T, NCH, RR, false>), grid, block, 0, s, (const T *)x, (const T *)gamma,  \
+                               (const T *)beta, rows, (int)C, eps, (T *)out, panel_rows);                              \
+    } while (0)
     switch (nch) {
         case 1: VTM_LN(1, 4); break;
         case 2: VTM_LN(2, 2); break;
