@@ -1113,12 +1113,12 @@ def _site_pass_checks(unet, sites_list, hiddens, B, F, expected_M):
     recomputation of a few of their rows (attention over the merged set, oracle-free)."""
     from vidtome_amd import patch as vpatch
     from vidtome_amd import sites as S
-    plans = []
+    seen = {}
     orig = vpatch.compute_merge
 
     def rec(module, x, info, **kw):
         res = orig(module, x, info, **kw)
-        plans.append(getattr(res[0], "plan", None))
+        seen[id(module)] = getattr(res[0], "plan", None)
         return res
 
     vpatch.compute_merge = rec
@@ -1127,6 +1127,7 @@ def _site_pass_checks(unet, sites_list, hiddens, B, F, expected_M):
             outs = S.run_segment_pass(unet, hiddens)
     finally:
         vpatch.compute_merge = orig
+    plans = [seen.get(id(blk)) for blk in unet.blocks]      # (un-merged sites may never call compute_merge)
     for site, h, o, plan in zip(sites_list, hiddens, outs, plans):
         assert o.shape == h.shape and bool(torch.isfinite(o).all()), site.name
         if site.downsample <= 2:
@@ -1134,6 +1135,31 @@ def _site_pass_checks(unet, sites_list, hiddens, B, F, expected_M):
         else:
             assert plan is None
     return outs, plans
+
+
+def _block_rows_vs_oracle(oracle, blk, plan, hidden, out, fsize, share=1, n_rows=192, seed=0):
+    """Block outputs at FULL size against the oracle on SAMPLED token positions: for position i of the joined chunk the
+    reference is  to_out(softmax(q K^T) V)[inv[i]] + hidden[i]  with q / K / V projected (fp32) from the merged tokens the
+    plan selects, the attention rows by oracle.attention_qkv (double accumulation); `share` > 1 = PnP shared
+    probabilities (q / k of the source sample for every sample, pnp_utils.py:57-67).  1e-3 of the output scale."""
+    from vidtome_amd.utils import join_frame
+    a = blk.attn1
+    f32 = lambda t: t.detach().float().cpu().numpy()
+    wq, wk, wv, wo, bo = f32(a.to_q.weight), f32(a.to_k.weight), f32(a.to_v.weight), f32(a.to_out[0].weight), f32(a.to_out[0].bias)
+    merged = f32(plan.merged[:, :plan.M])                        # (B, M, C): row copies of OUR norm1 output
+    Bn, L = plan.inv.shape
+    g = np.random.default_rng(seed)
+    idx = np.unique(np.concatenate([np.arange(8), np.arange(L - 8, L), g.integers(0, L, n_rows)]))
+    inv = plan.inv.cpu().numpy()
+    m = inv[:, idx]                                              # (B, S) merged row of every sampled position
+    src = lambda t: np.broadcast_to(t[:1], t.shape) if share > 1 else t
+    k, v = merged @ wk.T, merged @ wv.T
+    q = np.stack([src(merged)[b, m[b]] for b in range(Bn)]) @ wq.T
+    o = oracle.attention_qkv(np.ascontiguousarray(q), np.ascontiguousarray(src(k)), v, a.heads)
+    hj, oj = f32(join_frame(hidden, fsize)), f32(join_frame(out, fsize))
+    ref = o @ wo.T + bo + hj[:, idx]
+    err = np.abs(oj[:, idx] - ref).max()
+    assert err < 1e-3 * max(1.0, np.abs(ref).max()), err
 
 
 @pytest.mark.parametrize("B,Ml,U,Nd", [(2, 1000, 400, 700), (1, 17, 0, 5), (3, 34816, 17408, 34816), (2, 300, 300, 64)])
@@ -1250,7 +1276,7 @@ def test_projection_paths_agree(L):
                 assert (x - y).abs().max().item() < 4e-3 * max(1.0, y.abs().max().item()), mode
 
 
-def test_cfg5_sd21_768_full_size(L):
+def test_cfg5_sd21_768_full_size(L, oracle):
     """cfg-5: SD-2.1-768, 16 frames 768x768 (latent 96x96), ratio 0.6, fp16: N = 9216 / 2304 tokens per frame,
     head dim 64, ragged merged lengths (64 513 / 16 129 local, 90 319 / 22 581 with global merging)."""
     import vidtome_amd
@@ -1262,12 +1288,16 @@ def test_cfg5_sd21_768_full_size(L):
     unet.set_size(latent)
     torch.manual_seed(123)
     hiddens = [S.synthetic_hidden(s, B, F, latent, torch.float16, DEV, seed=50 + i) for i, s in enumerate(sl)]
-    _site_pass_checks(unet, sl, hiddens, B, F, {1: 64513, 2: 16129})           # SURVEY.md 8d sizes
-    _site_pass_checks(unet, sl, hiddens, B, F, {1: 90319, 2: 22581})           # second chunk: + global merge
+    outs, plans = _site_pass_checks(unet, sl, hiddens, B, F, {1: 64513, 2: 16129})           # SURVEY.md 8d sizes
+    _block_rows_vs_oracle(oracle, unet.blocks[1], plans[1], hiddens[1], outs[1], F)          # mid site, local levels only
+    hiddens2 = [S.synthetic_hidden(s, B, F, latent, torch.float16, DEV, seed=150 + i) for i, s in enumerate(sl)]
+    outs, plans = _site_pass_checks(unet, sl, hiddens2, B, F, {1: 90319, 2: 22581})          # second chunk: + global merge
+    for i in (0, 1):                                                                         # top (d = 64, ragged 90 319) and mid
+        _block_rows_vs_oracle(oracle, unet.blocks[i], plans[i], hiddens2[i], outs[i], F, seed=i)
     vidtome_amd.remove_patch(unet)
 
 
-def test_cfg3_pnp_batch3_aligned_full_size(L):
+def test_cfg3_pnp_batch3_aligned_full_size(L, oracle):
     """cfg-3 shape: batch 3 (source | uncond | cond), align_batch=True (one matching shared by the batch,
     merge.py:93-108) and PnP shared-probability attention (pnp_utils.py:57-67,86-90) at 16 x 512x512."""
     import vidtome_amd
@@ -1289,6 +1319,9 @@ def test_cfg3_pnp_batch3_aligned_full_size(L):
             # aligned matching: every sample of the batch shares ONE index set
             gm = plan.gather_map
             assert torch.equal(gm[0], gm[1]) and torch.equal(gm[0], gm[2])
+        # block outputs at full size vs the oracle (shared probabilities: q / k of the source sample), sampled positions
+        for i in (1, 2):            # up2.0 (C = 640, d = 80) and up3.0 (C = 320, d = 40); up1.0 does not merge
+            _block_rows_vs_oracle(oracle, unet.blocks[i], plans[i], hiddens[i], outs[i], F, share=B, seed=i)
     # shared probabilities: with identical V across the batch groups the three groups' attention outputs
     # coincide although their own q/k differ (q/k of the source group are used for all)
     blk = unet.blocks[2]         # up3.0: C = 320
