@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void unmerge_add_kernel(const char *__restrict
         const int64_t c = idx % chunks;
         const int64_t row = idx / chunks;  // b * L + i
         const int64_t b = row / L;
-        uint4 v = vtm::ld16<NT>(y + (b * M + inv[row]) * row_bytes + c * 16);
+        uint4 v = vtm::ld16<false>(y + (b * M + inv[row]) * row_bytes + c * 16);   // (merged rows are read by several positions)
         if (resid) {
             const uint4 r = vtm::ld16<NT>(resid + row * row_bytes + c * 16);
             v = Add16<T>::apply(v, r);

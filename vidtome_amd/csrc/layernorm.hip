@@ -214,7 +214,10 @@ void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_
     // input + output beyond the Infinity Cache: streaming loads / stores (common.h)
     const bool nt = 2 * rows * C * (int64_t)sizeof(T) > vtm::STREAM_BYTES;
     if (C == 320) {
-        constexpr int R = 2;
+#ifndef VTM_LN_R
+#define VTM_LN_R 2          // rows per lane group in flight (A/B build switch: 3, 4)
+#endif
+        constexpr int R = VTM_LN_R;
         const int lpr = (int)(C / 40);
         const dim3 g((unsigned)vtm::cdiv(rows, (int64_t)WAVES_PER_BLOCK * (64 / lpr) * R)), b(WAVES_PER_BLOCK * 64);
 #define VTM_LNR(LPR, NT_)                                                                                              \
