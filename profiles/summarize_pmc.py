@@ -36,7 +36,12 @@ traffic = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separat
                    "tools/kbench.py ... (tools/gpu_session.sh); KiB; hbm_read_bytes = 2 * FETCH_SIZE * 1024 (gfx950), WRITE_SIZE matched the "
                    "written bytes exactly in the three gather-path kernels (calibration)"}
 for nm, kern, label, alg in (("attn", "attention_kernel", "attention_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224", 2 * (34816 + 52224) * 320 * 2 * 2),
-                             ("match", "filter_kernel", "filter_kernel top_l1 (B=2 Ns=49152 Nd=16384 C=320)", 83886080)):
+                             ("match", "filter_kernel", "filter_kernel top_l1 (B=2 Ns=49152 Nd=16384 C=320)", 83886080),
+                             # round 3: the GEGLU projection of the cfg-2 top site (131 072 tokens, C = 320 -> 2 x 1280, gated
+                             # activation in the epilogue): panels in (84 MB + 1.6 MB of weights), panels out (336 MB)
+                             ("ff", "panel_gemm_kernel<__half, 0>", "panel_gemm_kernel<half,GEGLU> n=131072 K=320 D=1280", 131072 * (320 + 1280) * 2 + 2560 * 320 * 2)):
+    if not os.path.exists(base + f"sq_{nm}_counter_collection.csv"):
+        continue
     c, n = counters(f"sq_{nm}_counter_collection.csv", kern)
     us = duration_us(f"sq_{nm}_kernel_trace.csv", kern)
     cyc = c["GRBM_GUI_ACTIVE"] / 8

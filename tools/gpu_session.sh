@@ -9,15 +9,19 @@ mkdir -p $O
 cd $R
 python -m pytest tests -m gpu -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests.log
 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"
-python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python bench.py --no-cpu-baseline --full-block > $O/bench_full_block.json 2>> $O/bench.err; echo "bench full rc=$?"
 python -c "
 import json;d=json.load(open('$O/bench.json'));print(d['value'],d['ms_per_step'],d['roofline']['frac'],d['roofline']['top_block'],d['matching'],d.get('projections'),d['cpu_baseline']['seconds_per_step'],d['cpu_baseline']['cores'])"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1; echo "prof rc=$?"
+rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py --steps 7 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1; echo "prof rc=$?"
 grep '"metric"' $O/prof.log > $O/bench_profiled.json
+python $R/profiles/summarize_rocpd.py $O/prof/k_results.db > $O/kernel_stats.txt 2>&1; rm -f $O/prof/k_results.db
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc -o sq_attn --output-format csv -- python $R/tools/kbench.py attn --Mq 34816 --M 52224 --d 40 --iters 3 > $O/pmc_sq_attn.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc -o sq_match --output-format csv -- python $R/tools/kbench.py match --shape top_l1 --iters 3 > $O/pmc_sq_match.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc -o sq_ff --output-format csv -- python $R/tools/kbench.py ff --n 131072 --C 320 --iters 3 > $O/pmc_sq_ff.log 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc -o ${ctr}_ff --output-format csv -- python $R/tools/kbench.py ff --n 131072 --C 320 --iters 3 > $O/pmc_${ctr}_ff.log 2>&1
   rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc -o ${ctr}_attn --output-format csv -- python $R/tools/kbench.py attn --Mq 34816 --M 52224 --d 40 --iters 3 > $O/pmc_${ctr}_attn.log 2>&1
   rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc -o ${ctr}_match --output-format csv -- python $R/tools/kbench.py match --shape top_l1 --iters 3 > $O/pmc_${ctr}_match.log 2>&1
 done
@@ -27,5 +31,5 @@ for what in gather unmerge layernorm; do
   done
 done
 ls $O/pmc | wc -l
-(cd $R/tools/ubench && hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 attn_tile_model.hip -o /tmp/atm 2>/dev/null && /tmp/atm > $O/attn_tile_model.txt 2>&1)
-python $R/tools/sweep_nsplit.py > $O/sweep_nsplit.txt 2>&1
+python $R/profiles/summarize_pmc.py $O $TAG > $O/pmc_summary.txt 2>&1; tail -5 $O/pmc_summary.txt
+rm -rf $O/pmc/*/ 2>/dev/null; du -sh $O
