@@ -154,6 +154,14 @@ def _worker(rank, world, port, mode, q, early=True):
             dist.destroy_process_group()
 
 
+STEPS4 = {"ring": [[3, 6, 4, 1, 4], [2, 4, 4]], "neighbour": [[3, 6, 4, 1, 4, 2], [2, 4, 4]], "allgather": [[3, 6, 4, 1], [4, 2, 2, 5]]}
+
+
+def _worker4(rank, world, port, mode, q):
+    STEPS[mode] = STEPS4[mode]          # (module global of this spawned process only)
+    _worker(rank, world, port, mode, q, True)
+
+
 @pytest.mark.parametrize("mode", ["ring", "neighbour", "neighbour-single-message", "allgather"])
 def test_two_rank_exchange_gloo(oracle, mode):
     """neighbour: the early hand-over (joined chunk when the block starts, composed map after the local levels, the
@@ -167,6 +175,23 @@ def test_two_rank_exchange_gloo(oracle, mode):
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in results:
+        assert ok, f"rank {rank} failed: {err}"
+
+
+@pytest.mark.parametrize("mode", ["ring", "neighbour", "allgather"])
+def test_four_rank_exchange_gloo(oracle, mode):
+    """World size 4 (the per-pair communicators of a real ring: no wrap-around group as with two ranks; idle ranks in the
+    3-chunk step; the all-gather pads to the round's longest chunk)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, mode, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, ok, err in results:

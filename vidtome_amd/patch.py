@@ -16,9 +16,12 @@ Differences that are design, not omissions:
 * ``module.global_tokens`` stays on the device (the reference parks it on the CPU and syncs per block,
   patch.py:65,70,80,82);
 * the block generator is always a CPU generator (see utils.init_generator);
-* ``attn1`` is evaluated from the module's own weights by the fused path (projection GEMMs through
-  hipBLASLt via torch, attention core = vtm_attention), including the reference's PnP injection branch when
-  ``utils/pnp_utils.py``-style control is registered on the module.
+* ``attn1`` is evaluated from the module's own weights by the fused path (projection GEMMs fed through the composed
+  merge map or as panel GEMMs, attention core = vtm_attention: no library GEMM on the default path), including the
+  reference's PnP injection branch when ``utils/pnp_utils.py``-style control is registered on the module;
+* with a global level the attention runs only for the DISTINCT merged rows the chunk's local tokens read
+  (MergePlan.q_rows / q_count), and the rest of the block (norm2 / attn2, norm3 / GEGLU feed-forward) runs as panel GEMMs
+  (csrc/ff.hip) when the modules are the plain arithmetic.
 """
 from __future__ import annotations
 
