@@ -193,6 +193,7 @@ class KernelTimer:
         self.records = {"attention": [], "matching": [], "layernorm": [], "gather_rows": [], "unmerge_add": [],
                         "projections": [], "ff_geglu": [], "linear_panels": [], "layernorm_panels": []}
         self.enabled = False
+        self.ref_flops = 0.0           # attention flops of the same launches had every merged row been a query
 
     def _wrap(self, name, kind, flops_of):
         orig = getattr(self.lib_mod, name)
@@ -211,11 +212,16 @@ class KernelTimer:
 
     def __enter__(self):
         # attention(q, k, vt, heads, M, scale, share): 4 * B * M^2 * C flops (QK^T + PV, all heads)
-        self._wrap("attention", "attention", lambda q, k, vt, heads, M, scale, share=1: 4.0 * q.shape[0] * M * M * q.shape[2])
+        def sa_flops(q, k, vt, heads, M, scale, share=1):
+            f = 4.0 * q.shape[0] * M * M * q.shape[2]
+            self.ref_flops += f
+            return f
+        self._wrap("attention", "attention", sa_flops)
         # attention_kv(q, k, vt, heads, Mq, Mk, scale): 4 * B * Mq * Mk * C executed flops
         # (with a device-side query bound the executed rows are the per-sample counts, rounded up to whole query blocks
         # of 256 (d <= 48) / 512 (d <= 96) / 128 queries: read back AFTER the timed region)
         def kv_flops(q, k, vt, heads, Mq, Mk, scale, use_workspace=True, q_count=None):
+            self.ref_flops += 4.0 * q.shape[0] * (Mk * Mk if Mq > 256 and Mk > Mq else Mq * Mk) * q.shape[2]
             if q_count is None:
                 return 4.0 * q.shape[0] * Mq * Mk * q.shape[2]
             d = q.shape[2] // heads
@@ -590,6 +596,9 @@ def main():
                          "top_block": {"launches": top_n, "avg_ms": round(top_ms, 4),
                                        "tflops": round(top_flops / (top_ms * 1e-3) / 1e12, 1) if top_ms > 0 else 0.0},
                          "attention_ms_per_step": round(ams / timed_passes, 3),
+                         # for context only: the reference computes attention outputs for EVERY merged row (M^2 instead of the
+                         # live / distinct Mq x M): the same time expressed in those flops
+                         "reference_equivalent_tflops": round(mt.ref_flops / (ams * 1e-3) / 1e12, 1) if ams > 0 else 0.0,
                          "event_passes": timed_passes,
                          "note": "power-limited: with these (random) operand values the kernel runs at the 1400 W package cap, "
                                  "sclk ~1.95 GHz; the same launch with non-toggling operands reaches 1 130-1 166 TFLOP/s = the floor "
