@@ -106,13 +106,16 @@ class _Done:
 
 
 class DistTransport:
-    """``torch.distributed`` point-to-point + all-gather.  With RCCL the operations run on the communicator's own
-    stream; `wait()` makes the CURRENT stream wait for them (no host block).
+    """``torch.distributed`` point-to-point + all-gather.  With RCCL the operations run on communicator streams;
+    `wait()` makes the CURRENT stream wait for them (no host block).
 
-    Ring traffic goes rank -> rank + 1, plus the wrap-around W-1 -> 0.  torch keeps ONE communicator (and one stream)
-    per pair of ranks, so with two ranks both directions would share a stream, and a send queued behind a receive
-    that waits for the peer's send -- itself queued behind a receive -- never starts.  The wrap-around therefore
-    gets a group (= communicator) of its own.
+    Every DIRECTED edge of the ring (rank r -> rank r + 1, and W-1 -> 0) gets a process group -- i.e. a communicator and
+    a stream -- of its own.  The protocol needs that independence: rank W-1's successor is rank 0's chunk of the NEXT
+    round, so its sends wait for a receiver that is a whole round behind; if they shared a stream with rank W-1's own
+    receives (one communicator per rank, or with two ranks one per PAIR: 0 -> 1 and 1 -> 0), those receives would queue
+    behind the waiting sends, rank W-2's sends behind them, and the ring would lock up within W-1 blocks.  (torch
+    happens to keep one communicator per pair of ranks for un-batched point-to-point operations, which covers W > 2;
+    the explicit edge groups do not depend on that.)
 
     gloo (the CPU test backend) moves host memory only: device tensors are staged through the host there -- a
     test-only path, it synchronises."""
@@ -122,13 +125,29 @@ class DistTransport:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._gloo = dist.get_backend(group) == "gloo"
-        self._wrap_group = group
-        if not self._gloo and self.world == 2:
-            ranks = None if group is None else dist.get_process_group_ranks(group)
-            self._wrap_group = dist.new_group(ranks)          # collective: every rank of `group` constructs one
+        self._edge = {}
+        if self.world > 1:
+            ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
+            for r in range(self.world):                       # collective: every rank constructs every edge group
+                pair = sorted({ranks[r], ranks[(r + 1) % self.world]})
+                self._edge[r] = dist.new_group(pair, backend=dist.get_backend(group))
+            if not self._gloo:
+                # RCCL creates a communicator at its first use, and that creation blocks the HOST until both ends have
+                # arrived: do it here, edge by edge (an order in which nobody waits for a rank that waits for it),
+                # instead of in the middle of the first blocks
+                tok = torch.zeros(1, device=torch.device("cuda", torch.cuda.current_device()))
+                for r in range(self.world):
+                    nxt = (r + 1) % self.world
+                    if self.rank == r:
+                        dist.send(tok, dst=ranks[nxt], group=self._edge[r])
+                    elif self.rank == nxt:
+                        dist.recv(tok, src=ranks[r], group=self._edge[r])
+                torch.cuda.synchronize()
 
     def _group_for(self, src: int, dst: int):
-        return self._wrap_group if dst < src else self.group
+        if (src + 1) % self.world != dst:
+            raise RuntimeError(f"DistTransport: {src} -> {dst} is not an edge of the ring")
+        return self._edge[src]
 
     def _global(self, r: int) -> int:
         return r if self.group is None else dist.get_global_rank(self.group, r)
@@ -468,11 +487,12 @@ class AnchorExchange:
         pair of ranks, each with its own stream), so a send that has to wait for its receiver -- rank W-1's successor is
         rank 0's chunk of the NEXT round -- never holds up this rank's receive.  (Grouping the two into one
         ncclGroup would couple them and deadlock on exactly that wrap-around.)  Returns the receive handle or None."""
+        # (receive first: were a communicator still to be created at this point, the creation blocks the host until the
+        # peer arrives -- with every rank posting its receive first, the ring unblocks from rank 0 onwards)
+        h = None if recv_spec is None else self.t.irecv(recv_spec[0], recv_spec[1], recv_spec[2], src)
         if send is not None:
             self._send(send, dst, None)
-        if recv_spec is None:
-            return None
-        return self.t.irecv(recv_spec[0], recv_spec[1], recv_spec[2], src)
+        return h
 
     def _send(self, tensor: torch.Tensor, dst: int, st: _BlockState) -> None:
         if dst == self.rank:
