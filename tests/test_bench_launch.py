@@ -63,6 +63,17 @@ def test_bench_two_ranks_one_gpu_gloo(exchange):
 
 
 @pytest.mark.gpu
+def test_bench_four_ranks_one_gpu_gloo():
+    """World size 4 (one process group per directed ring edge, no two-rank special case), neighbour exchange with the
+    early hand-over, the four ranks sharing cuda:0 over gloo."""
+    d = _line(_run(["--gpus", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {"VIDTOME_BENCH_BACKEND": "gloo"},
+                   timeout=1200))
+    assert d["n_gpus"] == 4 and d["ranks"] == 4 and len(d["per_rank_ms_per_step"]) == 4
+    assert d["config"]["exchange"] == "neighbour"
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
 @pytest.mark.parametrize("exchange", ["neighbour", "allgather", "ring"])
 def test_bench_two_ranks_rccl(exchange):

@@ -36,7 +36,7 @@ def test_hot_kernels_keep_their_register_budget(built):
     four waves per SIMD (<= 128 VGPRs, no scratch); the shipped GEMM tiles fit two."""
     from vidtome_amd import build
     res = {}
-    for obj in ("match_filter.o", "attention.o", "linear.o"):
+    for obj in ("match_filter.o", "attention.o", "linear.o", "ff.o"):
         res.update(build.kernel_resources(os.path.join(build.LIBDIR, obj)))
 
     def only(*parts):
@@ -49,6 +49,10 @@ def test_hot_kernels_keep_their_register_budget(built):
         assert v["vgpr_count"] <= 256, (k, v)
     for k, v in only("16attention_kernel", "Li40E").items():      # half and bf16
         assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+    # the panel GEMMs share the filter's hand-issued memory pipeline: no spills of either kind, two workgroups per CU
+    for k, v in only("panel_gemm_kernel").items():
+        assert v["sgpr_spill_count"] == 0 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+        assert v["vgpr_count"] <= 256, (k, v)
     for name in ("linear_rows_kernel", "linear_rows_ws_kernel"):
         for k, v in only(name).items():
             assert v["vgpr_count"] <= 256 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)

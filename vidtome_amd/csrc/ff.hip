@@ -76,6 +76,7 @@ struct Epi {
     const void *resid;     // ROWS: (n, ldo) added to the result, or null
     int64_t n;             // valid token rows
     int64_t N;             // ROWS: valid output channels
+    int64_t nbias;         // entries of `bias` (the last weight tile may reach beyond them)
 };
 
 // Weight-row order of a GEGLU tile (prepared once by the host, vtm_ff_pack_geglu): tile t holds the VALUE rows of output
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(
 #pragma unroll
         for (int k = 0; k < MAX_TILES_PER_WG * FBD / THREADS; ++k) {
             const int i = tid + k * THREADS;
-            if (i < cnt) sBias[i] = bsrc != nullptr ? bsrc[i] : 0.0f;
+            if (i < cnt) sBias[i] = (bsrc != nullptr && (int64_t)jt0 * FBD + i < E.nbias) ? bsrc[i] : 0.0f;
         }
     }
 
@@ -428,7 +429,7 @@ VTM_EXPORT int vtm_ff_geglu(const void *x_panels, int64_t n, int64_t n_pad, cons
     VTM_REQUIRE(n > 0 && n_pad >= n && n_pad % FBS == 0, "vtm_ff_geglu: token rows must be padded to 256");
     VTM_REQUIRE(D > 0 && D % 64 == 0 && w_rows_pad >= 2 * D && w_rows_pad % FBS == 0, "vtm_ff_geglu: D %% 64, packed weight rows padded to 256");
     VTM_REQUIRE(K > 0 && K % FBK == 0, "vtm_ff_geglu: K must be a multiple of 64");
-    Epi E{bias, out_panels, n_pad, 0, nullptr, n, D};
+    Epi E{bias, out_panels, n_pad, 0, nullptr, n, D, 2 * D};
     hipStream_t s = vtm::as_stream(stream);
     if (dtype == VTM_F16) return launch_panel_gemm<__half, EPI_GEGLU>(x_panels, n, n_pad, w1_panels, 2 * D, w_rows_pad, K, E, s);
     if (dtype == VTM_BF16) return launch_panel_gemm<vtm_bf16, EPI_GEGLU>(x_panels, n, n_pad, w1_panels, 2 * D, w_rows_pad, K, E, s);
@@ -444,7 +445,7 @@ VTM_EXPORT int vtm_linear_panels(const void *x_panels, int64_t n, int64_t n_pad,
     VTM_REQUIRE(K > 0 && K % FBK == 0, "vtm_linear_panels: K must be a multiple of 64");
     VTM_REQUIRE(ldo >= N && ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(resid) & 15) == 0, "vtm_linear_panels: output rows must be 16-byte aligned");
-    Epi E{bias, out, 0, ldo, resid, n, N};
+    Epi E{bias, out, 0, ldo, resid, n, N, N};
     hipStream_t s = vtm::as_stream(stream);
     if (dtype == VTM_F16) return launch_panel_gemm<__half, EPI_ROWS>(x_panels, n, n_pad, w_panels, N, w_rows_pad, K, E, s);
     if (dtype == VTM_BF16) return launch_panel_gemm<vtm_bf16, EPI_ROWS>(x_panels, n, n_pad, w_panels, N, w_rows_pad, K, E, s);
