@@ -7,7 +7,13 @@
 
 namespace {
 
-constexpr int WAVES_PER_BLOCK = 4;
+#ifndef VTM_LN_RG
+#define VTM_LN_RG 0         // A/B build switch: rows per wave of the wave-per-row kernel (0 = the shipped 4 / 2 / 2 / 2)
+#endif
+#ifndef VTM_LN_WAVES
+#define VTM_LN_WAVES 4          // (A/B build switch)
+#endif
+constexpr int WAVES_PER_BLOCK = VTM_LN_WAVES;
 constexpr int MAX_CHUNKS = 4;       // 8-channel chunks per lane: C <= 64 * 8 * 4 = 2048
 
 template <typename T, bool NT = false>
@@ -209,13 +215,15 @@ template <typename T>
 void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_t rows, int64_t C, float eps, void *out,
                       int64_t panel_rows, hipStream_t s) {
 #ifndef VTM_OLD_LN   // (A/B build switch)
-    // measured (profiles/r02_sweeps.txt): +24 % HBM rate at C = 320 beyond the Infinity Cache; no gain at 640 / 1280, where a
-    // wave per row already uses all its lanes -- those keep the kernel above
+    // measured (profiles/r02_sweeps.txt): +24 % HBM rate at C = 320 beyond the Infinity Cache
     // input + output beyond the Infinity Cache: streaming loads / stores (common.h)
     const bool nt = 2 * rows * C * (int64_t)sizeof(T) > vtm::STREAM_BYTES;
-    if (C == 320) {
+    // round 3 (one round of rows per wave, profiles/r03_hbm_nt.txt): the lanes-per-row kernel also wins at C = 640 (6.0 vs 4.2
+    // TB/s beyond the Infinity Cache, +6 % at the cfg-2 mid sites) and at C = 1280 for large row counts; the few-thousand-row
+    // C = 1280 sites stay with a wave per row (14.7 vs 16.7 us)
+    if (C == 320 || C == 640 || (C == 1280 && rows >= 32768)) {
 #ifndef VTM_LN_R
-#define VTM_LN_R 2          // rows per lane group in flight (A/B build switch: 3, 4)
+#define VTM_LN_R 1          // rows per lane group in flight (A/B in profiles/r03_hbm_nt.txt: 1 beats 2, 3, 4)
 #endif
         constexpr int R = VTM_LN_R;
         const int lpr = (int)(C / 40);
@@ -223,13 +231,15 @@ void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_
 #define VTM_LNR(LPR, NT_)                                                                                              \
     hipLaunchKernelGGL((layernorm_rows_kernel<T, LPR, R, NT_>), g, b, 0, s, (const T *)x, (const T *)gamma, (const T *)beta, rows, \
                        eps, (T *)out, panel_rows)
-        if (nt) VTM_LNR(8, true); else VTM_LNR(8, false);
+        if (lpr == 8) { if (nt) VTM_LNR(8, true); else VTM_LNR(8, false); }
+        else if (lpr == 16) { if (nt) VTM_LNR(16, true); else VTM_LNR(16, false); }
+        else { if (nt) VTM_LNR(32, true); else VTM_LNR(32, false); }
 #undef VTM_LNR
         return;
     }
 #endif
     const int nch = (int)vtm::cdiv(C, 512);
-    const int R = nch == 1 ? 4 : 2;
+    const int R = VTM_LN_RG ? VTM_LN_RG : (nch == 1 ? 4 : 2);
     const dim3 grid((unsigned)vtm::cdiv(rows, (int64_t)WAVES_PER_BLOCK * R)), block(WAVES_PER_BLOCK * 64);
 #define VTM_LN(NCH, RR)                                                                                               \
     do {                                                                                                              \
@@ -241,10 +251,10 @@ void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_
                                (const T *)beta, rows, (int)C, eps, (T *)out, panel_rows);                              \
     } while (0)
     switch (nch) {
-        case 1: VTM_LN(1, 4); break;
-        case 2: VTM_LN(2, 2); break;
-        case 3: VTM_LN(3, 2); break;
-        default: VTM_LN(4, 2); break;
+        case 1: VTM_LN(1, (VTM_LN_RG ? VTM_LN_RG : 4)); break;
+        case 2: VTM_LN(2, (VTM_LN_RG ? VTM_LN_RG : 2)); break;
+        case 3: VTM_LN(3, (VTM_LN_RG ? VTM_LN_RG : 2)); break;
+        default: VTM_LN(4, (VTM_LN_RG ? VTM_LN_RG : 2)); break;
     }
 #undef VTM_LN
 }
