@@ -170,18 +170,25 @@ struct SplitArgs {   // one operand: gathered rows, their norms (out), the panel
     int64_t n_pad;
 };
 
-constexpr int PREP_PIECES = 10;                        // 16-byte pieces (8 channels) of a row per chunk
+#ifndef VTM_PREP_PIECES
+#define VTM_PREP_PIECES 10      // (A/B build switches; 4 odd multiples keep the LDS rows conflict-free: 2, 6, 10, 14 ...)
+#endif
+#ifndef VTM_PREP_WAVES
+#define VTM_PREP_WAVES 4
+#endif
+constexpr int PREP_WAVES = VTM_PREP_WAVES;
+constexpr int PREP_PIECES = VTM_PREP_PIECES;           // 16-byte pieces (8 channels) of a row per chunk
 constexpr int PREP_STRIDE = PREP_PIECES * 16 + 16;     // bytes per LDS row: 44 words = 4 x odd -> conflict-free b128
 
 template <typename T>
-__global__ __launch_bounds__(256) void prep_operand(const T *__restrict__ x0, int64_t P0,
+__global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restrict__ x0, int64_t P0,
                                                     const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
                                                     SplitArgs A0, SplitArgs A1, int64_t C_pad,
                                                     uint32_t *__restrict__ zero, int64_t zero_words,
                                                     unsigned long long *__restrict__ best, int64_t nbest) {
     static_assert(sizeof(T) == 2 || sizeof(T) == 4, "element size");
     constexpr int EPP = 16 / (int)sizeof(T);           // elements per 16-byte piece (8 for the 16-bit types, 4 for fp32)
-    __shared__ __attribute__((aligned(16))) char slab[4][64 * PREP_STRIDE];
+    __shared__ __attribute__((aligned(16))) char slab[PREP_WAVES][64 * PREP_STRIDE];
     const int64_t G = C_pad / 8;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
     for (int64_t w = gid; w < zero_words; w += gsz) zero[w] = 0u;      // amax, cnt, flags
@@ -1020,7 +1027,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         unsigned long long *bp0 = reinterpret_cast<unsigned long long *>(best);
         uint32_t *zp = reinterpret_cast<uint32_t *>(w + L.amax);
         const int64_t zw = (int64_t)((L.cand - L.amax) / 4);
-        const dim3 grid((unsigned)vtm::cdiv(total, 256)), block(256);
+        const dim3 grid((unsigned)vtm::cdiv(total, 64 * PREP_WAVES)), block(64 * PREP_WAVES);
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(prep_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
