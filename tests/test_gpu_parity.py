@@ -629,10 +629,22 @@ def test_attention_golden_gpu_gather_fed_path(L):
             assert np.abs(yq - y[:, c["rows"], :]).max() < 2e-3 * scale     # same operands, another query tiling
 
 
-@pytest.mark.parametrize("F,N_side,C,heads,coins,proj", [(8, 16, 320, 8, (0.0, 1.0), "auto"), (16, 32, 320, 8, (1.0, 0.0), "auto"),
-                                                        (8, 16, 640, 8, (0.0, 1.0), "auto"), (8, 16, 640, 8, (1.0, 0.0), "rows"),
-                                                        (8, 16, 320, 8, (0.0, 1.0), "panels")])
-def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, F, N_side, C, heads, coins, proj, monkeypatch):
+E2E_CASES = {
+    # name: F, N_side, C, heads, coins, proj, dtype, B, aligned + shared probabilities, ratios, tolerance
+    "c320_d40": (8, 16, 320, 8, (0.0, 1.0), "auto", torch.float16, 2, False, (0.5, 0.5), 1e-3),
+    "c320_d40_f16_n1024": (16, 32, 320, 8, (1.0, 0.0), "auto", torch.float16, 2, False, (0.5, 0.5), 1e-3),
+    "c640_d80_panels": (8, 16, 640, 8, (0.0, 1.0), "auto", torch.float16, 2, False, (0.5, 0.5), 1e-3),
+    "c640_d80_rows": (8, 16, 640, 8, (1.0, 0.0), "rows", torch.float16, 2, False, (0.5, 0.5), 1e-3),
+    "c320_d40_panels": (8, 16, 320, 8, (0.0, 1.0), "panels", torch.float16, 2, False, (0.5, 0.5), 1e-3),
+    "sd21_d64_ratio06": (8, 16, 320, 5, (0.0, 1.0), "auto", torch.float16, 2, False, (0.6, 0.6), 1e-3),        # cfg-5's head dim / ratios
+    "pnp_b3_aligned_shared": (4, 16, 320, 8, (0.0, 1.0), "auto", torch.float16, 3, True, (0.5, 0.5), 1e-3),  # cfg-3
+    "single_frame_chunks": (1, 16, 320, 8, (0.0, 1.0), "auto", torch.float16, 2, False, (0.5, 0.5), 1e-3),   # no local level
+    "bf16": (8, 16, 320, 8, (1.0, 0.0), "auto", torch.bfloat16, 2, False, (0.5, 0.5), 8e-3),                 # bf16: 8 mantissa bits
+}
+
+
+@pytest.mark.parametrize("case", sorted(E2E_CASES))
+def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, case, monkeypatch):
     """What bench.py times, end to end, against the pinned oracle: an fp16 site with the bench's channel counts and head
     dims (C = 320 / d = 40: gather-fed projections + live / compacted queries; C = 640 / d = 80: panel-GEMM projections; and
     each of them forced onto the other path), three
@@ -644,16 +656,20 @@ def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, F, N_side, C, heads,
     import vidtome_amd
     from vidtome_amd import patch as vpatch
     from vidtome_amd import sites
+    F, N_side, C, heads, coins, proj, dtype, B, pnp, ratios, tol = E2E_CASES[case]
     monkeypatch.setattr(vpatch, "PROJ_MODE", proj)            # auto: gather-fed GEMMs at C = 320, panel GEMMs at C = 640
-    B, latent = 2, (N_side, N_side)
+    latent = (N_side, N_side)
     site = sites.Site("s", 1, C, heads)
-    unet = sites.SiteUNet([site], seed=3).to(device=DEV, dtype=torch.float16)
+    unet = sites.SiteUNet([site], seed=3).to(device=DEV, dtype=dtype)
+    if pnp:      # what pnp.register_attention_control + register_time set: shared probabilities at this timestep
+        a_ = unet.blocks[0].attn1
+        a_.injection_schedule, a_.t, a_.vtm_num_inputs = [500], 500, B
     with torch.no_grad():
         unet.blocks[0].norm1.weight.copy_(1.0 + 0.1 * torch.randn(C))
         unet.blocks[0].norm1.bias.copy_(0.1 * torch.randn(C))
         unet.blocks[0].attn1.to_out[0].bias.copy_(0.1 * torch.randn(C))
-    vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B,
-                            global_rand=0.5)
+    vidtome_amd.apply_patch(unet, local_merge_ratio=ratios[0], merge_global=True, global_merge_ratio=ratios[1], batch_size=B,
+                            global_rand=0.5, align_batch=pnp)
     unet.set_size(latent)
     blk = unet.blocks[0]
     torch.manual_seed(123)
@@ -685,11 +701,12 @@ def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, F, N_side, C, heads,
     for ck in range(3):
         if ck > 0:
             unet._tome_info["args"]["global_rand"] = args["global_rand"] = coins[ck - 1]
-        hidden = sites.synthetic_hidden(site, B, F, latent, torch.float16, DEV, seed=50 + ck, clip_seed=7)
+        hidden = sites.synthetic_hidden(site, B, F, latent, dtype, DEV, seed=50 + ck, clip_seed=7)
         with torch.no_grad():
             out = sites.run_segment_pass(unet, [hidden])[0]
         plan, nh = plans[-1], f32(norms[-1])
         m_o, u_o, merged_o, trace = oracle.compute_merge(nh, latent, args, draws, state)
+        assert len(plan.levels) == len(trace["levels"]) == (0 if F == 1 else 2 if F > 4 else 1)
         for lv, rl in zip(plan.levels, trace["levels"]):
             for n in ("unm_idx", "src_idx", "dst_idx"):
                 assert np.array_equal(getattr(lv, n).cpu().numpy(), rl[n]), (ck, n)
@@ -698,12 +715,13 @@ def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, F, N_side, C, heads,
             seen.add(trace["global"]["local_chunk"])
             assert plan.local_chunk == trace["global"]["local_chunk"]
             _tie_aware_equal(plan.global_level, trace["global"]["unm_idx"], trace["global"]["src_idx"],
-                             trace["global"]["dst_idx"], False)
-        assert np.array_equal(f32(blk.global_tokens), state["global_tokens"]), ck      # row copies of the fp16 pool
-        attn_o = oracle.self_attention(merged_o, w["wq"], w["wk"], w["wv"], w["wo"], w["bo"], heads)
+                             trace["global"]["dst_idx"], pnp)
+        assert np.array_equal(f32(blk.global_tokens), state["global_tokens"]), ck      # row copies of the 16-bit pool
+        attn_o = oracle.self_attention(merged_o, w["wq"], w["wk"], w["wv"], w["wo"], w["bo"], heads,
+                                       share_groups=B if pnp else 1)
         ref = u_o(attn_o) + f32(hidden)
         err = np.abs(f32(out) - ref).max()
-        assert err < 1e-3 * max(1.0, np.abs(ref).max()), (ck, err)
+        assert err < tol * max(1.0, np.abs(ref).max()), (ck, err)
     assert seen == {0, 1}
     vidtome_amd.remove_patch(unet)
 
@@ -938,6 +956,39 @@ def test_cross_attention_panels_vs_torch_fp32(L, B, N, Mk, C, heads):
         assert vpatch.fused_cross_ok(nd, ad, hd, ed, None, {})
         y = vpatch.norm_cross_attention_residual(nd, ad, hd, ed).float().cpu()
     assert (y - ref).abs().max() < 3e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_full_block_forward_panels_equals_library_path(L, monkeypatch):
+    """The WHOLE patched block (ToMeBlock.forward: segment, norm2 / attn2 over 77 conditioning tokens, norm3 / GEGLU
+    feed-forward; patch.py:128-201) at a merged top site, a merged mid site and an un-merged site: the panel-GEMM path
+    (default) against the library-GEMM path of rounds 1-2 (VIDTOME_FF=blas, VIDTOME_PROJ=blas) over two chunks -- same merge
+    plan, outputs within the fp16 tolerance of the two paths' own tests."""
+    import vidtome_amd
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import sites
+    sl = [sites.Site("top", 1, 320, 8), sites.Site("mid", 2, 640, 8), sites.Site("low", 4, 1280, 8)]
+    B, F, latent = 2, 4, (16, 16)
+    cond = torch.randn(B * F, 77, 768, generator=torch.Generator().manual_seed(3)).half().to(DEV)
+    outs = {}
+    for mode in ("panels", "blas"):
+        monkeypatch.setattr(vpatch, "FF_MODE", mode)
+        monkeypatch.setattr(vpatch, "PROJ_MODE", "auto" if mode == "panels" else "blas")
+        monkeypatch.setattr(vpatch, "FUSED_PROJ", mode == "panels")
+        unet = sites.SiteUNet(sl, seed=0, full=True).to(device=DEV, dtype=torch.float16)
+        vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B)
+        unet.set_size(latent)
+        torch.manual_seed(123)
+        res = []
+        with torch.no_grad():
+            for ck in range(2):
+                hs = [sites.synthetic_hidden(s_, B, F, latent, torch.float16, DEV, seed=20 * ck + i) for i, s_ in enumerate(sl)]
+                res.append([o.float() for o in sites.run_block_pass(unet, hs, cond)])
+        outs[mode] = res
+        vidtome_amd.remove_patch(unet)
+    for a, b in zip(outs["panels"], outs["blas"]):
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.isfinite(x).all()
+            assert (x - y).abs().max().item() < 6e-3 * max(1.0, y.abs().max().item())
 
 
 def test_attention_fuzz_vs_torch_fp32(L):
