@@ -61,6 +61,9 @@ LOCAL = [
     # cfg-5 (SD-2.1-768, 16 x 9 216 tokens, ratio 0.6): the largest level of any BASELINE configuration, one sample
     # (110 592 x 36 864 scores = 16.3 GB in fp32: no fp64 run)
     ("local_cfg5_l1_110592x36864_c320", 1, 16, 9216, 0, 320, 0.6, False, 16, False),
+    # cfg-3 (PnP: batch 3, aligned matching) at the full top-block level-1 size: ONE matching over the three samples'
+    # concatenated scores (49 152 x 3 * 16 384)
+    ("local_cfg3_l1_aligned_b3_49152x16384_c320", 3, 16, 4096, 0, 320, 0.5, True, 17, False),
 ]
 GLOBAL = [
     # name, B, src_len, dst_len, C, ratio, align, unmerge_chunk, seed, check in fp64

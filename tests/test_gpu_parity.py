@@ -412,8 +412,8 @@ def test_planted_mid_and_full_size_golden_gpu(L, mode, monkeypatch):
     monkeypatch.setattr(merge, "MATCH_MODE", mode)
     for c in load_cases("planted_mid.npz"):
         name = str(c["name"])
-        if mode == "exact" and "cfg5" in name:
-            continue                                    # 2.6 TFLOP each on the fp32 MFMA: covered by the filtered run
+        if mode == "exact" and ("cfg5" in name or "cfg3" in name):
+            continue                                    # 1.5-2.6 TFLOP each on the fp32 MFMA: covered by the filtered run
         if str(c["kind"]) == "local":
             x = planted_local_chunk(int(c["B"]), int(c["F"]), int(c["tnum"]), int(c["unm_pre"]), int(c["C"]),
                                     int(c["randf"]), int(c["seed"]))

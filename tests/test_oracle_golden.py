@@ -305,8 +305,8 @@ def test_planted_mid_and_full_size_golden(oracle, which):
         group = "local" if kind == "local" else ("global_full" if int(c["src_len"]) > 10000 else "global_mid")
         if group != which:
             continue
-        if "cfg5" in name:
-            continue        # 2.6 TFLOP each on the host cores: the cfg-5 full-size cases are checked on the GPU (-m gpu), where
+        if "cfg5" in name or "cfg3" in name:
+            continue        # 1.5-2.6 TFLOP each on the host cores: these full-size cases are checked on the GPU (-m gpu), where
                             # the HIP path reproduces the reference's hashes directly
         ran += 1
         x = _planted_mid_inputs(c)
