@@ -192,12 +192,19 @@ def main():
                                 align_batch=align)
         unet.set_size(latent)
         torch.manual_seed(123)
-        hs = [sites.synthetic_hidden(s_, Bc, Fc, latent, torch.float16, dev, seed=1234 + i) for i, s_ in enumerate(sl)]
-        with torch.no_grad():
-            sites.run_segment_pass(unet, hs)
-            med, best = timeit(lambda: sites.run_segment_pass(unet, hs), a.iters)
+        # bench.py's regime: 3 chunks of one clip rotate, anchor chain re-seeded like a step of 8 chunks (sites.ClipStream)
+        stream = sites.ClipStream(unet, sl, Bc, Fc, latent, torch.float16, dev)
+        stream.populate()
+        chunk = [0]
+
+        def one_pass():
+            stream.step(chunk[0])
+            chunk[0] += 1
+        for _ in range(2):
+            one_pass()
+        med, best = timeit(one_pass, max(a.iters, 7))
         print(f"sites {a.shape}: B={Bc} F={Fc} latent={latent} local={lr} global={gr} align={align}: median {med:.2f} ms per "
-              f"chunk-step ({1e3 / med:.2f} steps/s), best {best:.2f} ms")
+              f"chunk-step ({1e3 / med:.2f} steps/s), best {best:.2f} ms  [3 rotating chunks, 7-update anchor chain]")
     else:
         raise SystemExit("unknown benchmark")
 
