@@ -198,6 +198,27 @@ def test_four_rank_exchange_gloo(oracle, mode):
         assert ok, f"rank {rank} failed: {err}"
 
 
+def _worker8(rank, world, port, mode, q):
+    STEPS[mode] = [[3, 6, 4, 1, 4, 2, 5, 4, 3, 2], [2, 4, 4]]
+    _worker(rank, world, port, mode, q, True)
+
+
+def test_eight_rank_neighbour_gloo(oracle):
+    """The world size of the driver's scaling run (8 ranks, bench.py's default exchange with the early hand-over): a
+    10-chunk step (two rounds, the second partial) and a 3-chunk step (five ranks idle)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, "neighbour", q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in results:
+        assert ok, f"rank {rank} failed: {err}"
+
+
 @pytest.mark.parametrize("W", [1, 3])
 def test_fake_ranks_in_process(oracle, W):
     """the single-process N-fake-rank replay -- W exchange endpoints on an in-memory transport,
