@@ -51,7 +51,7 @@ COMPACT_QUERIES = os.environ.get("VIDTOME_COMPACT_QUERIES", "1") != "0"
 class MergePlan:
     """What ``compute_merge`` produces for one block call: composed maps + the merged tokens."""
 
-    __slots__ = ("fsize", "L", "M", "gather_map", "inv", "_merged", "levels", "global_level", "local_chunk",
+    __slots__ = ("fsize", "L", "M", "gather_map", "_inv", "_inv_parts", "_merged", "levels", "global_level", "local_chunk",
                  "x_joined", "anchors_in", "q_rows", "inv_q", "q_count", "pad_to")
 
     def __init__(self):
@@ -59,7 +59,8 @@ class MergePlan:
         self.global_level = None
         self.local_chunk = None
         self.gather_map = None
-        self.inv = None
+        self._inv = None
+        self._inv_parts = None          # (local-levels inverse map, local position -> merged position): composed on demand
         self.anchors_in = None
         # Global level only: the rows of the merged sequence whose attention output unmerge() ever reads
         # (q_rows[b, t] = merged row of local token t) and the local-levels-only inverse map.  The merged
@@ -74,6 +75,16 @@ class MergePlan:
         self.q_count = None
         self._merged = None
         self.pad_to = 8
+
+    @property
+    def inv(self) -> Optional[torch.Tensor]:
+        """The composed unmerge map of ALL levels (B, L): merged row every position of the joined chunk is restored from.
+        With a global level the patched block unmerges through `inv_q` (the rows its live queries produce) and never needs
+        this map, so it is composed on first use (API users, tests, VIDTOME_LIVE_QUERIES=0)."""
+        if self._inv is None and self._inv_parts is not None:
+            inv_local, loc = self._inv_parts
+            self._inv = _lib.compose(inv_local, loc, self.L) if inv_local is not None else loc
+        return self._inv
 
     @property
     def merged(self) -> torch.Tensor:
@@ -173,12 +184,12 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                     plan.inv_q = _lib.compose(inv, tmap, L) if inv is not None else tmap
                 else:
                     plan.q_rows, plan.inv_q = loc, inv
-                inv = _lib.compose(inv, loc, L) if inv is not None else loc
+                plan._inv_parts, inv = (inv, loc), None      # composed lazily (MergePlan.inv)
                 cur = gl.new_cur
                 n_cur = cur.shape[1]
 
         plan.M = n_cur
-        plan.gather_map, plan.inv, plan.pad_to = cur, inv, pad_to
+        plan.gather_map, plan._inv, plan.pad_to = cur, inv, pad_to
         merged = plan.merged if (materialize or cur is None) else None             # cur None: F == 1, a view
         if args["merge_global"]:
             if anchors_out is not None:
