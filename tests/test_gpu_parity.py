@@ -960,6 +960,46 @@ def test_cross_attention_panels_vs_torch_fp32(L, B, N, Mk, C, heads):
     assert (y - ref).abs().max() < 3e-3 * max(1.0, float(ref.abs().max()))
 
 
+def test_panel_gemm_fuzz_vs_torch_fp32(L):
+    """vtm_linear_panels / vtm_ff_geglu on random shapes (token counts around the 256-row tile edges, K = 64 ... 1280, output
+    widths with ragged last 128-row weight tiles, with / without bias and residual, row-range operands) against fp32 PyTorch
+    on the same fp16 operands."""
+    g = torch.Generator().manual_seed(11)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for trial in range(24):
+        n = [1, 255, 256, 257, 511, 1000, 4097][ri(0, 6)] if trial % 2 else ri(1, 3000)
+        K = 64 * ri(1, 20)
+        N = 8 * ri(1, 80)
+        x = torch.randn(n, K, generator=g).half()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).half()
+        bias = (0.1 * torch.randn(N, generator=g)).float() if ri(0, 1) else None
+        resid = torch.randn(n, N, generator=g).half() if ri(0, 1) else None
+        ref = x.float() @ w.float().t() + (bias if bias is not None else 0.0)
+        ref = ref.half().float() + (resid.float() if resid is not None else 0.0)       # torch rounds the Linear output first
+        xp, wp = L.to_panels(x.to(DEV)), L.to_panels(w.to(DEV))
+        y = L.linear_panels(xp, n, wp, N, None if bias is None else bias.to(DEV), None if resid is None else resid.to(DEV))
+        assert y.shape == (n, N)
+        assert (y.float().cpu() - ref).abs().max() < 3e-3 * max(1.0, float(ref.abs().max())), (trial, n, K, N)
+        # the same product with the operand roles swapped (how V^T = W_v X^T is computed): (N, n_pad8) = w x^T
+        n8 = (n + 7) // 8 * 8
+        yt = torch.zeros((N, L.panel_rows(n)), dtype=torch.float16, device=DEV)
+        L.linear_panels(wp, N, xp, n8, None, out=yt)
+        assert (yt[:, :n].float().cpu() - (x.float() @ w.float().t()).t()).abs().max() < 3e-3 * max(1.0, float(ref.abs().max()))
+    for trial in range(8):                                   # GEGLU epilogue: D % 64 == 0
+        n, K, D = ri(1, 2000), 64 * ri(1, 20), 64 * ri(1, 12)
+        x = torch.randn(n, K, generator=g).half()
+        w = (torch.randn(2 * D, K, generator=g) * K ** -0.5).half()
+        b = (0.1 * torch.randn(2 * D, generator=g)).float()
+        t = torch.arange(D // 64)[:, None] * 64 + torch.arange(64)[None, :]
+        order = torch.cat([t, t + D], dim=1).reshape(-1).to(torch.int32)
+        wp = L.to_panels(w.to(DEV), order.to(DEV))
+        hp = L.ff_geglu(L.to_panels(x.to(DEV)), n, wp, D, b[order.long()].to(DEV))
+        got = hp[:, :n].permute(1, 0, 2).reshape(n, D).float().cpu()
+        proj = (x.float() @ w.float().t() + b).half().float()
+        ref = proj[:, :D] * torch.nn.functional.gelu(proj[:, D:]).half().float()
+        assert (got - ref).abs().max() < 3e-3 * max(1.0, float(ref.abs().max())), (trial, n, K, D)
+
+
 def test_full_block_forward_panels_equals_library_path(L, monkeypatch):
     """The WHOLE patched block (ToMeBlock.forward: segment, norm2 / attn2 over 77 conditioning tokens, norm3 / GEGLU
     feed-forward; patch.py:128-201) at a merged top site, a merged mid site and an un-merged site: the panel-GEMM path
