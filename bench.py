@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--chunks-per-step", type=int, default=8,
                     help="N = 1: chunks of a denoising step -- the anchor chain is re-seeded every chunks_per_step - 1 "
                          "passes with the first chunk's local tokens (the reference resets the anchors after every step)")
+    ap.add_argument("--frames", type=int, default=FRAMES,
+                    help="frames per chunk (16 = the headline cfg-2 chunk; 8 = one of cfg-4's eight chunks -- not the headline)")
     ap.add_argument("--full-block", action="store_true",
                     help="secondary measurement (NOT the headline): every pass runs the WHOLE patched block at the 16 sites -- "
                          "the hot-path segment plus the cross-attention over 77 text tokens and the GEGLU feed-forward "
@@ -412,9 +414,11 @@ def cpu_baseline_torch(budget_s: float):
 
 
 def main():
+    global FRAMES
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    FRAMES = args.frames
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -566,7 +570,9 @@ def main():
                      "with f32 accumulate" if filtered else
                      "f16 tokens; matching f32 MFMA (exact); attention f16 MFMA with f32 accumulate",
             "data": "synthetic",
-            "config": {"workload": "SD-1.5 16 frames 512x512 (cfg-2): hot-path pass over the 16 transformer-block "
+            "config": {"workload": ("SD-1.5 16 frames 512x512 (cfg-2)" if FRAMES == 16 else
+                                    f"SD-1.5 {FRAMES}-frame chunk 512x512 (NOT the headline chunk size)") +
+                                   ": hot-path pass over the 16 transformer-block "
                                    "sites, batch 2 (CFG), local merge 0.5" +
                                    ("" if args.local_only else " + global merge 0.5 (steady state)"),
                        "regime": ("same chunk fed to every pass (anchors = copies of its own rows; rounds 1-2)"
