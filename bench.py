@@ -88,6 +88,13 @@ def parse():
                          "(patch.py:171-199)")
     ap.add_argument("--same-chunk", action="store_true",
                     help="rounds 1-2's regime: every pass processes the same chunk (anchors = copies of its own rows)")
+    ap.add_argument("--data", default="corr05", choices=["n01", "corr01", "corr05", "flat25", "dup"],
+                    help="synthetic token regime (vidtome_amd/sites.DATA_REGIMES): n01 = N(0,1) and corr01 = base + 0.1 N(0,1) "
+                         "are the two SURVEY.md 8d names; corr05 = base + 0.5 N(0,1) (default: what rounds 1-3 measured); "
+                         "flat25 / dup load the matcher's candidate logic (profiles/r04_data_regimes.txt)")
+    ap.add_argument("--watchdog-seconds", type=float, default=120.0,
+                    help="N > 1: a rank that makes no progress for this long prints where it is stuck (pass, block, exchange "
+                         "phase, peer) and exits with code 3 (0 = off)")
     ap.add_argument("--event-every", type=int, default=5,
                     help="record HIP events around the hot launches on every k-th timed pass (the others are event-free)")
     return ap.parse_args()
@@ -184,6 +191,35 @@ class BoxSampler(threading.Thread):
         return out
 
 
+class Watchdog(threading.Thread):
+    """N > 1: a rank stuck in a collective / point-to-point transfer would otherwise burn the driver's whole timeout
+    without a word.  The main thread ticks after every pass; when nothing has ticked for `limit_s` the watchdog prints
+    where the rank is (pass, and the exchange's last bookkeeping entry: block key, phase, peer rank) and ends the process
+    with code 3 -- the launcher (self_launch / torchrun) then takes the other ranks down."""
+
+    def __init__(self, rank: int, limit_s: float, where):
+        super().__init__(daemon=True)
+        self.rank, self.limit, self.where = rank, limit_s, where
+        self.last = time.monotonic()
+        self.label = "start-up"
+        self._halt = threading.Event()
+
+    def tick(self, label: str) -> None:
+        self.last, self.label = time.monotonic(), label
+
+    def run(self):
+        while not self._halt.wait(1.0):
+            idle = time.monotonic() - self.last
+            if idle > self.limit:
+                sys.stderr.write(f"bench.py watchdog: rank {self.rank} made no progress for {idle:.0f} s after '{self.label}'; "
+                                 f"exchange state: {self.where()}\n")
+                sys.stderr.flush()
+                os._exit(3)
+
+    def stop(self):
+        self._halt.set()
+
+
 class KernelTimer:
     """HIP events around the hot kernels' launches, recorded on the launch stream (torch's current stream):
     `attention` = vtm_attention (one kernel), `matching` = vtm_match_filtered / vtm_match (the fused
@@ -234,6 +270,18 @@ class KernelTimer:
         # match_filtered(x0, x1, a_rows, b_rows, align): 2 * B * Ns * Nd * C algorithmic flops
         self._wrap("match_filtered", "matching",
                    lambda x0, x1, ar, br, align, want_flag=False: 2.0 * x0.shape[0] * ar.shape[1] * br.shape[1] * x0.shape[2])
+        # on the event passes the matcher also hands back its device-side counters (refined pairs, escaped rows): read
+        # AFTER the timed region
+        timed_match = self.lib_mod.match_filtered
+        self.match_flags = []
+
+        def match_with_counters(x0, x1, ar, br, align, want_flag=False):
+            if not self.enabled or want_flag:
+                return timed_match(x0, x1, ar, br, align, want_flag)
+            best, flag = timed_match(x0, x1, ar, br, align, True)
+            self.match_flags.append((flag, ar.shape[1] if align else x0.shape[0] * ar.shape[1]))
+            return best
+        self.lib_mod.match_filtered = match_with_counters
         self._wrap("match", "matching", lambda a, b, Ns, Nd, align: 2.0 * a.shape[0] * Ns * Nd * a.shape[1] * 8)
         # the HBM-bound kernels: algorithmic BYTES per call (rows read + rows written, indices ignored)
         esz = lambda t: t.element_size()
@@ -250,6 +298,13 @@ class KernelTimer:
         self._wrap("layernorm_panels", "layernorm_panels", lambda x, w, b, eps: 2.0 * x.numel() * esz(x))
         self._wrap("unmerge_add", "unmerge_add",
                    lambda y, inv, resid: (2.0 + (resid is not None)) * inv.numel() * y.shape[2] * esz(y))
+        # everything else the path launches (index algebra, sort, panel writers, query compaction): time only, so that the
+        # components of the line add up to the step
+        for name in ("sort_desc", "partition_local", "partition_global", "plan_apply", "compose", "decode_best",
+                     "compact_queries", "to_panels", "gather_panels", "geglu", "normalize_gather"):
+            if hasattr(self.lib_mod, name):
+                self.records[name] = []
+                self._wrap(name, name, lambda *a, **k: 0.0)
         return self
 
     def __exit__(self, *exc):
@@ -266,6 +321,21 @@ class KernelTimer:
         flops = sum(r[0] for r in rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in rec)
         return flops, ms, len(rec)
+
+    def match_counters(self):
+        """(refined pairs per src row, escaped rows, whole-call escapes, src rows) over the event passes."""
+        if not getattr(self, "match_flags", None):
+            return None
+        f = torch.stack([fl for fl, _ in self.match_flags]).cpu().long()
+        rows = sum(r for _, r in self.match_flags)
+        return {"refined_pairs_per_src_row": round(float(f[:, 3].sum()) / rows, 3),
+                "escaped_rows": int(f[:, 2].sum()), "escaped_row_fraction": round(float(f[:, 2].sum()) / rows, 5),
+                "whole_call_escapes": int(f[:, 0].sum()), "calls": len(self.match_flags)}
+
+    def ms_by_kind(self):
+        """{kind: total HIP-event ms} of every wrapped launch kind that ran."""
+        self._resolve()
+        return {k: sum(r[1].elapsed_time(r[2]) for r in rec) for k, rec in self.records.items() if rec}
 
     def largest(self, kind):
         """(flops, average ms, count) of the launches with the most work -- the top-block launches, whose average
@@ -458,8 +528,6 @@ def main():
         # previous rank's chunk over RCCL / xGMI (chunk_parallel.py).  The whole run is ONE stream of chunks
         # (chunk index = pass * world + rank), so the exchange knows which chunk is the last and leaves no send unmatched.
         from vidtome_amd import chunk_parallel as cp
-        if world == 1 and mode == "allgather":
-            raise SystemExit("bench.py: --exchange allgather needs N > 1 (a collective); use neighbour (same semantics)")
         ex = cp.AnchorExchange(mode, transport=None if world > 1 else cp.LocalTransport.fabric(1)[0])
         cp.enable(unet, ex)
         ex.begin_step([FRAMES] * (total_passes * world))
@@ -473,15 +541,21 @@ def main():
     K = 1 if args.same_chunk else max(2, args.chunks)
     stream = sites.ClipStream(unet, site_list, BATCH, FRAMES, LATENT, torch.float16, dev, n_sets=args.chunks,
                               chunks_per_step=args.chunks_per_step, same_chunk=args.same_chunk, rank=rank,
-                              reseed=ex is None,
+                              reseed=ex is None, regime=args.data,
                               sets=None if ex is None else {(p_ * world + rank) % K for p_ in range(total_passes)},
                               cond=(torch.randn(BATCH * FRAMES, 77, 768, generator=torch.Generator().manual_seed(77))
                                     .to(device=dev, dtype=torch.float16) if args.full_block else None))
     passes = [0]
+    dog = None
+    if world > 1 and args.watchdog_seconds > 0:
+        dog = Watchdog(rank, args.watchdog_seconds, (lambda: ex.where) if ex is not None else (lambda: "no exchange"))
+        dog.start()
 
     def step():
         c = passes[0] * world + rank
         passes[0] += 1
+        if dog is not None:
+            dog.tick(f"pass {passes[0] - 1} started (chunk {c})")
         if ex is None:
             return stream.step(c)
         ex.begin_chunk(c)
@@ -514,6 +588,8 @@ def main():
         fence()
         dt = time.perf_counter() - t0
     box = sampler.stop() if sampler is not None else None
+    if dog is not None:
+        dog.tick("timed region done")
     if ex is not None:
         ex.end_step()
     # (gloo -- the test hook -- moves host tensors)
@@ -545,6 +621,23 @@ def main():
             return {"launches": n, "ms_per_step": round(ms / timed_passes, 3), "GBps": rate(by, ms),
                     "largest": {"launches": tn, "MB": round(tb_ / 1e6, 1), "avg_us": round(tms * 1e3, 1),
                                 "GBps": rate(tb_, tms), "frac_of_hbm_peak": round(rate(tb_, tms) / HBM_PEAK_GBPS, 3)}}
+
+        # the clock the chip actually sustained in THIS run (sysfs samples during the timed region): the MFMA roof scales
+        # with it -- 2.5 PFLOP/s is the dense fp16 peak at the nominal 2.4 GHz
+        sclk = (box or {}).get("sclk_mhz", {}).get("mean")
+        watts = (box or {}).get("power_w", {}).get("mean")
+        roof_at_clock = FP16_PEAK_TFLOPS * sclk / 2400.0 if sclk else None
+        if sclk and watts:
+            box_note = (f"this run: package power {watts:.0f} W mean, shader clock {sclk / 1e3:.2f} GHz mean over the timed region "
+                        f"(bench.box) -- the fp16 MFMA roof at that clock is {roof_at_clock:.0f} TFLOP/s; with non-toggling "
+                        f"operands the same launch reaches 1 130-1 166 TFLOP/s at 2.4 GHz = the floor of its instruction mix "
+                        f"(profiles/r02_ubench.txt, DESIGN.md section 10)")
+        else:
+            box_note = "no clock / power sample available on this box (sysfs hwmon not readable)"
+        # every launch kind of the path, HIP-event time per step on the event passes; what is left of the step is dispatch
+        # gaps and host time
+        comp = {k: round(v / timed_passes, 3) for k, v in sorted(mt.ms_by_kind().items(), key=lambda kv: -kv[1])}
+        comp_sum = sum(comp.values())
 
         par = f"chunk-parallel x{world}"
         if ex is not None:
@@ -583,12 +676,21 @@ def main():
                                    f"chunk's local tokens like a denoising step of {args.chunks_per_step} chunks "
                                    f"(generate.py:233-236)" if ex is None else
                                    "anchors as the exchange mode defines them")),
+                       "data_regime": args.data + ": " + {
+                           "n01": "h ~ N(0,1), frames uncorrelated (SURVEY 8d)",
+                           "corr01": "h[f] = base + 0.1 N(0,1) (SURVEY 8d: realistic cross-frame cosine)",
+                           "corr05": "h[f] = base + 0.5 N(0,1) (rounds 1-3)",
+                           "flat25": "corr05 + a flat region over a quarter of every frame (candidate-list overflow -> exact escape)",
+                           "dup": "corr05 + a fifth of the positions exact copies of others"}[args.data],
                        "full_block": bool(args.full_block),
                        "sites": 16, "merged_sites": 10, "chunk_frames": FRAMES, "batch": BATCH,
                        "matcher": _merge.MATCH_MODE + (" (fp16-MFMA filter, fp32 refine; global-level index order inside "
                                                        "groups of EXACTLY equal similarity is the stable one, the "
                                                        "reference's is implementation-defined)" if filtered else ""),
-                       "parallelism": par, "exchange": mode if ex is not None else None},
+                       "parallelism": par, "exchange": mode if ex is not None else None,
+                       "exchange_bytes_per_step": None if ex is None else
+                       {"sent": int(ex.bytes_sent / max(1, total_passes)), "received": int(ex.bytes_received / max(1, total_passes)),
+                        "note": "this rank, averaged over all passes (N = 1: handed over in place, nothing crosses a link)"}},
             # dominant single kernel of the step: the merged-token self-attention (MFMA-bound)
             # `achieved` counts EXECUTED flops (4 B Mq Mk C per launch): with a global level the block only computes the
             # attention rows unmerge() reads, so the reference-algorithmic 4 B M^2 C would overstate the kernel
@@ -606,9 +708,9 @@ def main():
                          # live / distinct Mq x M): the same time expressed in those flops
                          "reference_equivalent_tflops": round(mt.ref_flops / (ams * 1e-3) / 1e12, 1) if ams > 0 else 0.0,
                          "event_passes": timed_passes,
-                         "note": "power-limited: with these (random) operand values the kernel runs at the 1400 W package cap, "
-                                 "sclk ~1.95 GHz; the same launch with non-toggling operands reaches 1 130-1 166 TFLOP/s = the floor "
-                                 "of its instruction mix (profiles/r02_ubench.txt, DESIGN.md section 10)"},
+                         "sustained_sclk_mhz": sclk,
+                         "frac_at_sustained_clock": round(att_tf / roof_at_clock, 4) if roof_at_clock else None,
+                         "note": box_note},
             # the fused similarity + top-1 step (second largest).  The filtered matcher executes the reference's
             # 2 B Ns Nd C flops ONCE on the fp16 MFMA (one-product filter) and re-evaluates the few surviving pairs in
             # fp32: its roof is the fp16 MFMA peak.  The exact fallback kernel runs on the fp32 MFMA (157.3 TFLOP/s).
@@ -617,7 +719,10 @@ def main():
                          "executed_tflops": round(mat_tf, 1),
                          "peak": FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS,
                          "frac": round(mat_tf / (FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS), 4),
-                         "calls": mn, "matching_ms_per_step": round(mms / timed_passes, 3)},
+                         "calls": mn, "matching_ms_per_step": round(mms / timed_passes, 3),
+                         # device-side counters of the event passes: pairs the exact refine pass evaluated per src row,
+                         # rows whose candidate list overflowed (exact_rows_kernel), calls recomputed as a whole
+                         "counters": mt.match_counters() if filtered else None},
             # the HBM-bound kernels of the path: algorithmic bytes (rows read + rows written) / HIP-event time.  The
             # cfg-2 working sets (<= 212 MB) fit the 256 MB Infinity Cache, so `pmc` carries the counter-derived rates
             # measured beyond it
@@ -626,6 +731,14 @@ def main():
                                               "ms_per_step": round(ms / timed_passes, 3),
                                               "tflops": round(f / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0})(
                 *mt.summary("projections")),
+            # EVERY launch kind of the pass (vidtome_amd._lib entry points), HIP-event ms per step on the event passes; the
+            # panel-GEMM projections of the C >= 640 / un-merged sites are `linear_panels` + their panel writers
+            "components_ms_per_step": comp,
+            "components_sum_ms": round(comp_sum, 3),
+            "unaccounted_ms_per_step": round(ms_per_step - comp_sum, 3),
+            "timing": f"value = {args.steps} passes / wall time between two fences (barrier + synchronize; perf_counter), "
+                      f"i.e. the MEAN pass; kernel figures = HIP events on every {every}-th pass "
+                      f"({timed_passes} event passes)",
             "gather_path": {"hbm_peak_GBps": HBM_PEAK_GBPS, "layernorm": hbm("layernorm"),
                             "gather_rows": hbm("gather_rows"), "unmerge_add": hbm("unmerge_add"),
                             "pmc": pmc_gather_path()},
@@ -649,6 +762,8 @@ def main():
             line["cpu_baseline"] = (cpu_baseline_torch if args.cpu_baseline == "torch" else cpu_baseline_port)(
                 args.cpu_seconds)
         print(json.dumps(line), flush=True)
+    if dog is not None:
+        dog.stop()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

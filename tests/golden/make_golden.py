@@ -348,7 +348,9 @@ class StandInUNet(ModelMixin):
             # i.i.d. Gaussian token directions mixed with a little latent content: cosines are well spread,
             # which keeps the case separable from rounding noise (see MARGIN)
             hidden = self.mix(torch.tanh(2.0 * self.embed(tok) + 0.3 * bi)) * 0.25 + \
-                torch.randn(tok.shape[0], tok.shape[1], self.C, generator=self.gen).to(tok.dtype)
+                getattr(self, "hidden_noise", 1.0) * torch.randn(tok.shape[0], tok.shape[1], self.C, generator=self.gen).to(tok.dtype)
+            if getattr(self, "fp16_grid", False):     # make_golden_chain16.py: hidden states an fp16 model can hold exactly
+                hidden = hidden.half().to(tok.dtype)
             out = blk(hidden, encoder_hidden_states=encoder_hidden_states)
             self.records.append({"block": bi, "ds": ds, "hidden": hidden.clone(), "out": out.clone()})
             outs.append(out)
@@ -368,7 +370,33 @@ def run_chain(dtype, cfg, weights_seed):
     unet = StandInUNet(C, heads)
     for p in unet.parameters():     # drawn in fp32 so the fp64 screening run sees the same weights
         p.copy_(torch.randn_like(p) * (0.5 if p.ndim == 1 else p.shape[-1] ** -0.5))
+    if cfg.get("fp16_grid"):
+        # make_golden_chain16.py: weights and hidden states on the fp16 grid (an fp16 model holds them exactly; the
+        # reference still computes in `dtype`), positions of one clip correlated across frames
+        for p in unet.parameters():
+            p.copy_(p.half().float())
+        unet.fp16_grid = True
+        unet.hidden_noise = cfg.get("hidden_noise", 1.0)
     unet = unet.to(dtype)
+    if cfg.get("round_norm1"):
+        # make_golden_chain16.py: the model an fp16 run holds -- norm1's output on the fp16 grid (what the matcher and the
+        # attention of an fp16 model see).  An integer > 1 additionally moves a random 2e-4 of the elements by one fp16
+        # ulp (screening: another correctly-implemented fp16 LayerNorm may round that many elements the other way)
+        class RoundedNorm(torch.nn.Module):
+            def __init__(self, inner, seed):
+                super().__init__()
+                self.inner = inner
+                self.gen = torch.Generator().manual_seed(seed) if seed > 1 else None
+
+            def forward(self, x):
+                y = self.inner(x).half()
+                if self.gen is not None:
+                    hit = torch.rand(y.shape, generator=self.gen) < 2e-4
+                    step = torch.where(torch.rand(y.shape, generator=self.gen) < 0.5, 1, -1).to(torch.int16)
+                    y = torch.where(hit, (y.view(torch.int16) + step).view(torch.float16), y)
+                return y.to(x.dtype)
+        for bi, (_, blk) in enumerate(unet.blocks()):
+            blk.norm1 = RoundedNorm(blk.norm1, int(cfg["round_norm1"]) * 100 + bi if int(cfg["round_norm1"]) > 1 else 1)
     pipe = Pipe(unet)
     # PnP attention override: the reference's own attention arithmetic (pnp_utils.py:39-106)
     ref_pnp.register_attention_control(pipe, cfg["injection"], cfg["B"])
@@ -442,7 +470,7 @@ def run_chain(dtype, cfg, weights_seed):
     finally:
         ref_merge.bipartite_soft_matching_randframe = orig_rf
         ref_merge.bipartite_soft_matching_2s = orig_2s
-    weights = {n: p.detach().clone() for n, p in unet.state_dict().items()}
+    weights = {n.replace("norm1.inner.", "norm1."): p.detach().clone() for n, p in unet.state_dict().items()}
     return chunks, weights, names, rng_state
 
 

@@ -2,7 +2,12 @@
 """Mid- and full-size matcher fixtures from the REFERENCE (vidtome/merge.py), stored as sha256 of the index arrays ->
 tests/golden/planted_mid.npz.  Run in the build container only (imports /root/reference):
 
-    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_mid.py
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_mid.py [--set cfg14]
+
+`--set cfg14` (round 4) writes tests/golden/planted_cfg14.npz instead: the EXACT level shapes of BASELINE.json's cfg-1
+(4 frames 256 x 256, local merging only: 3 072 x 1 024 x 320 at the top blocks, 768 x 256 x 640 at the mid blocks) and of one
+of cfg-4's eight 8-frame chunks (level 1: 24 576 x 8 192 x 320, level 2 with the carried-over unmerged tokens: 4 096 x
+16 384, global level 18 432^2; mid blocks 6 144 x 2 048 x 640 and 4 608^2), same format.
 
 Round 1's fixtures stop at 64 tokens per frame / C <= 40 (and ONE full-size case, the planted cfg-2 local level 1).  These
 cover the sizes where the 128 x 256 tiles of the HIP matcher are fully populated, for the LOCAL matcher with and without
@@ -78,6 +83,21 @@ GLOBAL = [
 ]
 
 
+LOCAL_CFG14 = [
+    ("local_cfg1_top_f4_n1024_c320", 2, 4, 1024, 0, 320, 0.5, False, 31),            # cfg-1 top block: its ONLY level
+    ("local_cfg1_mid_f4_n256_c640", 2, 4, 256, 0, 640, 0.5, False, 32),
+    ("local_cfg4_l1_f8_n4096_c320", 2, 8, 4096, 0, 320, 0.5, False, 33),             # 24 576 x 8 192
+    ("local_cfg4_l2_f2_n4096_u12288_c320", 2, 2, 4096, 12288, 320, 0.5, False, 34),  # 4 096 x 16 384
+    ("local_cfg4_mid_l1_f8_n1024_c640", 2, 8, 1024, 0, 640, 0.5, False, 35),         # 6 144 x 2 048
+    ("local_cfg4_mid_l2_f2_n1024_u3072_c640", 2, 2, 1024, 3072, 640, 0.5, False, 36),
+]
+GLOBAL_CFG14 = [
+    ("global_cfg4_18432_c320_chunk0", 2, 18432, 18432, 320, 0.5, False, 0, 37, True),
+    ("global_cfg4_18432_c320_chunk1", 2, 18432, 18432, 320, 0.5, False, 1, 38, False),
+    ("global_cfg4_mid_4608_c640", 2, 4608, 4608, 640, 0.5, False, 1, 39, True),
+]
+
+
 def margins64(a, b, align):
     """fp64: (min gap between adjacent sorted row maxima, min top-1 / top-2 gap)."""
     a = torch.from_numpy(a).double()
@@ -93,9 +113,11 @@ def margins64(a, b, align):
 
 
 def main():
+    cfg14 = "--set" in sys.argv and sys.argv[sys.argv.index("--set") + 1] == "cfg14"
+    local_cases, global_cases = (LOCAL_CFG14, GLOBAL_CFG14) if cfg14 else (LOCAL, GLOBAL)
     out = {}
     n = 0
-    for name, B, F, tnum, unm_pre, C, ratio, align, seed, *rest in LOCAL:
+    for name, B, F, tnum, unm_pre, C, ratio, align, seed, *rest in local_cases:
         check64 = rest[0] if rest else True
         t0 = time.time()
         gen = fork_generator(123)
@@ -117,7 +139,7 @@ def main():
             out[f"{n}/{k}_shape"] = np.array(v.shape)
         print(f"{name}: randf {randf}, r {idx['src_idx'].shape[-1]}, {time.time() - t0:.1f} s", flush=True)
         n += 1
-    for name, B, sl, dl, C, ratio, align, chunk, seed, check64 in GLOBAL:
+    for name, B, sl, dl, C, ratio, align, chunk, seed, check64 in global_cases:
         t0 = time.time()
         a, b = planted_batch(sl, dl, C, seed, B)
         x = np.concatenate([a, b], axis=1)
@@ -142,7 +164,7 @@ def main():
         print(f"{name}: r {idx['src_idx'].shape[-1]}, fp64 gaps {g1:.2e} / {g2:.2e}, {time.time() - t0:.1f} s", flush=True)
         n += 1
     out["n_cases"] = np.array(n)
-    path = os.path.join(HERE, "planted_mid.npz")
+    path = os.path.join(HERE, "planted_cfg14.npz" if cfg14 else "planted_mid.npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
     print("wrote", path, n, "cases", os.path.getsize(path) // 1024, "KiB")
 

@@ -172,7 +172,7 @@ def test_match_filtered_hard_cases(L):
     xf[:, Ns + 2] = xf[:, Ns] + 3e-7 * torch.randn(B, C, generator=g)
     xf[:, 0] = xf[:, Ns] + 1e-3 * torch.randn(B, C, generator=g)
     _filtered_vs_exact(L, xf.to(DEV), Ns, Nd, False, expect_flag=0)
-    # (4) zero token -> NaN row -> device flag -> every row recomputed by refine_kernel's exact row pass
+    # (4) zero token -> NaN row -> device flag -> every row recomputed by exact_rows_kernel
     x = torch.randn(B, Ns + Nd, C, generator=g).half()
     x[0, 3] = 0
     x[1, Ns + 50] = 0
@@ -204,8 +204,8 @@ def test_match_filtered_hard_cases(L):
         xs[1, Ns + 9] *= 1e10
         _filtered_vs_exact(L, xs.to(dt).to(DEV), Ns, Nd, False, expect_flag=0)
         _filtered_vs_exact(L, xs.to(dt).to(DEV), Ns, Nd, True, expect_flag=0)
-    # (5) candidate overflow: every dst row identical -> more than 32 candidates per row -> those rows are
-    #     recomputed by the exact row pass (no whole-call fallback)
+    # (5) candidate overflow: every dst row identical -> more than 64 candidates per row -> those rows are
+    #     recomputed by exact_rows_kernel (no whole-call fallback)
     x = torch.randn(B, Ns + Nd, C, generator=g).half()
     x[:, Ns:] = x[:, Ns:Ns + 1]
     for align in (False, True):
@@ -214,6 +214,89 @@ def test_match_filtered_hard_cases(L):
         _filtered_vs_exact(L, x.to(DEV), Ns, Nd, align, expect_flag=0)
         _, flag = L.match_filtered(x.to(DEV), None, ra, rb, align, want_flag=True)
         assert int(flag[2].item()) == (Ns if align else B * Ns)
+
+
+def _regime_tokens(regime, B, Ns, Nd, C, N, seed=0):
+    """(B, Ns + Nd, C) fp16 tokens of a data regime (sites.DATA_REGIMES) after a LayerNorm -- what the matcher sees."""
+    from vidtome_amd import sites
+    g = torch.Generator().manual_seed(seed)
+    x = sites.regime_tokens(regime, B, (Ns + Nd) // N, N, C, g)
+    return torch.nn.functional.layer_norm(x, (C,)).reshape(B, Ns + Nd, C).half()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("align", [False, True])
+def test_match_filtered_escape_rows_equal_exact(L, dtype, align):
+    """The escape (exact_rows_kernel: fp32-MFMA tiles over the rows whose candidate list overflowed, operands normalised on
+    the fly) against the exact matcher, bit for bit: flat regions (a quarter of the positions of every frame hold one
+    content vector + 2 % noise -> hundreds of dst rows inside each such row's window), mixed with ordinary rows in the same
+    call, ragged sizes (rows past the lists / past Nd inside the tiles), batch 3 (three lists; aligned: one list, every
+    sample's dst set), C not a multiple of the 32-channel step, fp32 / bf16 tokens with tiny components (IEEE-division
+    fallback inside the per-row reciprocal form)."""
+    from vidtome_amd import sites
+    g = torch.Generator().manual_seed(21)
+    for (B, F, N, C, fs) in [(2, 8, 256, 320, 6), (3, 5, 200, 40, 3), (2, 6, 333, 72, 4), (1, 4, 640, 640, 3)]:
+        x = sites.regime_tokens("flat25", B, F, N, C, g)
+        x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, F * N, C)
+        if dtype != torch.float16:
+            x[:, ::7, 3] = 1e-30
+            x[:, 5::11, C - 1] = 0.0
+        x = x.to(dtype).to(DEV)
+        Ns, Nd = fs * N, (F - fs) * N
+        ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+        rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+        _filtered_vs_exact(L, x, Ns, Nd, align, expect_flag=0)
+        _, flag = L.match_filtered(x, None, ra, rb, align, want_flag=True)
+        rows = Ns if align else B * Ns
+        assert 0 < int(flag[2].item()) < rows, flag.tolist()       # some rows escaped, not all
+        # a zero dst token on top: the whole call goes through the escape (every row, every list), same bits
+        x[B - 1, Ns + 7] = 0
+        _filtered_vs_exact(L, x, Ns, Nd, align, expect_flag=1)
+
+
+def test_match_filtered_worst_cases_are_bounded(L):
+    """TIME, not only bits: the escapes of the filtered matcher must cost what the exact fp32-MFMA matcher
+    costs, not the ~1000x of the scalar row pass rounds 1-3 fell back to.  cfg-2 top-block level 1 (2 x 49 152 x 16 384 x
+    320): (a) a quarter of every frame is a flat region -> 25 % of the src rows overflow their candidate lists; (b) ONE zero
+    token among the dst rows -> every row of the call is recomputed.  Both within 2x the exact kernel on the same input."""
+    B, Ns, Nd, C, N = 2, 49152, 16384, 320, 4096
+    ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+    rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+
+    def ms(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    report = {}
+    for name in ("corr05", "flat25", "zero"):
+        x = _regime_tokens("corr05" if name == "zero" else name, B, Ns, Nd, C, N)
+        if name == "zero":
+            x[0, Ns + 5] = 0
+        x = x.to(DEV)
+        a_op, _ = L.normalize_gather(x, None, ra)
+        b_op, _ = L.normalize_gather(x, None, rb)
+        exact = L.match(a_op, b_op, Ns, Nd, False)
+        got, flag = L.match_filtered(x, None, ra, rb, False, want_flag=True)
+        assert torch.equal(got, exact), name
+        t_exact = ms(lambda: L.match(a_op, b_op, Ns, Nd, False))
+        t_filt = ms(lambda: L.match_filtered(x, None, ra, rb, False))
+        report[name] = (round(t_filt, 2), round(t_exact, 2), flag.tolist())
+        del a_op, b_op
+    print("filtered ms / exact ms / flags:", report)
+    assert report["corr05"][2][0] == 0 and report["corr05"][2][2] == 0
+    assert report["flat25"][2][0] == 0 and report["flat25"][2][2] >= B * Ns // 5      # ~25 % of the rows escaped
+    assert report["zero"][2][0] == 1
+    for name in ("flat25", "zero"):
+        assert report[name][0] <= 2.0 * report[name][1], report
 
 
 @pytest.mark.parametrize("C", [64, 256, 1024])
@@ -399,18 +482,21 @@ def test_planted_golden_gpu(L):
         _planted_gpu(c)
 
 
+@pytest.mark.parametrize("fname", ["planted_mid.npz", "planted_cfg14.npz"])
 @pytest.mark.parametrize("mode", ["filtered", "exact"])
-def test_planted_mid_and_full_size_golden_gpu(L, mode, monkeypatch):
+def test_planted_mid_and_full_size_golden_gpu(L, mode, fname, monkeypatch):
     """tests/golden/planted_mid.npz (REFERENCE runs, make_golden_mid.py): local matcher at 256 / 1 024 tokens per frame,
     C = 320 / 640, level-2 shape, aligned batches; GLOBAL matcher (`bipartite_soft_matching_2s`) up to the full cfg-2 sizes
     8 704^2 x 640 and 34 816^2 x 320, both unmerge_chunk values, rectangular, aligned; and the LARGEST levels of any
     BASELINE configuration, cfg-5's level 1 (110 592 x 36 864 x 320) and its ragged global level (64 513^2 x 320).  The HIP
     path -- the default filtered matcher AND the exact fp32 kernel -- reproduces the reference's index arrays bit for bit
-    (sha256)."""
+    (sha256).  planted_cfg14.npz (round 4): the exact level shapes of cfg-1 (3 072 x 1 024 x 320; 768 x 256 x 640) and of a
+    cfg-4 chunk (24 576 x 8 192, 4 096 x 16 384 with carried-over unmerged tokens, global 18 432^2; mid: 6 144 x 2 048 x 640,
+    4 608^2)."""
     from inputs import idx_sha, planted_batch, planted_local_chunk
     from vidtome_amd import merge
     monkeypatch.setattr(merge, "MATCH_MODE", mode)
-    for c in load_cases("planted_mid.npz"):
+    for c in load_cases(fname):
         name = str(c["name"])
         if mode == "exact" and ("cfg5" in name or "cfg3" in name):
             continue                                    # 1.5-2.6 TFLOP each on the fp32 MFMA: covered by the filtered run
@@ -554,6 +640,126 @@ def test_chain_golden_gpu(L, name):
         vpatch.compute_merge = orig
     vidtome_amd.remove_patch(unet)
     assert all(b.__class__.__name__ == "BasicTransformerBlock" for b in blocks)
+
+
+@pytest.mark.parametrize("name", ["chain16_cfg_f4_d40", "chain16_pnp_f4_d64", "chain16_cfg_f8_d80"])
+def test_default_fp16_path_vs_reference_chain(L, name):
+    """The DEFAULT path of an fp16 model -- gather-fed projection GEMMs (C <= 320) / panel GEMMs (C = 640), live and
+    compacted queries, the fp16 attention core -- against BLOCK OUTPUTS RECORDED FROM THE REFERENCE
+    (tests/golden/make_golden_chain16.py: the reference's apply_patch + ToMeBlock.forward + sa_forward on its CPU fp32 path,
+    weights and hidden states on the fp16 grid so that the fp16 model holds them exactly; cases screened so that the merge
+    decisions do not hinge on what an fp16 rounding of norm1's output can move).  Multi-chunk chains with global merging,
+    both coin outcomes, an anchor reset, a single-frame chunk, PnP batch 3 with aligned matching and shared probabilities,
+    two local levels.  Block outputs and anchors within 1e-3 of the output scale (north_star's fp16 tolerance)."""
+    import vidtome_amd
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import pnp
+    from standin import Pipe, StandInUNet, load_block_weights
+
+    cfg, z = load_chain(name)
+    unet = load_block_weights(StandInUNet(cfg["C"], cfg["heads"]), z, DEV, torch.float16)
+    for k in z.files:                      # the weights ARE fp16 values: the fp16 model is the reference's model
+        if k.startswith("w/up_blocks"):
+            assert np.array_equal(z[k], z[k].astype(np.float16).astype(np.float32)), k
+    pipe = Pipe(unet)
+    if cfg["injection"] is not None:
+        pnp.register_attention_control(pipe, cfg["injection"], cfg["B"])
+        pnp.register_time(pipe, cfg["t"])
+    vidtome_amd.apply_patch(unet, local_merge_ratio=cfg["local_ratio"], merge_global=cfg["merge_global"],
+                            global_merge_ratio=cfg["global_ratio"], batch_size=cfg["B"], align_batch=cfg["align"],
+                            target_stride=4, global_rand=0.5)
+    torch.set_rng_state(torch.from_numpy(z["rng_state"]))
+    # the path under test really is the in-house one: count its projection launches
+    calls = {"linear_rows": 0, "linear_panels": 0}
+    orig = {n: getattr(L, n) for n in calls}
+
+    def counted(n):
+        def f(*a, **k):
+            calls[n] += 1
+            return orig[n](*a, **k)
+        return f
+    for n in calls:
+        setattr(L, n, counted(n))
+    try:
+        names = [str(s) for s in z["block_names"]]
+        worst = 0.0
+        for ck, F in enumerate(cfg["chunk_frames"]):
+            if ck in cfg.get("reset_before", []):
+                vidtome_amd.update_patch(unet, global_tokens=None)             # generate.py:233-236
+            hiddens = [_t(z[f"c{ck}/b{bi}/hidden"]) for bi in range(9)]       # stored as fp16
+            assert all(h.dtype == torch.float16 for h in hiddens)
+            latent = torch.zeros(tuple(int(v) for v in z[f"c{ck}/latent_shape"]), device=DEV, dtype=torch.float16)
+            with torch.no_grad():
+                outs = unet(latent, hiddens)
+            for bi in range(9):
+                ref_out = z[f"c{ck}/b{bi}/out"]
+                err = np.abs(outs[bi].float().cpu().numpy() - ref_out).max() / max(1.0, np.abs(ref_out).max())
+                worst = max(worst, err)
+                assert err < 1e-3, (name, ck, bi, err)
+            gts = vidtome_amd.collect_from_patch(unet, attr="global_tokens")
+            for nme in names:
+                key = f"c{ck}/gt/{nme}"
+                if key in z.files:      # anchors are row copies of norm1's output (ours: rounded to fp16 once)
+                    err = np.abs(gts[nme].float().cpu().numpy() - z[key]).max() / max(1.0, np.abs(z[key]).max())
+                    assert err < 1e-3, (name, ck, nme, err)
+        print(name, "worst block-output error / scale:", worst, calls)
+    finally:
+        for n in calls:
+            setattr(L, n, orig[n])
+    assert calls["linear_rows" if cfg["C"] <= 320 else "linear_panels"] > 0, calls
+    vidtome_amd.remove_patch(unet)
+
+
+def test_device_generator_opt_in(L):
+    """apply_patch(generator_device="device"): the reference's own generator rule on a GPU (vidtome/utils.py:24-25) -- the
+    block generator is a CUDA generator forked from torch.cuda.get_rng_state(), and every draw of compute_merge (one
+    randint per local level, merge.py:57-58; one rand per global level, patch.py:62) comes from it in the reference's
+    order.  The default ("cpu") forks the CPU state on the same model."""
+    import vidtome_amd
+    from vidtome_amd import merge as vmerge
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import sites
+    B, F, latent = 2, 8, (16, 16)
+    site = sites.Site("s", 1, 320, 8)
+    drawn = []
+    orig_r, orig_c = vmerge.draw_randf, vpatch._draw_coin
+
+    def rec_r(gen, ts):
+        v = orig_r(gen, ts)
+        drawn.append(("randf", gen.device.type, ts, v))
+        return v
+
+    def rec_c(gen):
+        v = orig_c(gen)
+        drawn.append(("coin", gen.device.type, None, v))
+        return v
+    vmerge.draw_randf, vpatch._draw_coin = rec_r, rec_c
+    try:
+        for mode in ("device", None):
+            unet = sites.SiteUNet([site], seed=1).to(device=DEV, dtype=torch.float16)
+            vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B,
+                                    generator_device=mode)
+            unet.set_size(latent)
+            torch.manual_seed(77)               # seeds the CPU and the CUDA default generators
+            want_dev = torch.Generator(device=DEV).set_state(torch.cuda.get_rng_state())
+            want_cpu = torch.Generator().set_state(torch.get_rng_state())
+            drawn.clear()
+            for ck in range(2):
+                h = sites.synthetic_hidden(site, B, F, latent, torch.float16, DEV, seed=9 + ck, clip_seed=3)
+                with torch.no_grad():
+                    sites.run_segment_pass(unet, [h])
+            g = want_dev if mode == "device" else want_cpu
+            assert unet.blocks[0].generator.device.type == ("cuda" if mode == "device" else "cpu")
+            assert [d[0] for d in drawn] == ["randf", "randf", "randf", "randf", "coin"]
+            for kind, dev_type, ts, v in drawn:
+                assert dev_type == g.device.type
+                if kind == "randf":
+                    assert v == int(torch.randint(0, ts, torch.Size([1]), generator=g, device=g.device))
+                else:
+                    assert v == float(torch.rand(1, generator=g, device=g.device))
+            vidtome_amd.remove_patch(unet)
+    finally:
+        vmerge.draw_randf, vpatch._draw_coin = orig_r, orig_c
 
 
 # ---------------------------------------------------------------------------------------------------

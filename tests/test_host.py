@@ -133,10 +133,14 @@ def test_patch_api_mechanics(built):
     unet = StandInUNet(16, 2)
     pipe = Pipe(unet)
     sig = inspect.signature(vidtome_amd.apply_patch)
-    assert [(k, v.default) for k, v in list(sig.parameters.items())[1:]] == [
+    pos = [(k, v.default) for k, v in list(sig.parameters.items())[1:] if v.kind is not inspect.Parameter.KEYWORD_ONLY]
+    assert pos == [
         ("local_merge_ratio", 0.9), ("merge_global", False), ("global_merge_ratio", 0.8), ("max_downsample", 2),
         ("seed", 123), ("batch_size", 2), ("include_control", False), ("align_batch", False),
         ("target_stride", 4), ("global_rand", 0.5)]                                     # patch.py:234-245
+    # the one addition is keyword-only and defaults to the reference-CPU-path behaviour
+    kwonly = {k: v.default for k, v in sig.parameters.items() if v.kind is inspect.Parameter.KEYWORD_ONLY}
+    assert kwonly == {"generator_device": None}
     out = vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True)
     assert out is unet
     blocks = list(unet.blocks())
@@ -361,3 +365,30 @@ def test_pnp_register_time_stamps_resnets(built):
             assert att.transformer_blocks[0].attn1.t == 481 and att.transformer_blocks[0].attn2.t == 481
     assert u.mid_block.attentions[0].transformer_blocks[0].attn1.t == 481
     assert not hasattr(u.mid_block.resnets[0], "t")                     # the reference leaves the mid resnets alone
+
+
+def test_generator_modes_follow_the_reference_rules():
+    """utils.init_generator: "cpu" (default) forks the CPU RNG state whatever the device (the reference's CPU path, i.e.
+    the oracle's stream); "device" is vidtome/utils.py:18-30 to the letter (CPU tensors -> CPU state, other device types
+    -> the fallback generator or a CPU fork; the CUDA branch needs a GPU and is covered by the -m gpu tests)."""
+    import torch
+    from vidtome_amd import utils
+    torch.manual_seed(123)
+    want = [int(torch.randint(0, 4, (1,), generator=torch.Generator().manual_seed(123))) for _ in range(1)]
+    g = utils.init_generator(torch.device("cpu"))
+    assert g.device.type == "cpu" and int(torch.randint(0, 4, (1,), generator=g)) == want[0] == 2      # SURVEY KAT
+    g2 = utils.init_generator(torch.device("cpu"), mode="device")
+    assert torch.equal(g2.get_state(), torch.get_rng_state())
+    fb = torch.Generator().manual_seed(7)
+    assert utils.init_generator(torch.device("meta"), fallback=fb, mode="device") is fb
+    assert utils.init_generator(torch.device("meta"), mode="device").device.type == "cpu"
+    assert utils.init_generator(torch.device("meta"), fallback=fb).device.type == "cpu"               # default: CPU fork
+    with pytest.raises(ValueError):
+        utils.init_generator(torch.device("cpu"), mode="gpu")
+    import vidtome_amd
+    from standin import StandInUNet
+    with pytest.raises(ValueError):
+        vidtome_amd.apply_patch(StandInUNet(16, 2), generator_device="cuda")
+    u = vidtome_amd.apply_patch(StandInUNet(16, 2), generator_device="device")
+    assert u._tome_info["args"]["generator_device"] == "device"
+    vidtome_amd.remove_patch(u)

@@ -293,16 +293,25 @@ def _idx_matches(c, got):
         assert idx_sha(g) == str(c[n + "_sha256"]), (str(c["name"]), n)
 
 
-@pytest.mark.parametrize("which", ["local", "global_mid", "global_full"])
+@pytest.mark.parametrize("which", ["local", "global_mid", "global_full", "cfg14_local", "cfg14_global"])
 def test_planted_mid_and_full_size_golden(oracle, which):
     """tests/golden/planted_mid.npz (make_golden_mid.py, REFERENCE runs): the local matcher at 256 / 1 024 tokens per frame
     with C = 320 / 640 (incl. the level-2 shape with carried-over unmerged tokens, aligned batches) and the GLOBAL
     matcher up to the full cfg-2 sizes 8 704^2 x 640 and 34 816^2 x 320 (both unmerge_chunk values, rectangular,
-    aligned): the oracle reproduces the reference's three index arrays bit for bit (sha256)."""
+    aligned): the oracle reproduces the reference's three index arrays bit for bit (sha256).
+    `cfg14_*` = tests/golden/planted_cfg14.npz (round 4): the exact level shapes of BASELINE.json's cfg-1 (3 072 x 1 024 x 320,
+    768 x 256 x 640: its only levels) and of one cfg-4 chunk (24 576 x 8 192, 4 096 x 16 384 with carried-over unmerged
+    tokens, global 18 432^2; mid blocks 6 144 x 2 048 x 640, 4 608^2)."""
     ran = 0
-    for c in load_cases("planted_mid.npz"):
+    fname = "planted_cfg14.npz" if which.startswith("cfg14") else "planted_mid.npz"
+    for c in load_cases(fname):
         kind, name = str(c["kind"]), str(c["name"])
-        group = "local" if kind == "local" else ("global_full" if int(c["src_len"]) > 10000 else "global_mid")
+        if which.startswith("cfg14"):
+            group = "cfg14_local" if kind == "local" else "cfg14_global"
+            if name.endswith("18432_c320_chunk1"):
+                continue    # the second 18 432^2 case (0.43 TFLOP on the host cores): on the GPU only
+        else:
+            group = "local" if kind == "local" else ("global_full" if int(c["src_len"]) > 10000 else "global_mid")
         if group != which:
             continue
         if "cfg5" in name or "cfg3" in name:

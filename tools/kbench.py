@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks on the cfg-2 shapes (used while optimising; run under rocprofv3 for counters).
 
-    python tools/kbench.py match  [--shape top_l1|top_l2|top_g|mid_l1] [--iters 5]
+    python tools/kbench.py match  [--shape top_l1|top_l2|top_g|mid_l1] [--iters 5] [--data n01|corr01|corr05|flat25|dup|zero|all]
+                                  (data regimes: vidtome_amd/sites.DATA_REGIMES; `zero` = corr05 with ONE zero token among the
+                                   dst rows, which sends the whole call to the exact escape; `all` prints the table of regimes)
     python tools/kbench.py attn   [--M 52224 --d 40 --heads 8 --B 2] [--iters 3]
     python tools/kbench.py sort   [--n 49152]
     python tools/kbench.py sites  --shape cfg2|cfg3|cfg4|cfg5            (a hot-path pass at the other BASELINE configurations)
@@ -49,26 +51,46 @@ def main():
     ap.add_argument("--n", type=int, default=49152)
     ap.add_argument("--align", action="store_true")
     ap.add_argument("--C", type=int, default=320)
-    ap.add_argument("--data", default="random", choices=["random", "zeros", "const"], help="attn: operand values")
+    ap.add_argument("--data", default="random", help="attn: random | zeros | const (operand values); match: n01 | corr01 | "
+                    "corr05 | flat25 | dup | zero | all (token regime; random = n01 in fp16 straight from the device generator)")
     a = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     if a.what == "match":
+        from vidtome_amd import sites
         B, Ns, Nd, C = SHAPES[a.shape]
-        x = torch.randn(B, Ns + Nd, C, generator=g, device=dev, dtype=torch.float16)
         ra = torch.arange(Ns, dtype=torch.int32, device=dev).expand(B, Ns).contiguous()
         rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=dev).expand(B, Nd).contiguous()
-        aop, _ = _lib.normalize_gather(x, None, ra)
-        bop, _ = _lib.normalize_gather(x, None, rb)
-        med, best = timeit(lambda: _lib.match(aop, bop, Ns, Nd, a.align), a.iters)
+
+        def tokens(regime):
+            if regime == "random":
+                return torch.randn(B, Ns + Nd, C, generator=g, device=dev, dtype=torch.float16)
+            N = 4096
+            while Ns % N or Nd % N:
+                N //= 2
+            gc = torch.Generator().manual_seed(0)
+            x = sites.regime_tokens("corr05" if regime == "zero" else regime, B, (Ns + Nd) // N, N, C, gc)
+            x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, Ns + Nd, C).half()   # the matcher sees norm1's output
+            if regime == "zero":
+                x[0, Ns + 5] = 0
+            return x.to(dev)
+
+        regimes = ["n01", "corr01", "corr05", "flat25", "dup", "zero"] if a.data == "all" else [a.data]
         fl = 2.0 * B * Ns * Nd * C
-        medf, bestf = timeit(lambda: _lib.match_filtered(x, None, ra, rb, a.align), a.iters)
-        _, fl_ = _lib.match_filtered(x, None, ra, rb, a.align, want_flag=True)
-        print("flags [whole-call exact, non-finite, overflow rows, -]:", fl_.tolist())
-        print(f"match_filtered {a.shape}: median {medf:.3f} ms ({2.0 * B * Ns * Nd * C / medf / 1e9:.1f} algorithmic "
-              f"TFLOP/s), best {bestf:.3f} ms")
-        print(f"match {a.shape} B={B} Ns={Ns} Nd={Nd} C={C}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), "
-              f"best {best:.3f} ms ({fl / best / 1e9:.1f} TFLOP/s)")
+        print(f"match {a.shape} B={B} Ns={Ns} Nd={Nd} C={C} align={a.align}")
+        print(f"{'data':8s} {'filtered ms':>12s} {'alg TFLOP/s':>12s} {'exact ms':>9s} {'pairs/row':>10s} {'escape rows':>12s} {'whole-call':>10s} equal")
+        for regime in regimes:
+            x = tokens(regime)
+            aop, _ = _lib.normalize_gather(x, None, ra)
+            bop, _ = _lib.normalize_gather(x, None, rb)
+            med, best = timeit(lambda: _lib.match(aop, bop, Ns, Nd, a.align), a.iters)
+            medf, bestf = timeit(lambda: _lib.match_filtered(x, None, ra, rb, a.align), a.iters)
+            out, fl_ = _lib.match_filtered(x, None, ra, rb, a.align, want_flag=True)
+            same = bool(torch.equal(out, _lib.match(aop, bop, Ns, Nd, a.align)))
+            f = fl_.tolist()                # [whole-call exact, non-finite, escape rows, refined pairs]
+            rows = Ns if a.align else B * Ns
+            print(f"{regime:8s} {medf:12.3f} {fl / medf / 1e9:12.1f} {med:9.3f} {f[3] / rows:10.2f} {f[2]:12d} {f[0]:10d} {same}")
+            del aop, bop
     elif a.what == "attn":
         B, M, h, d = a.B, a.M, a.heads, a.d
         C = h * d

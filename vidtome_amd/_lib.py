@@ -138,6 +138,11 @@ def _workspace(tag: str, nbytes: int, device: torch.device) -> torch.Tensor:
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag, threading.get_ident())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is None:
+            # a new (thread, stream, purpose): the moment to let go of the buffers of threads that no longer exist
+            alive = {t.ident for t in threading.enumerate()}
+            for k in [k for k in _WS if k[3] not in alive]:
+                del _WS[k]
         buf = _WS[key] = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
     return buf
 

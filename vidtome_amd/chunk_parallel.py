@@ -20,8 +20,12 @@ per chunk; only this hand-off couples ranks.  Three exchange modes, one class (`
                        that is otherwise idle -- but nothing is waited for where the anchors are consumed (sending the
                        merged tokens after the local levels leaves the whole transfer, 0.45 ms per cfg-2 top block, exposed).
                        VIDTOME_NEIGHBOUR_EARLY=0 selects that single-message form.
-``allgather``          the same semantics through one RCCL all-gather per merging block (north_star's wording); each
-                       rank uses only its predecessor's shard, so ``neighbour`` moves 1/(W-1) of the bytes.
+``allgather``          the same semantics with one RCCL all-gather per merging block (north_star's wording).  What is
+                       gathered is the composed local merge MAP of every rank (B, M_local int32, padded to the round's
+                       longest: a few hundred KB per rank), not the tokens: the joined chunk itself travels point-to-point to
+                       the one rank that needs it when the block starts, exactly as in the neighbour mode, so the collective on
+                       the critical path in front of the global level moves KBs (rounds 1-3 gathered the tokens: W - 1 times
+                       44.6 MB per cfg-2 top block, of which a rank used one shard).
 
 What makes this work without host round trips:
 
@@ -121,6 +125,11 @@ class DistTransport:
     test-only path, it synchronises."""
 
     def __init__(self, group=None):
+        if group is not None and dist.get_world_size(group) != dist.get_world_size():
+            # the edge groups below are made with dist.new_group, which EVERY rank of the default group has to enter --
+            # members of a sub-group constructing the transport on their own would wait for the others forever
+            raise NotImplementedError("DistTransport needs the default (WORLD) group: its per-edge process groups are "
+                                      "created collectively by all ranks (dist.new_group)")
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -143,6 +152,16 @@ class DistTransport:
                     elif self.rank == nxt:
                         dist.recv(tok, src=ranks[r], group=self._edge[r])
                 torch.cuda.synchronize()
+
+    def close(self) -> None:
+        """Destroy the per-edge process groups (communicators + streams).  Collective like their creation: every rank
+        calls it, after its last transfer has completed."""
+        for g in self._edge.values():
+            try:
+                dist.destroy_process_group(g)
+            except Exception:
+                pass
+        self._edge = {}
 
     def _group_for(self, src: int, dst: int):
         if (src + 1) % self.world != dst:
@@ -223,6 +242,9 @@ class LocalTransport:
     def all_gather(self, tensor):
         raise RuntimeError("LocalTransport has no collectives: use the 'ring' or 'neighbour' mode")
 
+    def close(self) -> None:
+        pass
+
 
 # ----------------------------------------------------------------------------------------------------
 # the exchange
@@ -270,6 +292,13 @@ class AnchorExchange:
         self.early = os.environ.get("VIDTOME_NEIGHBOUR_EARLY", "1") != "0"   # neighbour mode: joined chunk first, map later
         self._history: List[List[int]] = []
         self._modules: Dict[str, object] = {}                      # patched blocks registered by enable()
+        self.where = "idle"                                        # last bookkeeping entry (bench.py's watchdog prints it)
+
+    def close(self) -> None:
+        """Release the transport's communicators (collective; after end_step)."""
+        if self._cur is not None:
+            raise RuntimeError("close inside a step (call end_step first)")
+        self.t.close()
 
     # ---- step / chunk bookkeeping (host side only)
     @property
@@ -319,6 +348,7 @@ class AnchorExchange:
         """Consume the draws of the chunks after this rank's last one (the next step continues the same generator
         streams, like the sequential run) and retire the sends."""
         n = len(self._frames)
+        self.where = f"end_step: draining {len(self._inflight)} sends"
         self._history.append(self._frames)
         for st in self._blocks.values():
             self._replay(st, n)
@@ -331,6 +361,7 @@ class AnchorExchange:
                 work.wait()
         self._inflight.clear()
         self._cur = None
+        self.where = "idle (step finished)"
 
     def _replay(self, st: _BlockState, upto: int) -> None:
         """Advance the block's generator over chunks [st.drawn, upto) that other ranks process."""
@@ -367,10 +398,12 @@ class AnchorExchange:
         self._catch_up(st)
         self._replay(st, i)
         st.drawn = i + 1                                   # compute_merge itself makes chunk i's draws
-        if not args["merge_global"] or self.mode == "allgather":
+        self.where = f"chunk {i} block {key}: begin_block ({self.mode}; predecessor rank {self._owner(i - 1)}, " \
+                     f"successor rank {self._owner(i + 1)})"
+        if not args["merge_global"]:
             return
-        if self.mode == "neighbour":
-            if self.world > 1 and self.early:
+        if self.mode in ("neighbour", "allgather"):
+            if self.world > 1 and (self.early or self.mode == "allgather"):
                 # ship the joined chunk now, receive the predecessor's: both overlap this block's local levels
                 n = len(self._frames)
                 send = like if i + 1 < n else None
@@ -392,6 +425,8 @@ class AnchorExchange:
         rows of ``like`` they are, None when the chunk has no local level -- what the early hand-over ships instead)."""
         i, st = self._cur, self._blocks[key]
         n = len(self._frames)
+        self.where = f"chunk {i} block {key}: anchors_for ({self.mode}): waiting for rank {self._owner(i - 1)}'s tokens / " \
+                     f"handing over to rank {self._owner(i + 1)}"
         if self.mode == "ring":
             if i == 0:
                 return None
@@ -426,12 +461,18 @@ class AnchorExchange:
             if got is not None:
                 self.bytes_received += got.numel() * got.element_size()
             return got
-        local = local_tokens_fn().contiguous()
-        st.lens[i] = local.shape[1]
-        if self.mode == "neighbour":                       # world == 1: the predecessor ran here, hand over in place
+        if self.world == 1:                                # the predecessor ran here: hand over in place (both parallel modes)
+            local = local_tokens_fn().contiguous()
+            st.lens[i] = local.shape[1]
             got, st.carry = st.carry, local
             return got if i > 0 else None
-        # all-gather: chunk lengths differ between ranks -> pad to the round's maximum (known from the replay)
+        # all-gather: the joined chunks went point-to-point when the block started (begin_block); the collective moves the
+        # composed local merge MAPS.  Chunk lengths differ between ranks -> pad to the round's maximum (known from the replay)
+        B, C = like.shape[0], like.shape[2]
+        my_map = local_map if local_map is not None else \
+            torch.arange(like.shape[1], dtype=torch.int32, device=like.device).expand(B, -1)   # no local level: every row
+        Ml = my_map.shape[1]
+        st.lens[i] = Ml
         first = i - self.rank
         st_lens = dict(st.lens)
         # lengths of the later chunks of this round: simulate on a COPY of the generator (their draws are consumed
@@ -442,19 +483,20 @@ class AnchorExchange:
             st_lens[c] = simulate_block_draws(gen, self._frames[c], st.tsize, st.args, has_anchors=c > 0)["M_local"]
         round_chunks = range(first, min(first + self.world, n))
         m_max = max(st_lens[c] for c in round_chunks)
-        B, Ml, C = local.shape
-        padded = local if Ml == m_max else torch.cat([local, local.new_zeros(B, m_max - Ml, C)], dim=1)
-        gathered = self.t.all_gather(padded)               # every rank calls it once per round, also the idle ones
-        self.bytes_received += gathered.numel() * gathered.element_size()
+        padded = my_map if Ml == m_max else torch.cat([my_map, my_map.new_zeros(B, m_max - Ml)], dim=1)
+        gathered = self.t.all_gather(padded.contiguous())  # (W, B, m_max) int32; every rank calls it once per round
         prev_round_last, st.carry = st.carry, None
         last = first + self.world - 1
         if last < n:
             st.carry = gathered[self.world - 1][:, :st_lens[last]]
+        pool, st.pool = (st.pool.wait() if st.pool is not None else None), None
+        self.bytes_received += gathered.numel() * gathered.element_size() + (0 if pool is None else pool.numel() * pool.element_size())
         if i == 0:
             return None
-        if self.rank == 0:
-            return prev_round_last                         # chunk i-1 ran on rank W-1 in the previous round
-        return gathered[self.rank - 1][:, :st_lens[i - 1]]
+        # chunk i-1 ran on rank W-1 in the previous round (rank 0), else on rank - 1 in this one
+        pmap = (prev_round_last if self.rank == 0 else gathered[self.rank - 1][:, :st_lens[i - 1]]).contiguous()
+        return _lib.gather_rows(pool, None, pmap) if pool.is_cuda else \
+            torch.gather(pool, 1, pmap.long()[:, :, None].expand(-1, -1, C))
 
     def _skip_own_draws(self, gen: torch.Generator, st: _BlockState, i: int) -> None:
         """all-gather only: `gen` is a copy taken after this chunk's LOCAL draws; the coin of its global level (made by
@@ -466,6 +508,7 @@ class AnchorExchange:
         """After the block stored its new anchors (patch.py:80,82).  Exact mode forwards them to the next chunk."""
         i, st = self._cur, self._blocks[key]
         st.lens.setdefault(i, anchors.shape[1])
+        self.where = f"chunk {i} block {key}: published"
         if self.mode != "ring":
             return
         if i + 1 >= len(self._frames):

@@ -370,6 +370,10 @@ int launch_panel_gemm(const void *tok, int64_t n, int64_t n_pad, const void *w, 
                       const Epi &E, hipStream_t s) {
     // n_pad / Nw_pad are the ROW STRIDES of the two panel operands (an operand may be a row range of a larger panel
     // tensor); the tiles cover the valid rows only
+    // the kernel forms a lane's byte offset inside a k-group in 32 bits: (kh * n_pad + row) * 16 with kh <= 1 (the weight
+    // operand goes through wave-uniform 64-bit pointers + a lane offset < 1 KiB)
+    VTM_REQUIRE(2 * n_pad * 16 < (1ll << 32), "panel GEMM: %lld token panel rows exceed the 32-bit fragment offset",
+                (long long)n_pad);
     const int ns_tiles = (int)vtm::cdiv(n, FBS), nd_tiles = (int)vtm::cdiv(Nw, FBD);
     const int total_src_tiles = ns_tiles;
     const int max_patch = (int64_t)16 * FBS * K * 2 <= (3 << 20) ? 16 : 8;

@@ -214,10 +214,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void layernorm_rows_kernel(co
 template <typename T>
 void launch_layernorm(const void *x, const void *gamma, const void *beta, int64_t rows, int64_t C, float eps, void *out,
                       int64_t panel_rows, hipStream_t s) {
-#ifndef VTM_OLD_LN   // (A/B build switch)
-    // measured (profiles/r02_sweeps.txt): +24 % HBM rate at C = 320 beyond the Infinity Cache
     // input + output beyond the Infinity Cache: streaming loads / stores (common.h)
     const bool nt = 2 * rows * C * (int64_t)sizeof(T) > vtm::STREAM_BYTES;
+#ifndef VTM_OLD_LN   // (A/B build switch)
+    // measured (profiles/r02_sweeps.txt): +24 % HBM rate at C = 320 beyond the Infinity Cache
     // round 3 (one round of rows per wave, profiles/r03_hbm_nt.txt): the lanes-per-row kernel also wins at C = 640 (6.0 vs 4.2
     // TB/s beyond the Infinity Cache, +6 % at the cfg-2 mid sites) and at C = 1280 for large row counts; the few-thousand-row
     // C = 1280 sites stay with a wave per row (14.7 vs 16.7 us)

@@ -17,11 +17,15 @@
 // halves out of the fp16 subnormal range for every component that matters (a component below 6e-8 is
 // rounded with an absolute error <= 3e-11, far inside EPS even summed over 1280 channels).
 //
-// Escapes (all exact, no host round trip): a row whose candidate list overflows CAP (massively duplicated
-// dst rows) is recomputed exactly by the exact-row pass at the end of refine_kernel (all Nd chains of that row); any
-// row without a finite positive norm (zero token -> 0/0, merge.py:84 has no eps) raises a device flag
-// (survivors_kernel) that makes that same pass recompute EVERY row of the call -- slow, exact, and only ever
-// taken by degenerate inputs.
+// Escapes (all exact, no host round trip, BOUNDED cost): a row whose candidate list overflows CAP (flat image regions,
+// massively duplicated dst rows) is put on a per-sample list and recomputed by exact_rows_kernel: fp32-MFMA score tiles
+// [128 listed rows x all Nd] -- the arithmetic of vtm_match (v_mfma_f32_32x32x2_f32 = the canonical k-ascending fmaf
+// chain), operands normalised on the fly from the token rows and the canonical norms; any row without a finite positive
+// norm (zero token -> 0/0, merge.py:84 has no eps) raises a device flag (survivors_kernel) that makes that kernel
+// recompute EVERY row of the call.  Worst case = the cost of the exact matcher (~8 ms at the cfg-2 top level), not the
+// ~1000x of a scalar row pass (rounds 1-3).  A row stops collecting the moment its list overflows (the overflowing lane
+// publishes +inf as the row's running maximum, which every other lane / split of the row picks up), so flat regions do not
+// flood the filter with candidate pushes either.
 #include "common.h"
 
 #include <cstdlib>
@@ -423,10 +427,16 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     uint32_t ci[2][4];
     // candidate lists are slot-major, [slot][row] (cand_rows rows): the first entries of neighbouring rows -- all that most
     // rows ever have -- share cache lines for the lanes of survivors_kernel; 32-bit index (the launcher checks the size)
-    auto push = [&](int64_t srow, float v_scaled, uint32_t d) {   // append to the row's global candidate list
-        const int slot = atomicAdd(&cnt[out_row0 + srow], 1);     // cnt > CAP marks the row for the exact row pass
+    // The row's list is full: the row goes to exact_rows_kernel whatever else is found, so it stops collecting -- +inf
+    // becomes its published running maximum (nothing is ever within the window of +inf) and every lane / split of the row
+    // picks that up with its next re-read (a flat image region would otherwise push thousands of candidates per row).
+    // (This lane too: with its re-read at the end of the next tile -- no extra state in the loop, whose register budget
+    // has no slack.)
+    auto push = [&](int64_t srow, float v_scaled, uint32_t d) -> bool {   // append to the row's global candidate list
+        const int slot = atomicAdd(&cnt[out_row0 + srow], 1);     // cnt > CAP marks the row for exact_rows_kernel
         if (slot < CAP)
             cand[(uint32_t)slot * (uint32_t)cand_rows + (uint32_t)(out_row0 + srow)] = make_uint2(__float_as_uint(v_scaled * INV_S2), d + idx_base);
+        return slot >= CAP;
     };
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                     if (!__any(trig && second >= thr)) {
                         if (trig) {
                             if (cv[sb][3] >= thr)   // evicted entry still inside the window: spill it
-                                push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3]);
+                                if (push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3])) rm = INFINITY;
                             cv[sb][3] = cv[sb][2]; ci[sb][3] = ci[sb][2];
                             cv[sb][2] = cv[sb][1]; ci[sb][2] = ci[sb][1];
                             cv[sb][1] = cv[sb][0]; ci[sb][1] = ci[sb][0];
@@ -514,13 +524,14 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                             const float x = v[r];
                             if (x >= rm - WS && x > -INFINITY) {
                                 const float nrm_ = fmaxf(rm, x);
-                                if (cv[sb][3] >= nrm_ - WS) push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3]);
+                                bool full_list = false;
+                                if (cv[sb][3] >= nrm_ - WS) full_list = push(srow0 + sb * 32 + l31, cv[sb][3], ci[sb][3]);
                                 cv[sb][3] = cv[sb][2]; ci[sb][3] = ci[sb][2];
                                 cv[sb][2] = cv[sb][1]; ci[sb][2] = ci[sb][1];
                                 cv[sb][1] = cv[sb][0]; ci[sb][1] = ci[sb][0];
                                 cv[sb][0] = x;
                                 ci[sb][0] = (uint32_t)(dst0 + ib * 32 + (r & 3) + 8 * (r >> 2));
-                                rm = nrm_;
+                                rm = full_list ? INFINITY : nrm_;
                             }
                         }
                     }
@@ -529,7 +540,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
             }
             runmax[sb] = rm;
             if constexpr (SHARE) {
-                if (rm > rm_in && rm < INFINITY) atomicMax(&amax[out_row0 + srow0 + sb * 32 + l31], orderable(rm * INV_S2));
+                if (rm > rm_in) atomicMax(&amax[out_row0 + srow0 + sb * 32 + l31], orderable(rm * INV_S2));   // (+inf: the list is full)
             }
         }
     };
@@ -800,13 +811,14 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
 // ---- refine, step 1: per row, keep the candidates inside the window of the row's global approximate max ----
 __global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const unsigned int *__restrict__ amax,
                                                         const int *__restrict__ cnt, const uint2 *__restrict__ cand,
-                                                        int *__restrict__ flags, int *__restrict__ ovf_rows,
+                                                        int *__restrict__ flags, int *__restrict__ ovf_cnt,
+                                                        int *__restrict__ ovf_rows, int64_t Ns, int align,
                                                         uint2 *__restrict__ pairs, const float *__restrict__ na,
                                                         int64_t n_na, const float *__restrict__ nb, int64_t n_nb) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // any row of either operand without a finite positive norm (zero token -> NaN xhat, merge.py:84), or with one so
     // small / large that prep_operand's reciprocal is not a normal number: the filter's
-    // error window means nothing for this call -> refine_kernel recomputes EVERY row exactly (flags[0]).  The scan
+    // error window means nothing for this call -> exact_rows_kernel recomputes EVERY row (flags[0]).  The scan
     // rides on this launch (a kernel boundary separates it from the reader).
     {
         const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
@@ -830,9 +842,28 @@ __global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const 
     for (int c = 0; c < PRE; ++c) ns += __uint_as_float(pre[c].x) >= thr;   // NaN (not fetched) never counts
     if (n <= CAP)
         for (int c = PRE; c < n; ++c) ns += __uint_as_float(cand[(int64_t)c * rows_out + row].x) >= thr;
-    if (n > CAP) {   // the list overflowed (a dst row duplicated more than ~CAP times): refine_kernel's exact row pass
-        ovf_rows[atomicAdd(&flags[2], 1)] = (int)row;
-        ns = 0;
+    // the list overflowed (a flat region / a dst row duplicated more than ~CAP times): the row goes on its sample's list
+    // for exact_rows_kernel (one list per sample -- a tile of listed rows shares its dst operand; aligned: one list).
+    // One atomic per wave and list.
+    const bool ovf = live && n > CAP;
+    if (ovf) ns = 0;
+    {
+        const int l = (ovf && !align) ? (int)(row / Ns) : 0;
+        unsigned long long todo = __ballot(ovf);
+        while (todo) {
+            const int lead = __ffsll(todo) - 1;
+            const int l0 = __shfl(l, lead, 64);
+            const unsigned long long grp = __ballot(ovf && l == l0);
+            int base = 0;
+            if ((int)(threadIdx.x & 63) == lead) {
+                base = atomicAdd(&ovf_cnt[l0], __popcll(grp));
+                atomicAdd(&flags[2], __popcll(grp));
+            }
+            base = __shfl(base, lead, 64);
+            if (ovf && l == l0)
+                ovf_rows[(int64_t)l0 * Ns + base + __popcll(grp & ((1ull << (threadIdx.x & 63)) - 1ull))] = (int)(row - (int64_t)l0 * Ns);
+            todo &= ~grp;
+        }
     }
     const int lane = threadIdx.x & 63;
     int incl = ns;
@@ -864,11 +895,10 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
                                                      const int32_t *__restrict__ b_rows, int64_t Nd,
                                                      const float *__restrict__ na, const float *__restrict__ nb,
                                                      int align, const int *__restrict__ flags,
-                                                     const uint2 *__restrict__ pairs, const int *__restrict__ ovf_rows,
-                                                     unsigned long long *__restrict__ best, int64_t rows_out) {
-    extern __shared__ float sa[];   // exact-row pass: the normalised src row (C floats)
-    // a call with a norm outside [2^-100, 2^100] (flags[0]) is recomputed row by row below: its pairs are skipped, the fast
-    // division is only ever used inside that range
+                                                     const uint2 *__restrict__ pairs,
+                                                     unsigned long long *__restrict__ best) {
+    // a call with a norm outside [2^-100, 2^100] (flags[0]) is recomputed by exact_rows_kernel: its pairs are skipped, the
+    // fast division is only ever used inside that range
     const int npairs = flags[0] ? 0 : flags[3];
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (int64_t)gridDim.x * blockDim.x) {
         const uint2 pr = pairs[p];
@@ -918,46 +948,218 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
         atomicMax(&best[row], ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col));
     }
 
-    // ---- exact pass for the (rare) rows whose candidate list overflowed -- or for every row of a call with
-    // non-finite operands: all Nd canonical chains of the row, one workgroup per row (same launch: the list is
-    // almost always empty and a launch of its own costs more than the check).  NaN scores order like torch.max:
-    // the packed key puts NaN on top and the first column first.
-    const bool all_rows = flags[0] != 0;             // a non-finite xhat somewhere: every row, see survivors_kernel
-    const int64_t nrows = all_rows ? rows_out : (int64_t)flags[2];
-    for (int64_t it = blockIdx.x; it < nrows; it += gridDim.x) {
-        const int64_t row = all_rows ? it : (int64_t)ovf_rows[it];
-        const int64_t i = align ? row : row % Ns;
-        unsigned long long bestkey = 0;
-        const int64_t b0 = align ? 0 : row / Ns, b1 = align ? B : b0 + 1;
-        for (int64_t bi = b0; bi < b1; ++bi) {
-            __syncthreads();
-            const T *pa = pool_row(x0, P0, x1, P1, bi, a_rows[bi * Ns + i], C);
-            const float nrm_a = na[bi * Ns + i];
-            for (int64_t k = threadIdx.x; k < C; k += blockDim.x) sa[k] = to_f32(pa[k]) / nrm_a;
-            __syncthreads();
-            for (int64_t j = threadIdx.x; j < Nd; j += blockDim.x) {
-                const T *pb = pool_row(x0, P0, x1, P1, bi, b_rows[bi * Nd + j], C);
-                const float nrm_b = nb[bi * Nd + j];
-                float acc = 0.0f;
-                for (int64_t k = 0; k < C; k += 8) {
-                    float fb[8];
-                    load8(pb + k, fb);
+}
+
+// ---- escape: exact fp32-MFMA score tiles for the listed rows (or, flags[0], for every row of the call) ----
+// Same arithmetic as match_kernel (match.hip): v_mfma_f32_32x32x2_f32 accumulates in ascending k = the canonical fmaf chain,
+// MFMA A operand = dst tile, B operand = src tile, so a lane owns one src row and keeps a running (max, first argmax) pair
+// with torch.max's NaN rule.  What differs is where the operands come from: there are no fp32 operand panels on the
+// filtered path (they would double its workspace for a pass that normally has nothing to do), so a workgroup normalises
+// its tiles ON THE FLY -- token rows through the gather lists, divided by the canonical norms of prep_operand with the
+// IEEE-identical per-row reciprocal form of refine_kernel (plain IEEE division when flags[0] says that a norm is outside
+// the range where that form is valid) -- into LDS as the k-panel image [g][kh][row][4] the MFMA fragments are read from.
+// Per 32-channel step a thread fetches 2 + 2 row pieces (next step's, in flight behind this step's 64 MFMAs), and the
+// dst operand is normalised once per 128 listed rows (the scalar row pass this replaces normalised it once per ROW).
+// Work items = (list, 128-row tile of the list, sample [aligned: every sample's dst set], dst split); the counts live on
+// the device, so a fixed grid strides over the items and leaves at once when there are none.
+constexpr int XS = 128;   // listed src rows per workgroup, 32 per wave
+constexpr int XD = 128;   // dst rows per tile
+constexpr int XK = 32;    // channels per step
+constexpr int XP = XD + 1;   // rows per LDS panel (+1: the 4 pieces of a row land in different bank groups)
+static_assert(XS == XD, "one panel stride for both operands");
+
+__device__ __forceinline__ int64_t xcdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void exact_rows_kernel(
+    const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
+    const int32_t *__restrict__ a_rows, int64_t Ns, const int32_t *__restrict__ b_rows, int64_t Nd,
+    const float *__restrict__ na, const float *__restrict__ nb, int align, const int *__restrict__ flags,
+    const int *__restrict__ ovf_cnt, const int *__restrict__ ovf_rows, unsigned long long *__restrict__ best, int nsplit,
+    int tiles_per_split) {
+    __shared__ __attribute__((aligned(16))) float sD[8 * XP * 4];
+    __shared__ __attribute__((aligned(16))) float sS[8 * XP * 4];
+    constexpr int RAW = sizeof(T) == 4 ? 2 : 1;      // 16-byte loads per 8-channel piece
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const bool all = flags[0] != 0;
+    const int64_t nlists = align ? 1 : B, nsel = align ? B : 1;
+    const int KT = (int)xcdiv(C, XK);
+    const int nd_tiles = (int)xcdiv(Nd, XD);
+    const int prow = tid >> 2, pg = tid & 3;          // staging role: rows prow, prow + 64; 8-channel group pg of the step
+
+    for (int64_t item = blockIdx.x;; item += gridDim.x) {
+        // ---- which (list, tile, sample, split) ----
+        int64_t rem = item, l = 0, cnt_l = 0;
+        for (; l < nlists; ++l) {
+            cnt_l = all ? Ns : (int64_t)ovf_cnt[l];
+            const int64_t items_l = xcdiv(cnt_l, XS) * nsel * nsplit;
+            if (rem < items_l) break;
+            rem -= items_l;
+        }
+        if (l == nlists) break;
+        const int split = (int)(rem % nsplit);
+        rem /= nsplit;
+        const int64_t bi = align ? rem % nsel : l;
+        const int64_t tile = rem / nsel;
+        const int jt0 = split * tiles_per_split, jt1 = min(jt0 + tiles_per_split, nd_tiles);
+        if (jt0 >= jt1) continue;
+        auto listed = [&](int r) -> int64_t {         // row (within its sample) of tile entry r, -1 = past the list
+            const int64_t at = tile * XS + r;
+            if (at >= cnt_l) return -1;
+            return all ? at : (int64_t)ovf_rows[l * Ns + at];
+        };
+
+        // ---- this thread's two src rows (fixed for the item) ----
+        const T *ps[2];
+        RowDivisor ds[2];
+        bool vs[2];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(sa[k + e], fb[e] / nrm_b, acc);
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = listed(prow + 64 * u);
+            vs[u] = i >= 0;
+            const int64_t ii = vs[u] ? i : 0;
+            ps[u] = pool_row(x0, P0, x1, P1, bi, a_rows[bi * Ns + ii], C);
+            ds[u] = row_divisor(na[bi * Ns + ii]);
+        }
+        const T *pd[2];
+        RowDivisor dd[2];
+        bool vd[2];
+        auto dst_rows = [&](int jt) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t j = (int64_t)jt * XD + prow + 64 * u;
+                vd[u] = j < Nd;
+                const int64_t jj = vd[u] ? j : 0;
+                pd[u] = pool_row(x0, P0, x1, P1, bi, b_rows[bi * Nd + jj], C);
+                dd[u] = row_divisor(nb[bi * Nd + jj]);
+            }
+        };
+        uint4 raw[4][RAW];                             // pieces in flight: dst rows 0 / 1, src rows 0 / 1
+        auto fetch = [&](int kt) {
+            const int64_t k = (int64_t)kt * XK + pg * 8;
+            const bool kin = k < C;                    // C % 8 == 0: a piece is inside or outside as a whole
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int h = 0; h < RAW; ++h) {
+                    raw[u][h] = (kin && vd[u]) ? *reinterpret_cast<const uint4 *>(pd[u] + k + h * (8 / RAW)) : make_uint4(0, 0, 0, 0);
+                    raw[2 + u][h] = (kin && vs[u]) ? *reinterpret_cast<const uint4 *>(ps[u] + k + h * (8 / RAW)) : make_uint4(0, 0, 0, 0);
                 }
-                const uint32_t col = (uint32_t)((align ? bi * Nd : 0) + j);
-                const unsigned long long key = ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col);
-                bestkey = key > bestkey ? key : bestkey;
+            }
+        };
+        // one piece: 8 token values -> xhat (bit-identical to x / norm) -> the two k-halves of its panel group
+        auto stage = [&](const uint4 (&rw)[RAW], const RowDivisor &d, bool valid, float *panel, int row) {
+            float f[8], o[8];
+            if constexpr (sizeof(T) == 4) {
+                f[0] = __uint_as_float(rw[0].x); f[1] = __uint_as_float(rw[0].y); f[2] = __uint_as_float(rw[0].z); f[3] = __uint_as_float(rw[0].w);
+                f[4] = __uint_as_float(rw[1].x); f[5] = __uint_as_float(rw[1].y); f[6] = __uint_as_float(rw[1].z); f[7] = __uint_as_float(rw[1].w);
+            } else {
+                const T *e = reinterpret_cast<const T *>(&rw[0]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = to_f32(e[j]);
+            }
+            if (!valid) {                              // rows past the list / past Nd: zero operands (never published)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+            } else if (all) {                          // some norm of the call is out of range: IEEE division throughout
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f[j] / d.n;
+            } else {
+                bool ok = true;
+                if constexpr (!std::is_same<T, __half>::value) {   // fp16 tokens are always in range (refine_kernel)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ok = ok && div_ok(f[j], d);
+                }
+                if (ok) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = div_by_row(f[j], d);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = f[j] / d.n;
+                }
+            }
+            // panel (pg, kh) holds channels 8 pg + kh + {0, 2, 4, 6} of a row: ascending k for the 4 MFMAs that read it
+            *reinterpret_cast<float4 *>(&panel[((pg * 2 + 0) * XP + row) * 4]) = make_float4(o[0], o[2], o[4], o[6]);
+            *reinterpret_cast<float4 *>(&panel[((pg * 2 + 1) * XP + row) * 4]) = make_float4(o[1], o[3], o[5], o[7]);
+        };
+
+        f32x16 acc[4];
+        float bestv = -INFINITY;
+        uint32_t besti = 0xffffffffu;
+        const int steps = (jt1 - jt0) * KT;
+        dst_rows(jt0);
+        fetch(0);
+        int kt = 0, jt = jt0;
+        for (int st = 0; st < steps; ++st) {
+            __syncthreads();                           // everybody has read the previous step's panels
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                stage(raw[u], dd[u], vd[u], sD, prow + 64 * u);
+                stage(raw[2 + u], ds[u], vs[u], sS, prow + 64 * u);
+            }
+            __syncthreads();
+            const bool wrap = kt + 1 == KT;
+            if (st + 1 < steps) {                      // next step's pieces fly behind this step's MFMAs
+                if (wrap) dst_rows(jt + 1);
+                fetch(wrap ? 0 : kt + 1);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 af[4];
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) af[ib] = *reinterpret_cast<const float4 *>(&sD[((g * 2 + kh) * XP + ib * 32 + l31) * 4]);
+                const float4 bf = *reinterpret_cast<const float4 *>(&sS[((g * 2 + kh) * XP + wave * 32 + l31) * 4]);
+                const float bv[4] = {bf.x, bf.y, bf.z, bf.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib) {
+                        const float av = e == 0 ? af[ib].x : e == 1 ? af[ib].y : e == 2 ? af[ib].z : af[ib].w;
+                        f32x16 c = acc[ib];
+                        if (kt == 0 && g == 0 && e == 0) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+                        }
+                        acc[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e], c, 0, 0, 0);
+                    }
+                }
+            }
+            if (wrap) {   // dst tile finished: fold this lane's 64 scores into its running (max, first argmax)
+                const int dst0 = jt * XD + 4 * kh;
+                const bool full = (int64_t)(jt + 1) * XD <= Nd;
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int d = dst0 + ib * 32 + (r & 3) + 8 * (r >> 2);
+                        const float sc = acc[ib][r];
+                        bool upd = !(sc <= bestv) && (bestv == bestv);   // greater, or the first NaN (torch.max)
+                        if (!full) upd = upd && (d < Nd);
+                        bestv = upd ? sc : bestv;
+                        besti = upd ? (uint32_t)d : besti;
+                    }
+                }
+                ++jt;
+                kt = 0;
+            } else {
+                ++kt;
             }
         }
-        if (bestkey) atomicMax(&best[row], bestkey);
+        const int64_t i = listed(wave * 32 + l31);
+        if (i >= 0 && besti != 0xffffffffu) {
+            const uint32_t col = besti + (align ? (uint32_t)(bi * Nd) : 0u);
+            atomicMax(&best[align ? i : l * Ns + i], ((unsigned long long)orderable(bestv) << 32) | (uint32_t)(~col));
+        }
     }
 }
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf, pairs, total;
+    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf_cnt, ovf, pairs, total;
     int64_t Ns_pad, Nd_pad, C64;
 };
 
@@ -978,6 +1180,7 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     L.amax = take((size_t)rows_out * 4);      // amax, cnt and flags are contiguous: cleared together
     L.cnt = take((size_t)rows_out * 4);
     L.flags = take(256);
+    L.ovf_cnt = take((size_t)B * 4);          // per-sample overflow-list lengths (inside the cleared range)
     L.cand = take((size_t)rows_out * CAP * 8);
     L.ovf = take((size_t)rows_out * 4);
     L.pairs = take((size_t)rows_out * CAP * 8);
@@ -1012,7 +1215,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     unsigned int *amax = (unsigned int *)(w + L.amax);
     int *cnt = (int *)(w + L.cnt), *flags = (int *)(w + L.flags);
     uint2 *cand = (uint2 *)(w + L.cand);
-    int *ovf_rows = (int *)(w + L.ovf);
+    int *ovf_rows = (int *)(w + L.ovf), *ovf_cnt = (int *)(w + L.ovf_cnt);
     uint2 *pairs = (uint2 *)(w + L.pairs);
     const int64_t rows_out = align ? Ns : B * Ns;
     VTM_REQUIRE(rows_out * CAP < (1ll << 31), "vtm_match_filtered: too many rows for the 32-bit candidate index");
@@ -1090,23 +1293,37 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     }
     {
         hipLaunchKernelGGL(survivors_kernel, dim3((unsigned)vtm::cdiv(rows_out, 256)), dim3(256), 0, s, rows_out, amax, cnt,
-                           cand, flags, ovf_rows, pairs, (const float *)na, B * Ns, (const float *)nb, B * Nd);
+                           cand, flags, ovf_cnt, ovf_rows, Ns, align, pairs, (const float *)na, B * Ns, (const float *)nb, B * Nd);
         // one thread per surviving pair; the count lives on the device, so a fixed grid strides over the list
         const dim3 grid((unsigned)std::min<int64_t>(vtm::cdiv(rows_out * 2, 256), 4096)), block(256);
         unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
-        const size_t lds = (size_t)C * sizeof(float);
+        // the escape: a fixed grid strides over the (device-side) lists of overflowed rows -- normally empty, then the
+        // workgroups leave at once; dst splits of >= 8 tiles so that a short list still spreads over the chip
+        const int xd_tiles = (int)vtm::cdiv(Nd, XD);
+        int xsplit = xd_tiles / 8;
+        xsplit = xsplit < 1 ? 1 : xsplit > 16 ? 16 : xsplit;
+        const int xtps = (int)vtm::cdiv(xd_tiles, xsplit);
+        xsplit = (int)vtm::cdiv(xd_tiles, xtps);
+        const dim3 xgrid((unsigned)(2 * vtm::device_cus()));
         switch (dtype) {
             case VTM_F32:
-                hipLaunchKernelGGL(refine_kernel<float>, grid, block, lds, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp, rows_out);
+                hipLaunchKernelGGL(refine_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
+                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
+                hipLaunchKernelGGL(exact_rows_kernel<float>, xgrid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
+                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt, ovf_rows, bp, xsplit, xtps);
                 break;
             case VTM_F16:
-                hipLaunchKernelGGL(refine_kernel<__half>, grid, block, lds, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp, rows_out);
+                hipLaunchKernelGGL(refine_kernel<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
+                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
+                hipLaunchKernelGGL(exact_rows_kernel<__half>, xgrid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
+                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt, ovf_rows, bp, xsplit, xtps);
                 break;
             default:
-                hipLaunchKernelGGL(refine_kernel<vtm_bf16>, grid, block, lds, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, ovf_rows, bp, rows_out);
+                hipLaunchKernelGGL(refine_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
+                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
+                hipLaunchKernelGGL(exact_rows_kernel<vtm_bf16>, xgrid, block, 0, s, (const vtm_bf16 *)x0, P0,
+                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt,
+                                   ovf_rows, bp, xsplit, xtps);
         }
     }
     if (int rc = vtm::launch_status("vtm_match_filtered")) return rc;

@@ -15,7 +15,8 @@ Differences that are design, not omissions:
   use merge mode "replace", so merged tokens are a row selection of [chunk tokens | anchor tokens]);
 * ``module.global_tokens`` stays on the device (the reference parks it on the CPU and syncs per block,
   patch.py:65,70,80,82);
-* the block generator is always a CPU generator (see utils.init_generator);
+* the block generator forks the CPU RNG state by default (utils.init_generator; `generator_device="device"` opts into the
+  reference's device rule);
 * ``attn1`` is evaluated from the module's own weights by the fused path (projection GEMMs fed through the composed
   merge map or as panel GEMMs, attention core = vtm_attention: no library GEMM on the default path), including the
   reference's PnP injection branch when ``utils/pnp_utils.py``-style control is registered on the module;
@@ -121,8 +122,11 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
     if downsample > args["max_downsample"]:                                        # patch.py:27,86-88
         return merge.do_nothing, merge.do_nothing, x
 
+    gmode = args.get("generator_device", None)
     if args["generator"] is None:                                                  # patch.py:29-33
-        args["generator"] = init_generator(x.device)
+        args["generator"] = init_generator(x.device, mode=gmode)
+    elif args["generator"].device != x.device and (gmode or GENERATOR_MODE_DEFAULT()) == "device":
+        args["generator"] = init_generator(x.device, fallback=args["generator"], mode=gmode)
 
     plan = MergePlan()
     plan.fsize = fsize
@@ -344,10 +348,20 @@ FUSED_PROJ = PROJ_MODE != "blas"                      # (tests toggle this to co
 # path everywhere, "blas" keeps the library GEMMs of rounds 1-2.
 
 
+def _proj_dtypes_ok(attn: torch.nn.Module, dtype) -> bool:
+    """All four projection weights (and the biases that exist) are of the tokens' dtype: the in-house projection kernels
+    read raw 16-bit words and take the dtype from the TOKENS (a mixed-dtype module -- an fp32 to_out next to fp16
+    to_q / to_k / to_v, say -- would otherwise be packed and multiplied as garbage instead of leaving the fused path)."""
+    for lin in (attn.to_q, attn.to_k, attn.to_v, _out_linear(attn)):
+        if lin.weight.dtype != dtype or (getattr(lin, "bias", None) is not None and lin.bias.dtype != dtype):
+            return False
+    return True
+
+
 def fused_projections_ok(attn: torch.nn.Module, x: torch.Tensor) -> bool:
     """The gather-fused projection GEMM (vtm_linear_rows) takes fp16 / bf16 tokens with C % 32 == 0."""
     if not FUSED_PROJ or x.dtype not in (torch.float16, torch.bfloat16) or x.shape[-1] % 32 \
-            or attn.to_q.weight.dtype != x.dtype:
+            or not _proj_dtypes_ok(attn, x.dtype):
         return False
     return PROJ_MODE == "rows" or (PROJ_MODE == "auto" and x.shape[-1] <= 320)
 
@@ -356,7 +370,7 @@ def panel_projections_ok(attn: torch.nn.Module, x: torch.Tensor) -> bool:
     """The panel-GEMM projections (vtm_gather_panels / vtm_layernorm_panels + vtm_linear_panels): fp16 / bf16 tokens,
     C % 64 == 0, no bias on to_v (V^T = W_v X^T is computed with the roles of the operands swapped)."""
     return (PROJ_MODE in ("auto", "panels") and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 64 == 0
-            and attn.to_q.weight.dtype == x.dtype and getattr(attn.to_v, "bias", None) is None)
+            and _proj_dtypes_ok(attn, x.dtype) and getattr(attn.to_v, "bias", None) is None)
 
 
 def _panel_weight(lin: torch.nn.Module):
@@ -608,7 +622,7 @@ def fused_cross_ok(norm: torch.nn.Module, attn: torch.nn.Module, x: torch.Tensor
             and type(norm) is torch.nn.LayerNorm and len(norm.normalized_shape) == 1
             and norm.normalized_shape[0] == x.shape[-1] and x.shape[-1] % 64 == 0 and x.shape[1] % 8 == 0
             and (norm.weight is None or norm.weight.dtype == x.dtype) and (norm.bias is None or norm.bias.dtype == x.dtype)
-            and attn.to_q.weight.dtype == x.dtype and fused_attention_ok(attn, x, self_attn=False))
+            and _proj_dtypes_ok(attn, x.dtype) and fused_attention_ok(attn, x, self_attn=False))
 
 
 def cross_attention(attn: torch.nn.Module, x: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor],
@@ -857,18 +871,36 @@ def hook_tome_module(module: torch.nn.Module):
     """vidtome/patch.py:215-231: lazily create the block generator; all blocks fork the same state so their
     draws stay in lock-step within one pass."""
     def hook(module, args):
+        gmode = module._tome_info["args"].get("generator_device", None)
         if not hasattr(module, "generator"):
-            module.generator = init_generator(args[0].device)
+            module.generator = init_generator(args[0].device, mode=gmode)
+        elif module.generator.device != args[0].device and (gmode or GENERATOR_MODE_DEFAULT()) == "device":
+            # patch.py:221-224: the model moved to another device -> fork that device's state (opt-in stream only: the
+            # default CPU stream does not depend on where the tensors live)
+            module.generator = init_generator(args[0].device, fallback=module.generator, mode=gmode)
         return None
 
     module._tome_info["hooks"].append(module.register_forward_pre_hook(hook))
 
 
+def GENERATOR_MODE_DEFAULT() -> str:
+    from . import utils
+    return utils.GENERATOR_MODE
+
+
 def apply_patch(model: torch.nn.Module, local_merge_ratio: float = 0.9, merge_global: bool = False,
                 global_merge_ratio=0.8, max_downsample: int = 2, seed: int = 123, batch_size: int = 2,
                 include_control: bool = False, align_batch: bool = False, target_stride: int = 4,
-                global_rand=0.5):
-    """vidtome/patch.py:234-334 -- same arguments, defaults, return value and errors."""
+                global_rand=0.5, *, generator_device: Optional[str] = None):
+    """vidtome/patch.py:234-334 -- same arguments, defaults, return value and errors.
+
+    One keyword-only addition: ``generator_device`` = None (the process default, VIDTOME_GENERATOR, "cpu" unless set) |
+    "cpu" | "device".  "cpu": the block generators fork the CPU RNG state wherever the model lives -- the draw stream of the
+    reference's CPU path (the parity oracle).  "device": the reference's own rule (vidtome/utils.py:18-30, patch.py:31-32,
+    221-224): on a GPU they fork ``torch.cuda.get_rng_state()`` and draw on the device generator (re-forked when the model
+    changes device), which reproduces a GPU run of the reference draw for draw at the price of a host read-back per draw."""
+    if generator_device not in (None, "cpu", "device"):
+        raise ValueError(f"generator_device must be None, 'cpu' or 'device', got {generator_device!r}")
     _lib.lib()   # fail loudly right here if the HIP library is missing: there is no fallback
     remove_patch(model)                                                            # patch.py:277
     is_diffusers = isinstance_str(model, "DiffusionPipeline") or isinstance_str(model, "ModelMixin")
@@ -901,6 +933,7 @@ def apply_patch(model: torch.nn.Module, local_merge_ratio: float = 0.9, merge_gl
                 "local_merge_ratio": local_merge_ratio,
                 "global_rand": global_rand,
                 "target_stride": target_stride,
+                "generator_device": generator_device,          # (not a reference key; see the docstring)
             },
         }
         hook_tome_model(diffusion_model)
@@ -937,6 +970,10 @@ def remove_patch(model: torch.nn.Module):
                 info["hooks"].clear()
             if module.__class__.__name__ == "ToMeBlock":
                 module.__class__ = module._parent
+            # the fused path's derived copies of the weights (panel-layout packs, stacked q|k weights): ~0.4-0.5 GB of fp16
+            # for SD-1.5; they are rebuilt on demand if the model is patched again
+            module.__dict__.pop("_vtm_packed", None)
+            module.__dict__.pop("_vtm_wcache", None)
     _lib.release_workspaces()            # the cached scratch buffers of the patched path (re-created on demand)
     return roots[-1]                     # the reference returns its loop variable: the last tree walked
 

@@ -141,18 +141,56 @@ class SiteUNet(ModelMixin):
         self._tome_info["size"] = latent_hw
 
 
+DATA_REGIMES = {
+    # name: (frame_noise, flat fraction, duplicate fraction) -- SURVEY.md 8d names the first two; `corr05` is what rounds
+    # 1-3 measured; `flat25` / `dup` load the matcher's candidate logic
+    "n01": (None, 0.0, 0.0),        # h ~ N(0, 1), no cross-frame correlation: one candidate per row, low cosines
+    "corr01": (0.1, 0.0, 0.0),      # h[f] = base + 0.1 N(0, 1): realistic high cross-frame cosine (~0.99)
+    "corr05": (0.5, 0.0, 0.0),      # h[f] = base + 0.5 N(0, 1) (cosine ~0.8 between the frames of a position)
+    "flat25": (0.5, 0.25, 0.0),     # corr05 + a flat region: a quarter of the positions (every frame) hold ONE content vector
+                                    # + 2 % noise (a sky, a wall): ~N/4 dst rows per frame inside every such row's window
+    "dup": (0.5, 0.0, 0.2),         # corr05 + exact copies: a fifth of the positions repeat another position's tokens bit for
+                                    # bit in every frame (what anchor updates do to the global level, patch.py:80)
+}
+
+
+def regime_tokens(regime: str, batch: int, frames: int, N: int, C: int, g: torch.Generator,
+                  gb: torch.Generator = None) -> torch.Tensor:
+    """(batch, frames, N, C) fp32 tokens of one data regime (DATA_REGIMES); `gb` draws the clip content (base, flat
+    vector, duplicate pattern), `g` the per-frame noise."""
+    noise, flat, dup = DATA_REGIMES[regime]
+    gb = g if gb is None else gb
+    if noise is None:
+        return torch.randn(batch, frames, N, C, generator=g)
+    base = torch.randn(batch, 1, N, C, generator=gb)
+    x = base + noise * torch.randn(batch, frames, N, C, generator=g)
+    if flat > 0:
+        nf = int(N * flat)
+        content = torch.randn(batch, 1, 1, C, generator=gb)
+        x[:, :, :nf] = content + 0.02 * torch.randn(batch, frames, nf, C, generator=g)
+    if dup > 0:
+        nd = int(N * dup)
+        src = torch.randint(nd, N, (nd,), generator=gb)
+        x[:, :, :nd] = x[:, :, src]
+    return x
+
+
 def synthetic_hidden(site: Site, batch: int, frames: int, latent_hw: Tuple[int, int], dtype, device,
-                     seed: int, frame_noise: float = 0.5, clip_seed: int = None) -> torch.Tensor:
+                     seed: int, frame_noise: float = 0.5, clip_seed: int = None, regime: str = None) -> torch.Tensor:
     """(B*F, N, C) hidden states: per-sample base + frame_noise * N(0,1) per frame (frames of a clip are
     correlated).  Batch layout [uncond frames | cond frames] like generate.py:245.  With ``clip_seed`` the base comes
     from that seed and only the frame noise from ``seed``: different ``seed``s are then different CHUNKS OF ONE CLIP
-    (same content, independent frames) -- what consecutive chunks of a video look like to the global level."""
+    (same content, independent frames) -- what consecutive chunks of a video look like to the global level.
+    ``regime`` selects one of DATA_REGIMES instead (``corr05`` = the default arithmetic, same random stream)."""
     h, w = latent_hw[0] // site.downsample, latent_hw[1] // site.downsample
     N = h * w
     g = torch.Generator().manual_seed(seed)
     gb = g if clip_seed is None else torch.Generator().manual_seed(clip_seed)
-    base = torch.randn(batch, 1, N, site.channels, generator=gb)
-    x = base + frame_noise * torch.randn(batch, frames, N, site.channels, generator=g)
+    if regime is not None and regime != "corr05":
+        x = regime_tokens(regime, batch, frames, N, site.channels, g, gb)
+    else:
+        base = torch.randn(batch, 1, N, site.channels, generator=gb)
+        x = base + frame_noise * torch.randn(batch, frames, N, site.channels, generator=g)
     return x.reshape(batch * frames, N, site.channels).to(device=device, dtype=dtype)
 
 
@@ -162,7 +200,7 @@ def run_segment_pass(unet: SiteUNet, hiddens: List[torch.Tensor]) -> List[torch.
     outs = []
     for blk, h in zip(unet.blocks, hiddens):
         if not hasattr(blk, "generator"):
-            blk.generator = patch.init_generator(h.device)        # what hook_tome_module does
+            blk.generator = patch.init_generator(h.device, mode=blk._tome_info["args"].get("generator_device"))   # what hook_tome_module does
         outs.append(patch.self_attention_segment(blk, h))
     return outs
 
@@ -189,7 +227,7 @@ class ClipStream:
 
     def __init__(self, unet: "SiteUNet", site_list: List[Site], batch: int, frames: int, latent_hw: Tuple[int, int], dtype,
                  device, n_sets: int = 3, chunks_per_step: int = 8, same_chunk: bool = False, rank: int = 0,
-                 reseed: bool = True, sets=None, cond: torch.Tensor = None):
+                 reseed: bool = True, sets=None, cond: torch.Tensor = None, regime: str = None):
         self.unet, self.site_list = unet, site_list
         self.cond = cond                      # not None: full-block passes (run_block_pass)
         self.K = 1 if same_chunk else max(2, n_sets)
@@ -201,10 +239,10 @@ class ClipStream:
 
         def make(j):
             if same_chunk:
-                return [synthetic_hidden(s, batch, frames, latent_hw, dtype, device, seed=1234 + 97 * rank + i)
+                return [synthetic_hidden(s, batch, frames, latent_hw, dtype, device, seed=1234 + 97 * rank + i, regime=regime)
                         for i, s in enumerate(site_list)]
             return [synthetic_hidden(s, batch, frames, latent_hw, dtype, device, seed=1234 + 97 * j + i,
-                                     clip_seed=4321 + i) for i, s in enumerate(site_list)]
+                                     clip_seed=4321 + i, regime=regime) for i, s in enumerate(site_list)]
         self.sets = {j: make(j) for j in want}
 
     def _first_chunk(self, j: int) -> None:

@@ -14,16 +14,36 @@ def isinstance_str(x: object, cls_name: str) -> bool:
     return any(_cls.__name__ == cls_name for _cls in x.__class__.__mro__)
 
 
-def init_generator(device: torch.device, fallback: torch.Generator = None) -> torch.Generator:
+# Which RNG stream the block generators fork.  "cpu" (default): the CPU state, whatever device the model is on -- the draw
+# stream of the reference's CPU path, which is the parity oracle.  "device": the reference's own rule (vidtome/utils.py:18-30)
+# -- the CUDA generator's state when the model is on a GPU -- so that a run of the REFERENCE ON A GPU can be reproduced draw
+# for draw (one host read-back per draw).  Chosen per model with apply_patch(..., generator_device=...) or process-wide with
+# VIDTOME_GENERATOR=cpu|device.
+import os
+
+GENERATOR_MODE = os.environ.get("VIDTOME_GENERATOR", "cpu")
+
+
+def init_generator(device: torch.device, fallback: torch.Generator = None, mode: str = None) -> torch.Generator:
     """vidtome/utils.py:18-30: fork the current default RNG state into a private generator.
 
-    The reference forks the *device's* generator (the CUDA generator when the model is on a GPU).  The
-    parity oracle is the reference's CPU path, and the draws (one randint per local level, one rand per
-    global merge) are host-side control decisions, so this implementation always forks the CPU state:
-    ``torch.Generator('cpu').set_state(torch.get_rng_state())``.  That keeps the draw stream identical to
-    the reference CPU path and avoids a device sync per draw.
-    """
-    return torch.Generator(device="cpu").set_state(torch.get_rng_state())
+    ``mode`` "cpu" (default, see GENERATOR_MODE): always ``torch.Generator('cpu').set_state(torch.get_rng_state())`` --
+    the draws (one randint per local level, one rand per global merge) are host-side control decisions and the parity
+    oracle is the reference's CPU path, so the stream stays identical to it and no draw needs a device sync.
+    ``mode`` "device": the reference's behaviour to the letter -- CPU tensors fork the CPU state, CUDA tensors fork
+    ``torch.cuda.get_rng_state()`` into a generator on that device, any other device type keeps ``fallback`` (or forks
+    the CPU state)."""
+    mode = GENERATOR_MODE if mode is None else mode
+    if mode not in ("cpu", "device"):
+        raise ValueError(f"generator mode must be 'cpu' or 'device', got {mode!r}")
+    if mode == "cpu" or device is None:
+        return torch.Generator(device="cpu").set_state(torch.get_rng_state())
+    device = torch.device(device)
+    if device.type == "cpu":
+        return torch.Generator(device="cpu").set_state(torch.get_rng_state())
+    if device.type == "cuda":
+        return torch.Generator(device=device).set_state(torch.cuda.get_rng_state())
+    return fallback if fallback is not None else init_generator(torch.device("cpu"), mode=mode)
 
 
 def join_frame(x: torch.Tensor, fsize: int) -> torch.Tensor:
