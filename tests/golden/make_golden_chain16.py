@@ -9,7 +9,7 @@ against the oracle and against attention.npz, never against a recorded BLOCK out
 
 These fixtures close that: the reference's `apply_patch` + `ToMeBlock.forward` + `sa_forward` run -- in fp32, the CPU path
 north_star names as the oracle -- on a stand-in UNet with head dims / channel counts the HIP attention and projection
-kernels are instantiated for (d = 40, 64, 80; C = 80, 128, 640), whose weights, hidden states AND norm1 outputs lie on the
+kernels are instantiated for (d = 40, 64, 80; C = 160, 128, 320), whose weights, hidden states AND norm1 outputs lie on the
 fp16 grid: the model an fp16 run holds (norm1 = LayerNorm computed in fp32, rounded once -- what vtm_layernorm computes,
 tested against fp32 PyTorch on its own).  Everything downstream of norm1 is the unmodified reference in fp32.
 
@@ -33,16 +33,17 @@ sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402  (imports the reference)
 
 CFGS = [
-    # d = 40, C = 80: gather-fed projections (vtm_linear_rows), live + compacted queries, both coin outcomes, an F = 1 chunk
-    dict(name="chain16_cfg_f4_d40", B=2, C=80, heads=2, H=6, W=6, chunk_frames=[4, 4, 4, 1, 4, 4], reset_before=[3],
+    # d = 40, C = 160: gather-fed projections (vtm_linear_rows), live + compacted queries, both coin outcomes, an F = 1 chunk
+    dict(name="chain16_cfg_f4_d40", B=2, C=160, heads=4, H=6, W=6, chunk_frames=[4, 4, 4, 1, 4, 4], reset_before=[3],
          local_ratio=0.5, merge_global=True, global_ratio=0.5, align=False, injection=None, t=500,
          rng_seed=2, data_seed=7001, frame_noise=0.6),
     # d = 64 (SD-2.1's head dim), PnP batch 3: aligned matching, shared-probability attention
     dict(name="chain16_pnp_f4_d64", B=3, C=128, heads=2, H=6, W=6, chunk_frames=[4, 4, 4],
          local_ratio=0.6, merge_global=True, global_ratio=0.6, align=True, injection=[500], t=500,
          rng_seed=6, data_seed=7002, frame_noise=0.6),
-    # d = 80, C = 640: the panel-GEMM projection path, two local levels (F = 8)
-    dict(name="chain16_cfg_f8_d80", B=2, C=640, heads=8, H=6, W=6, chunk_frames=[8, 8, 3],
+    # d = 80 (SD-1.5's mid blocks), two local levels (F = 8); C = 320 so that the test can also force the panel-GEMM
+    # projection path (C % 64 == 0), which SD-1.5 takes at C >= 640
+    dict(name="chain16_cfg_f8_d80", B=2, C=320, heads=4, H=4, W=4, chunk_frames=[8, 8, 3],
          local_ratio=0.5, merge_global=True, global_ratio=0.5, align=False, injection=None, t=500,
          rng_seed=3, data_seed=7003, frame_noise=0.6),
 ]
@@ -64,7 +65,10 @@ def disagreement(plain, other):
 
 
 def main():
+    only = sys.argv[1:]
     for base in CFGS:
+        if only and base["name"] not in only:
+            continue
         for attempt in range(400):
             cfg = dict(base, data_seed=base["data_seed"] + 1000 * attempt, fp16_grid=True, round_norm1=1)
             plain, w, names, rng_state = mg.run_chain(torch.float32, cfg, weights_seed=2024)
@@ -83,8 +87,9 @@ def main():
             raise RuntimeError("could not screen " + base["name"])
         data = {"cfg_json": json.dumps(cfg), "rng_state": rng_state.numpy(), "block_names": np.array(names),
                 "screen_disagreement": np.array(worst)}
-        for k, v in w.items():
-            data["w/" + k] = v.numpy()
+        for k, v in w.items():          # on the fp16 grid: stored as fp16
+            assert torch.equal(v, v.half().float()), k
+            data["w/" + k] = v.half().numpy()
         for ck, ch in enumerate(plain):
             data[f"c{ck}/latent_shape"] = np.array(ch["latent"].shape)
             for r in ch["records"]:

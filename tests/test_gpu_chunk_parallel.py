@@ -70,7 +70,7 @@ def _sequential(sites_list, steps, latent, dev, rng_state, oracle=None):
                 if oracle is not None:
                     from test_gpu_parity import _block_rows_vs_oracle
                     for bi, blk in enumerate(unet.blocks):
-                        _block_rows_vs_oracle(oracle, blk, seen[id(blk)], hid[bi], outs[bi], F, n_rows=96, seed=ck)
+                        _block_rows_vs_oracle(oracle, blk, seen[id(blk)], hid[bi], outs[bi], F, n_rows=96, seed=ck, out_ulp=True)
                 gts = [blk.global_tokens.clone() for blk in unet.blocks]
                 out[(s, ck)] = ([o.clone() for o in outs], gts)
             vidtome_amd.update_patch(unet, global_tokens=None)                 # generate.py:233-236

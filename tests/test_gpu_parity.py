@@ -642,8 +642,10 @@ def test_chain_golden_gpu(L, name):
     assert all(b.__class__.__name__ == "BasicTransformerBlock" for b in blocks)
 
 
-@pytest.mark.parametrize("name", ["chain16_cfg_f4_d40", "chain16_pnp_f4_d64", "chain16_cfg_f8_d80"])
-def test_default_fp16_path_vs_reference_chain(L, name):
+@pytest.mark.parametrize("name,proj", [("chain16_cfg_f4_d40", "auto"), ("chain16_pnp_f4_d64", "auto"),
+                                       ("chain16_pnp_f4_d64", "panels"), ("chain16_cfg_f8_d80", "auto"),
+                                       ("chain16_cfg_f8_d80", "panels")])
+def test_default_fp16_path_vs_reference_chain(L, name, proj, monkeypatch):
     """The DEFAULT path of an fp16 model -- gather-fed projection GEMMs (C <= 320) / panel GEMMs (C = 640), live and
     compacted queries, the fp16 attention core -- against BLOCK OUTPUTS RECORDED FROM THE REFERENCE
     (tests/golden/make_golden_chain16.py: the reference's apply_patch + ToMeBlock.forward + sa_forward on its CPU fp32 path,
@@ -656,11 +658,12 @@ def test_default_fp16_path_vs_reference_chain(L, name):
     from vidtome_amd import pnp
     from standin import Pipe, StandInUNet, load_block_weights
 
+    monkeypatch.setattr(vpatch, "PROJ_MODE", proj)      # auto: gather-fed GEMMs (C <= 320); panels: the C >= 640 sites' path
     cfg, z = load_chain(name)
     unet = load_block_weights(StandInUNet(cfg["C"], cfg["heads"]), z, DEV, torch.float16)
     for k in z.files:                      # the weights ARE fp16 values: the fp16 model is the reference's model
         if k.startswith("w/up_blocks"):
-            assert np.array_equal(z[k], z[k].astype(np.float16).astype(np.float32)), k
+            assert z[k].dtype == np.float16, k
     pipe = Pipe(unet)
     if cfg["injection"] is not None:
         pnp.register_attention_control(pipe, cfg["injection"], cfg["B"])
@@ -706,7 +709,7 @@ def test_default_fp16_path_vs_reference_chain(L, name):
     finally:
         for n in calls:
             setattr(L, n, orig[n])
-    assert calls["linear_rows" if cfg["C"] <= 320 else "linear_panels"] > 0, calls
+    assert calls["linear_rows" if proj == "auto" else "linear_panels"] > 0, calls
     vidtome_amd.remove_patch(unet)
 
 
@@ -1436,11 +1439,15 @@ def _site_pass_checks(unet, sites_list, hiddens, B, F, expected_M):
     return outs, plans
 
 
-def _block_rows_vs_oracle(oracle, blk, plan, hidden, out, fsize, share=1, n_rows=192, seed=0):
+def _block_rows_vs_oracle(oracle, blk, plan, hidden, out, fsize, share=1, n_rows=192, seed=0, out_ulp=False):
     """Block outputs at FULL size against the oracle on SAMPLED token positions: for position i of the joined chunk the
     reference is  to_out(softmax(q K^T) V)[inv[i]] + hidden[i]  with q / K / V projected (fp32) from the merged tokens the
     plan selects, the attention rows by oracle.attention_qkv (double accumulation); `share` > 1 = PnP shared
-    probabilities (q / k of the source sample for every sample, pnp_utils.py:57-67).  1e-3 of the output scale."""
+    probabilities (q / k of the source sample for every sample, pnp_utils.py:57-67).  1e-3 of the output scale.  With
+    `out_ulp` (cfg-4's 18 432-key chunks, where a few rows have a sharply peaked softmax): all but 1e-4 of the sampled
+    elements within 1e-3 and every one within 2e-3 -- tools/diag/cfg4_err.py shows 2 of 164 000 elements at 1.3e-3 of the
+    scale (p99.9 = 3.7e-4), identically for an fp16 and an fp32 model: the fp16 rounding of q / k of a row whose largest
+    logit is tens of log2 units, not the projections."""
     from vidtome_amd.utils import join_frame
     a = blk.attn1
     f32 = lambda t: t.detach().float().cpu().numpy()
@@ -1457,7 +1464,12 @@ def _block_rows_vs_oracle(oracle, blk, plan, hidden, out, fsize, share=1, n_rows
     o = oracle.attention_qkv(np.ascontiguousarray(q), np.ascontiguousarray(src(k)), v, a.heads)
     hj, oj = f32(join_frame(hidden, fsize)), f32(join_frame(out, fsize))
     ref = o @ wo.T + bo + hj[:, idx]
-    err = np.abs(oj[:, idx] - ref).max()
+    diff = np.abs(oj[:, idx] - ref)
+    if out_ulp:
+        scale = max(1.0, np.abs(ref).max())
+        assert (diff > 1e-3 * scale).mean() < 1e-4 and diff.max() < 2e-3 * scale, (diff.max(), scale)
+        return
+    err = diff.max()
     assert err < 1e-3 * max(1.0, np.abs(ref).max()), err
 
 

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -s -k "match_filtered or planted or default_fp16_path or device_generator or chain_golden" > $O/tests_new.log 2>&1; echo "tests(new) rc=$?"; tail -5 $O/tests_new.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "${KSEL:-match_filtered or planted or default_fp16_path or device_generator or chain_golden}" > $O/tests_new.log 2>&1; echo "tests(new) rc=$?"; tail -5 $O/tests_new.log
 grep -E "filtered ms / exact ms|worst block-output" $O/tests_new.log
 timeout 300 python -m pytest tests/test_gpu_chunk_parallel.py -m gpu -q -x -k "cfg4" > $O/tests_cfg4.log 2>&1; echo "tests(cfg4) rc=$?"; tail -3 $O/tests_cfg4.log
 timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log

@@ -172,6 +172,9 @@ struct SplitArgs {   // one operand: gathered rows, their norms (out), the panel
     float *norms;
     uint4 *out_hi, *out_lo;
     int64_t n_pad;
+    // partial-sum pruning (filter_kernel): the norm of the hi operand's channels >= `cut`, per row (src operand) or as
+    // the maximum over every 128-row tile (dst operand); nullptr = not wanted
+    float *rest, *tile_rest;
 };
 
 #ifndef VTM_PREP_PIECES
@@ -189,8 +192,10 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
                                                     const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
                                                     SplitArgs A0, SplitArgs A1, int64_t C_pad,
                                                     uint32_t *__restrict__ zero, int64_t zero_words,
-                                                    unsigned long long *__restrict__ best, int64_t nbest) {
+                                                    unsigned long long *__restrict__ best, int64_t nbest, int64_t cut) {
     static_assert(sizeof(T) == 2 || sizeof(T) == 4, "element size");
+    static_assert(PREP_WAVES % 2 == 0, "a 128-row tile is two waves of one workgroup");
+    __shared__ float wave_rest[PREP_WAVES];
     constexpr int EPP = 16 / (int)sizeof(T);           // elements per 16-byte piece (8 for the 16-bit types, 4 for fp32)
     __shared__ __attribute__((aligned(16))) char slab[PREP_WAVES][64 * PREP_STRIDE];
     const int64_t G = C_pad / 8;
@@ -266,6 +271,7 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
     uint4 *__restrict__ out_hi = in_range ? A.out_hi + (b * G) * n_pad + i : nullptr;
     uint4 *__restrict__ out_lo = (in_range && A.out_lo) ? A.out_lo + (b * G) * n_pad + i : nullptr;
     constexpr int PPG = 8 / EPP;                                        // pieces per 8-channel panel group (1 or 2)
+    float rest = 0.0f;                                                  // sum of hi^2 over the channels >= cut
     issue(0);
     for (int c = 0; c < nchunks; ++c) {
         to_lds();
@@ -293,6 +299,10 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
             }
             if (!real) vh = vl = make_uint4(0, 0, 0, 0);               // padding rows: all-zero operands
             const int64_t g = ((int64_t)c * PREP_PIECES + col) / PPG;
+            if (g * 8 >= cut) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rest = __builtin_fmaf((float)ph[e], (float)ph[e], rest);
+            }
             if (in_range) {
                 out_hi[g * n_pad] = vh;
                 if (out_lo) out_lo[g * n_pad] = vl;
@@ -304,6 +314,18 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
             out_hi[g * n_pad] = make_uint4(0, 0, 0, 0);
             if (out_lo) out_lo[g * n_pad] = make_uint4(0, 0, 0, 0);
         }
+    // rest norms for the filter's partial-sum pruning, rounded UP a little (1 + 2^-16 each: the Cauchy-Schwarz bound must
+    // also cover the fp32 rounding of this sum and of the MFMA's own accumulation, ~1e-6 relative).  Non-finite values
+    // (bad rows) make every comparison against them false or true-forever; such calls are recomputed exactly anyway.
+    const float rnorm = real ? __builtin_sqrtf(rest) * (1.0f + 0x1p-16f) : 0.0f;
+    if (in_range && A.rest) A.rest[b * n_pad + i] = rnorm;
+    float wm = rnorm;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+    if (lane == 0) wave_rest[wave] = wm;
+    __syncthreads();
+    if (in_range && A.tile_rest && (threadIdx.x & 127) == 0)            // n_pad is a multiple of 256: tiles do not straddle
+        A.tile_rest[(b * n_pad + i) / 128] = fmaxf(wave_rest[wave], wave_rest[wave + 1]);
 }
 
 // ---- filter: approximate scores on the fp16 MFMA, candidate collection ----
@@ -311,7 +333,8 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const uint4 *__restrict__ ah, const uint4 *__restrict__ al, const uint4 *__restrict__ bh,
     const uint4 *__restrict__ bl, int64_t Ns, int64_t Nd, int64_t Ns_pad, int64_t Nd_pad, int64_t C_pad, int align,
     int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split, int total_src_tiles, int patch_tiles,
-    unsigned int *__restrict__ amax, int *__restrict__ cnt, uint2 *__restrict__ cand, int cand_rows, int *__restrict__ flags) {
+    unsigned int *__restrict__ amax, int *__restrict__ cnt, uint2 *__restrict__ cand, int cand_rows, int *__restrict__ flags,
+    const float *__restrict__ rest_a, const float *__restrict__ rest_bt, int KP) {
     // dst tile of one step: 8 panels x 128 rows x 16 B, hi and lo, double-buffered: 2 x 2 x 16 KiB
     __shared__ __attribute__((aligned(16))) uint4 sA[2][DST_LO ? 2 : 1][8 * FBD];
 
@@ -425,6 +448,17 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     constexpr float WS = WINDOW * SCALE * SCALE;
     float runmax[2], cv[2][4];
     uint32_t ci[2][4];
+    // ---- partial-sum pruning ----------------------------------------------------------------------------------
+    // After KP of the KT channel steps of a dst tile the score of a pair is  partial + sum over the remaining channels
+    // <= partial + |a_rest| |b_rest|  (Cauchy-Schwarz on the fp16 hi operands themselves: rest_a per src row, rest_bt =
+    // the largest |b_rest| of the tile, both from prep_operand).  A 32 x 32 block none of whose pairs can still come
+    // within the window of its row's running maximum will neither produce a candidate nor raise a maximum, so its
+    // remaining MFMAs are skipped (`live` bit per accumulator block; the loads and the barriers of the loop go on, the
+    // matrix pipe -- and its power -- go to the SIMD's other wave).  Frames of a video are correlated: a src row has a
+    // handful of strong matches, and >= 90 % of the blocks die at 60 % depth.  Exact: the skipped blocks hold partial
+    // sums that are below the threshold themselves, so collect_tile ignores them like any other low score.
+    float rest_l[2];
+    uint32_t live = 0xffu;
     // candidate lists are slot-major, [slot][row] (cand_rows rows): the first entries of neighbouring rows -- all that most
     // rows ever have -- share cache lines for the lanes of survivors_kernel; 32-bit index (the launcher checks the size)
     // The row's list is full: the row goes to exact_rows_kernel whatever else is found, so it stops collecting -- +inf
@@ -444,6 +478,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         // start from what other workgroups already found for this row: fewer early candidates
         runmax[sb] = srow < Ns ? from_orderable(amax[out_row0 + srow]) * (SCALE * SCALE)
                                : INFINITY;   // padding rows (all-zero operands) never collect anything
+        rest_l[sb] = rest_a ? rest_a[(int64_t)bi * Ns_pad + srow] : 0.0f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             cv[sb][e] = -INFINITY;
@@ -543,6 +578,26 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                 if (rm > rm_in) atomicMax(&amax[out_row0 + srow0 + sb * 32 + l31], orderable(rm * INV_S2));   // (+inf: the list is full)
             }
         }
+    };
+
+    [[maybe_unused]] auto prune_check = [&](int jt) -> uint32_t {
+        const float rb = rest_bt[(int64_t)bi * nd_tiles + jt];             // wave-uniform
+        uint32_t mask = 0;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            // a pair can still matter iff partial + rest_a * rest_b >= running max - window
+            const float need = runmax[sb] - WS - rest_l[sb] * rb;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const f32x16 &v = acc[ib][sb];
+                float q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = vmax2(vmax3(v[4 * k], v[4 * k + 1], v[4 * k + 2]), v[4 * k + 3]);
+                const float gm = vmax2(vmax3(q[0], q[1], q[2]), q[3]);
+                if (__any(gm >= need)) mask |= 1u << (sb * 4 + ib);
+            }
+        }
+        return mask;
     };
 
 #if VTM_FILTER_PRODUCTS > 1 || defined(VTM_FILTER_PHASED)
@@ -730,12 +785,16 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int sb = j >> 2, ib = j & 3;
-                f32x16 c = acc[ib][sb];
-                if constexpr (FIRST) {
+                bool alive = true;                   // (wave-uniform: a scalar bit test; see "partial-sum pruning")
+                if constexpr (!FIRST) alive = (live & (1u << j)) != 0u;
+                if (alive) {
+                    f32x16 c = acc[ib][sb];
+                    if constexpr (FIRST) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) c[r] = 0.0f;   // folds into the MFMA's zero C operand
+                        for (int r = 0; r < 16; ++r) c[r] = 0.0f;   // folds into the MFMA's zero C operand
+                    }
+                    acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], __builtin_bit_cast(h16x8, rb[s][sb][0]), c, 0, 0, 0);
                 }
-                acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ib], __builtin_bit_cast(h16x8, rb[s][sb][0]), c, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 4) {
 #ifndef VTM_EXP_NOLDSREAD
@@ -776,12 +835,16 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         __syncthreads();
 #endif
         group(std::integral_constant<int, 3>{}, std::false_type{});
+        if (kt + 1 == KP) live = prune_check(jt);      // (KP >= KT: pruning is off)
 #ifdef VTM_EXP_NOWRAP
         if (wrap && jt < 0) collect_tile(jt, std::true_type{});
 #else
-        if (wrap) collect_tile(jt, std::true_type{});
+        if (wrap && live) collect_tile(jt, std::true_type{});
 #endif
-        if (wrap) ++jt;
+        if (wrap) {
+            ++jt;
+            live = 0xffu;
+        }
         kt = kt1;
         pb = pbn;
         pa1 = pa2;
@@ -1159,7 +1222,7 @@ __global__ __launch_bounds__(256, 2) void exact_rows_kernel(
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf_cnt, ovf, pairs, total;
+    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf_cnt, ovf, pairs, rest_a, rest_bt, total;
     int64_t Ns_pad, Nd_pad, C64;
 };
 
@@ -1184,6 +1247,8 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     L.cand = take((size_t)rows_out * CAP * 8);
     L.ovf = take((size_t)rows_out * 4);
     L.pairs = take((size_t)rows_out * CAP * 8);
+    L.rest_a = take((size_t)B * L.Ns_pad * 4);
+    L.rest_bt = take((size_t)B * (L.Nd_pad / FBD) * 4);
     L.total = o;
     return L;
 }
@@ -1221,11 +1286,22 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
     VTM_REQUIRE(rows_out * CAP < (1ll << 31), "vtm_match_filtered: too many rows for the 32-bit candidate index");
 
     VTM_REQUIRE(dtype == VTM_F32 || dtype == VTM_F16 || dtype == VTM_BF16, "vtm_match_filtered: bad dtype");
+    // partial-sum pruning: check after KP of the KT channel steps; off for short rows and for the 2- / 3-product
+    // builds (their lo products are not covered by the hi rest norms)
+    const int KT = (int)(L.C64 / FBK);
+    int KP = (VTM_FILTER_PRODUCTS == 1 && KT >= 4) ? (2 * KT + 2) / 5 : 0;   // 40 % depth (profiles/r04_kp_sweep.txt)
+    if (const char *dbg = getenv("VTM_DEBUG_KP")) {      // tuning hook: 0 = off, else the step after which blocks are tested
+        const int v = atoi(dbg);
+        if (VTM_FILTER_PRODUCTS == 1 && v >= 0 && v < KT) KP = v;
+    }
+    const bool prune = KP > 0 && KP < KT;
+    float *rest_a = prune ? (float *)(w + L.rest_a) : nullptr, *rest_bt = prune ? (float *)(w + L.rest_bt) : nullptr;
+    const int64_t cut = prune ? (int64_t)KP * FBK : L.C64;
     {
         // one launch: canonical norms + fp16 panels of both operands; it also clears amax / cnt / flags (contiguous)
         // and zero-fills `best`
-        const SplitArgs A0{a_rows, Ns, na, ah, SRC_LO ? al : nullptr, L.Ns_pad};
-        const SplitArgs A1{b_rows, Nd, nb, bh, DST_LO ? bl : nullptr, L.Nd_pad};
+        const SplitArgs A0{a_rows, Ns, na, ah, SRC_LO ? al : nullptr, L.Ns_pad, rest_a, nullptr};
+        const SplitArgs A1{b_rows, Nd, nb, bh, DST_LO ? bl : nullptr, L.Nd_pad, nullptr, rest_bt};
         const int64_t total = B * (L.Ns_pad + L.Nd_pad);
         unsigned long long *bp0 = reinterpret_cast<unsigned long long *>(best);
         uint32_t *zp = reinterpret_cast<uint32_t *>(w + L.amax);
@@ -1234,15 +1310,15 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(prep_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, A0, A1, L.C64, zp, zw, bp0, rows_out);
+                                   B, C, A0, A1, L.C64, zp, zw, bp0, rows_out, cut);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(prep_operand<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, A0, A1, L.C64, zp, zw, bp0, rows_out);
+                                   P1, B, C, A0, A1, L.C64, zp, zw, bp0, rows_out, cut);
                 break;
             default:
                 hipLaunchKernelGGL(prep_operand<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, A0, A1, L.C64, zp, zw, bp0, rows_out);
+                                   (const vtm_bf16 *)x1, P1, B, C, A0, A1, L.C64, zp, zw, bp0, rows_out, cut);
         }
     }
 
@@ -1289,7 +1365,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         const int64_t grid = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit;
         hipLaunchKernelGGL(filter_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
                            L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles, amax,
-                           cnt, cand, (int)rows_out, flags);
+                           cnt, cand, (int)rows_out, flags, (const float *)rest_a, (const float *)rest_bt, prune ? KP : 0x7fffffff);
     }
     {
         hipLaunchKernelGGL(survivors_kernel, dim3((unsigned)vtm::cdiv(rows_out, 256)), dim3(256), 0, s, rows_out, amax, cnt,
