@@ -183,6 +183,21 @@ int vtm_gather_rows(const void *x0, int64_t P0, const void *x1, int64_t P1, int 
                     int64_t C, const int32_t *map, int64_t M, void *out, int64_t out_rows,
                     vtm_stream_t stream);
 
+/* vtm_merge_reduce -- the `merge` closure's OTHER modes (merge.py:127-131 / 431-435; never reached from
+ * compute_merge, part of the closure protocol):
+ *     dst = dst.scatter_reduce(-2, dst_idx.expand(n, r, c), gather(src, src_idx), reduce=mode, include_self=True)
+ * with torch's CPU arithmetic -- the sources of a destination row are folded into it one by one in index order, in fp32;
+ * a 16-bit tensor is rounded once at the end; "mean" divides the rounded sum by (1 + number of sources) and rounds again;
+ * amax / amin propagate NaN.  x is (B, N, C); src_rows (B, r) / dst_rows (B, Nd) are the rows of x of the merged src tokens
+ * (in src_idx order) and of the dst tokens; seg_dst (B, r) lists the destinations of the r pairs in ASCENDING order and
+ * seg_order (B, r) the pair each entry is (a STABLE sort by destination, e.g. vtm_sort_desc on keys whose high word is
+ * 0xffffffff - dst_idx).  Writes out[b, out_row0 + j, :] for j < Nd; out is (B, out_ld, C) -- the merged sequence
+ * [unm | dst] with out_row0 = number of unmerged tokens. */
+enum { VTM_REDUCE_SUM = 0, VTM_REDUCE_PROD = 1, VTM_REDUCE_MEAN = 2, VTM_REDUCE_AMAX = 3, VTM_REDUCE_AMIN = 4 };
+int vtm_merge_reduce(const void *x, int dtype, int64_t B, int64_t N, int64_t C, const int32_t *src_rows,
+                     const int32_t *dst_rows, const int32_t *seg_dst, const int32_t *seg_order, int64_t r, int64_t Nd,
+                     int mode, void *out, int64_t out_ld, int64_t out_row0, vtm_stream_t stream);
+
 /* vtm_unmerge_add -- the composed `unmerge` closure + split_frame + residual
  * (merge.py:135-155 / 439-460, vidtome/utils.py:37-40, patch.py:168-169):
  * out[b, i, :] = y[b, inv[b, i], :] (+ resid[b, i, :] when resid != NULL).  y is (B, M, C). */
@@ -229,6 +244,10 @@ int vtm_attention_kv_bounded(const void *q, int64_t ldq, const void *k, int64_t 
                              void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
                              int64_t Mk, int64_t Mkp, int64_t d, float scale, const int32_t *q_count, void *ws,
                              size_t ws_bytes, vtm_stream_t stream);
+/* workspace of a vtm_attention_kv_bounded launch: with a device-side query count the launch cannot plan its rounds, so every
+ * work item is split in two along the key axis (one partial record per workgroup, merged by a second kernel); with less
+ * workspace than this the launch falls back to the plain plan of vtm_attention_ws_bytes */
+size_t vtm_attention_kv_bounded_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64_t Mk, int64_t d);
 
 /* vtm_compact_queries -- which attention outputs a global level with the local chunk on the src side actually needs
  * (bipartite_soft_matching_2s's unmerge, merge.py:439-460, returns for every merged local token the output row of the

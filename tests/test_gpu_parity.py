@@ -172,12 +172,22 @@ def test_match_filtered_hard_cases(L):
     xf[:, Ns + 2] = xf[:, Ns] + 3e-7 * torch.randn(B, C, generator=g)
     xf[:, 0] = xf[:, Ns] + 1e-3 * torch.randn(B, C, generator=g)
     _filtered_vs_exact(L, xf.to(DEV), Ns, Nd, False, expect_flag=0)
-    # (4) zero token -> NaN row -> device flag -> every row recomputed by exact_rows_kernel
+    # (4) zero token among the DST rows -> NaN column for every src row -> device flag -> every row recomputed by
+    #     exact_rows_kernel; a zero SRC token alone only sends its own row there (no whole-call escape)
     x = torch.randn(B, Ns + Nd, C, generator=g).half()
     x[0, 3] = 0
     x[1, Ns + 50] = 0
     _filtered_vs_exact(L, x.to(DEV), Ns, Nd, False, expect_flag=1)
     _filtered_vs_exact(L, x.to(DEV), Ns, Nd, True, expect_flag=1)
+    x = torch.randn(B, Ns + Nd, C, generator=g).half()
+    x[0, 3] = 0
+    x[1, 77] = 0
+    for align in (False, True):
+        ra_ = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+        rb_ = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+        _filtered_vs_exact(L, x.to(DEV), Ns, Nd, align, expect_flag=0)
+        _, fl = L.match_filtered(x.to(DEV), None, ra_, rb_, align, want_flag=True)
+        assert fl.tolist()[:3] == [0, 1, 2], fl.tolist()          # not whole-call, "special rows seen", two rows listed
     # (4b) fp32 tokens with norms far outside the range where the filter's reciprocal-multiply operands are trustworthy
     #      (1e-38 .. 1e-33 and 1e+33): same flag, same exact result; moderate scales (1e-20, 1e+15) stay on the fast path
     xf = torch.randn(B, Ns + Nd, C, generator=g)
@@ -186,7 +196,10 @@ def test_match_filtered_hard_cases(L):
     xs[1, Ns + 3] *= 1e15
     _filtered_vs_exact(L, xs.to(DEV), Ns, Nd, False, expect_flag=0)
     xs = xf.clone()
-    xs[0, 7] *= 1e-36
+    xs[0, 7] *= 1e-36                                     # a SRC row: only that row takes the escape
+    _filtered_vs_exact(L, xs.to(DEV), Ns, Nd, False, expect_flag=0)
+    xs = xf.clone()
+    xs[0, Ns + 7] *= 1e-36                                # a DST row: the whole call
     _filtered_vs_exact(L, xs.to(DEV), Ns, Nd, False, expect_flag=1)
     xs = xf.clone()
     xs[1, Ns + 3] *= 3e31
@@ -711,6 +724,36 @@ def test_default_fp16_path_vs_reference_chain(L, name, proj, monkeypatch):
             setattr(L, n, orig[n])
     assert calls["linear_rows" if proj == "auto" else "linear_panels"] > 0, calls
     vidtome_amd.remove_patch(unet)
+
+
+def test_merge_modes_golden_gpu(L):
+    """The closures' non-"replace" merge modes on the HIP path (vtm_merge_reduce: torch's CPU scatter_reduce arithmetic --
+    sequential fp32 accumulation in index order, one rounding for 16-bit tokens, "mean" = rounded sum / (1 + sources),
+    rounded again; NaN-propagating amax / amin) against what the REFERENCE's closures returned (tests/golden/modes.npz):
+    bit for bit, fp32 / fp16 / bf16 tokens, local and global matcher, aligned batches."""
+    from vidtome_amd import merge
+    for c in load_cases("modes.npz"):
+        x = _t(c["x"])
+        if str(c["kind"]) == "randframe":
+            torch.manual_seed(123)
+            gen = torch.Generator(device="cpu").set_state(torch.get_rng_state())
+            m, u, info = merge.bipartite_soft_matching_randframe(x, int(c["F"]), float(c["ratio"]), int(c["unm_pre"]), gen, 4,
+                                                                 bool(c["align"]))
+        else:
+            m, u, info = merge.bipartite_soft_matching_2s(x, int(c["F"]), float(c["ratio"]), bool(c["align"]))
+        for n in ("unm_idx", "src_idx", "dst_idx"):
+            assert np.array_equal(info[n].cpu().numpy(), c[n]), n
+        assert torch.equal(m(x, mode="replace"), m(x))
+        for mode in ("sum", "prod", "mean", "amax", "amin"):
+            got = m(x, mode=mode).cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), c[f"f32/{mode}"].view(np.uint32)), (str(c["kind"]), mode)
+            for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+                if int(c["C"]) % 8:
+                    continue
+                goth = m(x.to(dt), mode=mode).cpu().view(torch.int16).numpy()
+                assert np.array_equal(goth, c[f"{name}/{mode}"]), (str(c["kind"]), name, mode)
+        with pytest.raises(ValueError):
+            m(x, mode="median")
 
 
 def test_device_generator_opt_in(L):

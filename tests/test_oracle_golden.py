@@ -383,3 +383,32 @@ def test_torch_baseline_times_the_right_algorithm(oracle):
         if trace["global"] is not None:
             coins.add(trace["global"]["local_chunk"])
     assert coins == {0, 1}
+
+
+def test_merge_modes_golden(oracle):
+    """The reference's non-"replace" merge modes (merge.py:127-131 / 431-435: scatter_reduce with include_self=True) through
+    the oracle's closures against tests/golden/modes.npz (make_golden_modes.py: the reference's own `merge(x, mode=...)` for
+    sum / prod / mean / amax / amin on fp32, fp16 and bf16 tokens, destinations hit up to 7 times, a NaN token): bit for bit."""
+    import torch
+    rounders = {"f16": lambda v: v.astype(np.float16),
+                "bf16": lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).bfloat16().float().numpy()}
+    for c in load_cases("modes.npz"):
+        x = c["x"]
+        if str(c["kind"]) == "randframe":
+            m, u, info = oracle.bipartite_soft_matching_randframe(x, int(c["F"]), float(c["ratio"]), int(c["unm_pre"]),
+                                                                  int(c["randf"]), 4, bool(c["align"]))
+        else:
+            m, u, info = oracle.bipartite_soft_matching_2s(x, int(c["F"]), float(c["ratio"]), bool(c["align"]))
+        for n in ("unm_idx", "src_idx", "dst_idx"):
+            assert np.array_equal(info[n], c[n]), n
+        assert int(c["max_sources_per_dst"]) >= 2
+        for mode in ("sum", "prod", "mean", "amax", "amin"):
+            got = m(x, mode=mode)
+            assert np.array_equal(got.view(np.uint32), c[f"f32/{mode}"].view(np.uint32)), mode
+            xh = torch.from_numpy(x).half()
+            goth = m(xh.float().numpy(), mode=mode, round_to=rounders["f16"])
+            assert np.array_equal(goth.astype(np.float16).view(np.int16), c[f"f16/{mode}"]), ("f16", mode)
+            xb = torch.from_numpy(x).bfloat16()
+            gotb = m(xb.float().numpy(), mode=mode, round_to=rounders["bf16"])
+            assert np.array_equal(torch.from_numpy(np.ascontiguousarray(gotb, dtype=np.float32)).bfloat16().view(torch.int16).numpy(),
+                                  c[f"bf16/{mode}"]), ("bf16", mode)

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "vtm_compose": ([_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp], _int),
     "vtm_gather_rows": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _vp], _int),
     "vtm_unmerge_add": ([_vp, _i64, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp], _int),
+    "vtm_merge_reduce": ([_vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _i64, _i64, _vp], _int),
     "vtm_attention": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _f32,
                        _int, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_attention_ws_bytes": ([_i64, _i64, _i64, _i64, _i64], ctypes.c_size_t),
@@ -56,6 +57,7 @@ _SIGNATURES = {
                           _f32, _int, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_attention_kv_bounded": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _f32, _vp, _vp, ctypes.c_size_t, _vp], _int),
+    "vtm_attention_kv_bounded_ws_bytes": ([_i64, _i64, _i64, _i64, _i64], ctypes.c_size_t),
     "vtm_compact_queries_ws_bytes": ([_i64, _i64], ctypes.c_size_t),
     "vtm_compact_queries": ([_vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp], _int),
     "vtm_panel_rows": ([_i64], _i64),
@@ -312,6 +314,32 @@ def gather_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], idx: torch.Tensor,
     return out
 
 
+REDUCE_MODES = {"sum": 0, "prod": 1, "mean": 2, "amax": 3, "amin": 4}      # torch.scatter_reduce's (merge.py:127-131)
+
+
+@_on_device
+def merge_reduce(x: torch.Tensor, src_rows: torch.Tensor, dst_rows: torch.Tensor, dst_idx: torch.Tensor, mode: str,
+                 out: torch.Tensor, out_row0: int) -> torch.Tensor:
+    """The reference's non-"replace" merge modes: fold row src_rows[b, i] of x into dst row dst_idx[b, i] (whose own row
+    of x is dst_rows[b, j]) like ``scatter_reduce(..., reduce=mode, include_self=True)`` on the CPU, writing the Nd
+    reduced rows to out[:, out_row0:out_row0 + Nd].  The pairs are sorted by destination with the library's own stable
+    radix sort (index order survives inside a destination's segment -- that order is the summation order)."""
+    if mode not in REDUCE_MODES:
+        raise ValueError(f"merge mode {mode!r}: expected 'replace' or one of {sorted(REDUCE_MODES)}")
+    _req(x, "x"), _req(src_rows, "src_rows"), _req(dst_rows, "dst_rows"), _req(dst_idx, "dst_idx"), _req(out, "out")
+    B, N, C = x.shape
+    r, Nd = src_rows.shape[1], dst_rows.shape[1]
+    if r > 0:
+        keys = ((-1 - dst_idx.long()) << 32).contiguous()       # high word = 0xffffffff - dst: "descending" = ascending dst
+        order = sort_desc(keys)
+        seg_dst = torch.gather(dst_idx, 1, order.long()).contiguous()
+    else:
+        order = seg_dst = dst_idx
+    _check(lib().vtm_merge_reduce(_ptr(x), dtype_code(x), B, N, C, _ptr(src_rows), _ptr(dst_rows), _ptr(seg_dst), _ptr(order),
+                                  r, Nd, REDUCE_MODES[mode], _ptr(out), out.shape[1], out_row0, _stream()), "vtm_merge_reduce")
+    return out
+
+
 @_on_device
 def unmerge_add(y: torch.Tensor, inv: torch.Tensor, resid: Optional[torch.Tensor]) -> torch.Tensor:
     """out[b, i] = y[b, inv[b, i]] (+ resid[b, i]);  y is (B, Mp, C) (only rows < M are referenced)."""
@@ -326,6 +354,10 @@ def unmerge_add(y: torch.Tensor, inv: torch.Tensor, resid: Optional[torch.Tensor
     _check(lib().vtm_unmerge_add(_ptr(y), Mp, _ptr(inv), _ptr(resid), dtype_code(y), B, L, C, _ptr(out), _stream()),
            "vtm_unmerge_add")
     return out
+
+
+# A/B switch (profiles/r04_attention_split_all.txt): split every work item of a query-bounded attention launch in two
+SPLIT_ALL_BOUNDED = os.environ.get("VIDTOME_ATT_SPLIT_ALL", "1") != "0"
 
 
 def _attention_ws(B: int, heads: int, Mq: int, Mk: int, d: int, device):
@@ -407,6 +439,10 @@ def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
     out = torch.zeros((B, Mqp, C), dtype=q.dtype, device=q.device) if Mqp != Mq else \
         torch.empty((B, Mqp, C), dtype=q.dtype, device=q.device)
     ws, nb = _attention_ws(B, heads, Mq, Mk, d, q.device) if use_workspace else (None, 0)
+    if q_count is not None and use_workspace and SPLIT_ALL_BOUNDED:
+        nb2 = int(lib().vtm_attention_kv_bounded_ws_bytes(B, heads, Mq, Mk, d))
+        if nb2 > 0:
+            ws, nb = _workspace("attention", nb2, q.device), nb2
     if q_count is not None:
         if q_count.dtype != torch.int32 or q_count.numel() != B or not q_count.is_cuda:
             raise RuntimeError("attention_kv: q_count must be a (B,) int32 device tensor")

@@ -247,7 +247,8 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
     int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t nwhole,
-    int nsplit_tail, float *__restrict__ partial_base, int xcd_groups, const int32_t *__restrict__ q_count) {
+    int nsplit_tail, float *__restrict__ partial_base, int xcd_groups, const int32_t *__restrict__ q_count,
+    int64_t split_major_items) {
     // M / Mp: queries per sample and their row stride; Mk / Mkp: keys per sample and the row stride of k
     // (self-attention passes the same values; cross-attention, patch.py:178-183, has Mk = 77).
     // Work decomposition: work item = (query block, head, sample), query blocks fastest.  Workgroups [0, nwhole) take
@@ -290,9 +291,13 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const bool tail_wg = (int64_t)blockIdx.x >= nwhole;
     const int64_t tail_id = (int64_t)blockIdx.x - nwhole;
     const int nsplit = tail_wg ? nsplit_tail : 1;
-    const int64_t lin = item_of(tail_wg ? nwhole + tail_id / nsplit : (int64_t)blockIdx.x, nqb, xcd_groups);
-    const int split = tail_wg ? (int)(tail_id % nsplit) : 0;
-    float *partial = tail_wg ? partial_base + tail_id * rec_floats(D) * (waves_for(D) * 64) : nullptr;
+    // split-minor (a partly filled last round: the splits of an item sit next to each other) or split-MAJOR (launches
+    // with a device-side query bound split EVERY item, see launch(): all first halves, then all second halves, so that
+    // workgroup p and its item still share p % 8 = the XCD the item's (sample, head) pair is pinned to)
+    const int64_t tail_item = split_major_items ? tail_id % split_major_items : tail_id / nsplit;
+    const int split = !tail_wg ? 0 : split_major_items ? (int)(tail_id / split_major_items) : (int)(tail_id % nsplit);
+    const int64_t lin = item_of(tail_wg ? nwhole + tail_item : (int64_t)blockIdx.x, nqb, xcd_groups);
+    float *partial = tail_wg ? partial_base + (tail_item * nsplit + split) * rec_floats(D) * (waves_for(D) * 64) : nullptr;
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t bq = b % src_batch;  // PnP injection: q/k of the source sample (pnp_utils.py:57-67)
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
@@ -664,10 +669,16 @@ struct TailPlan {
     int64_t nqb, total, full;   // query blocks per (sample, head), all workgroups, workgroups in whole rounds
     int nsplit;                 // splits of each remaining work item (1 = none)
     size_t ws_bytes;
+    bool split_all;             // every item is split (launches with a device-side query bound)
 };
 
+// `bounded`: the launch carries a device-side query count (vtm_attention_kv_bounded: compacted live queries).  How many
+// of its workgroups do real work is not known when it is launched -- the cfg-2 top block launches 2 176 for ~1 800 live
+// ones, 3.5 rounds of 512 that cost 4 -- so the round structure cannot be planned.  It is made finer instead: EVERY
+// work item is split in two along the key axis (split-major order), the live ones then fill 7 half-length rounds
+// (profiles/r04_attention_split_all.txt); the price is one partial record per workgroup for attention_combine_kernel.
 template <int D>
-TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk) {
+TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk, bool bounded = false) {
     constexpr int WAVES = waves_for(D), QB = WAVES * QW;
     constexpr int wg_per_cu = D <= 48 ? 2 : 1;   // resident workgroups per CU (launch bounds / LDS)
     TailPlan p;
@@ -678,6 +689,14 @@ TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk) {
     const int64_t rem = p.total - p.full, ntiles = vtm::cdiv(Mk, KV);
     p.nsplit = 1;
     p.ws_bytes = 0;
+    p.split_all = false;
+    if (bounded && p.total >= 2 * slots && ntiles >= 64 && p.total % 8 == 0) {
+        p.full = 0;
+        p.nsplit = 2;
+        p.split_all = true;
+        p.ws_bytes = (size_t)p.total * 2 * rec_floats(D) * (WAVES * 64) * sizeof(float);
+        return p;
+    }
     // worth it only behind at least one whole round, for long key axes, and when the last round is at most a
     // quarter full (a workgroup that has its CU to itself already runs about twice as fast as in a full round;
     // measured: 128 of 512 -> -7 %, 16 of 256 -> -18 %, 192 or 256 of 512 -> no gain)
@@ -712,10 +731,12 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
         }
     }
     constexpr int WAVES = waves_for(D);
-    TailPlan p = plan_tail<D>(B, h, M, Mk);
+    TailPlan p = plan_tail<D>(B, h, M, Mk, q_count != nullptr);
+    if (p.split_all && (!ws || ws_bytes < p.ws_bytes)) p = plan_tail<D>(B, h, M, Mk);   // not enough workspace: the plain plan
     if (p.nsplit > 1 && (!ws || ws_bytes < p.ws_bytes)) {   // no workspace: plain single launch
         p.nsplit = 1;
         p.full = p.total;
+        p.split_all = false;
     }
     const float scale_log2e = scale * 1.4426950408889634f;
     const int64_t src_batch = B / share_groups;
@@ -732,7 +753,8 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
 #endif
     hipLaunchKernelGGL((attention_kernel<T, D>), dim3((unsigned)(p.full + rem * p.nsplit)), dim3(WAVES * 64), lds, s,
                        (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
-                       scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws, xcd_groups, q_count);
+                       scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws, xcd_groups, q_count,
+                       p.split_all ? rem : (int64_t)0);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem), dim3(WAVES * 64), 0, s,
                            (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups, q_count);
@@ -772,6 +794,22 @@ VTM_EXPORT size_t vtm_attention_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64
         case 32: return plan_tail<32>(B, h, Mq, Mk).ws_bytes;
         case 96: return plan_tail<96>(B, h, Mq, Mk).ws_bytes;
         case 128: return plan_tail<128>(B, h, Mq, Mk).ws_bytes;
+    }
+    return 0;
+}
+
+VTM_EXPORT size_t vtm_attention_kv_bounded_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64_t Mk, int64_t d) {
+    if (B <= 0 || h <= 0 || Mq <= 0 || Mk <= 0) return 0;
+    switch (d) {
+        case 40: return plan_tail<40>(B, h, Mq, Mk, true).ws_bytes;
+        case 64: return plan_tail<64>(B, h, Mq, Mk, true).ws_bytes;
+        case 80: return plan_tail<80>(B, h, Mq, Mk, true).ws_bytes;
+        case 160: return plan_tail<160>(B, h, Mq, Mk, true).ws_bytes;
+        case 8: return plan_tail<8>(B, h, Mq, Mk, true).ws_bytes;
+        case 16: return plan_tail<16>(B, h, Mq, Mk, true).ws_bytes;
+        case 32: return plan_tail<32>(B, h, Mq, Mk, true).ws_bytes;
+        case 96: return plan_tail<96>(B, h, Mq, Mk, true).ws_bytes;
+        case 128: return plan_tail<128>(B, h, Mq, Mk, true).ws_bytes;
     }
     return 0;
 }

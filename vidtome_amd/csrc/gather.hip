@@ -86,6 +86,65 @@ __global__ __launch_bounds__(256) void unmerge_add_kernel(const char *__restrict
     }
 }
 
+// ---- the reference's other merge modes (merge.py:127-131: dst.scatter_reduce(-2, dst_idx, src, reduce=mode,
+// include_self=True)); never reached from compute_merge, kept for the closure protocol ----
+// torch's CPU kernel folds the sources of a destination row into it ONE BY ONE IN INDEX ORDER, in fp32 whatever the tensor
+// dtype; a 16-bit tensor is rounded once at the end, "mean" then divides by (1 + number of sources) and rounds again; amax /
+// amin propagate NaN (probed bit for bit, tests/golden/make_golden_modes.py).  The pairs arrive sorted by destination
+// (stable, so index order survives inside a destination's segment: vtm_sort_desc on the host side): a thread owns 8
+// channels of one dst row, finds its segment by bisection and walks it.
+enum { RED_SUM = 0, RED_PROD = 1, RED_MEAN = 2, RED_AMAX = 3, RED_AMIN = 4 };
+
+template <typename T>
+__device__ __forceinline__ T round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half round_to<__half>(float v) { return __float2half_rn(v); }
+template <> __device__ __forceinline__ vtm_bf16 round_to<vtm_bf16>(float v) { return __float2bfloat16(v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void merge_reduce_kernel(const T *__restrict__ x, int64_t N, int64_t C, int64_t B,
+                                                           const int32_t *__restrict__ src_rows, const int32_t *__restrict__ dst_rows,
+                                                           const int32_t *__restrict__ seg_dst, const int32_t *__restrict__ seg_order,
+                                                           int64_t r, int64_t Nd, int mode, T *__restrict__ out, int64_t out_ld,
+                                                           int64_t out_row0) {
+    const int64_t chunks = C / 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Nd * chunks) return;
+    const int64_t c = idx % chunks, j = (idx / chunks) % Nd, b = idx / (chunks * Nd);
+    const int32_t *sd = seg_dst + b * r;
+    int64_t lo = 0, hi = r;                    // first pair whose destination is >= j
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sd[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    float acc[8];
+    const T *self = x + (b * N + dst_rows[b * Nd + j]) * C + c * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = vtm::to_f32(self[e]);
+    float count = 1.0f;
+    for (int64_t p = lo; p < r && sd[p] == j; ++p) {
+        const T *s = x + (b * N + src_rows[b * r + seg_order[b * r + p]]) * C + c * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = vtm::to_f32(s[e]);
+            switch (mode) {
+                case RED_PROD: acc[e] = acc[e] * v; break;
+                case RED_AMAX: acc[e] = (v != v || acc[e] != acc[e]) ? NAN : fmaxf(acc[e], v); break;
+                case RED_AMIN: acc[e] = (v != v || acc[e] != acc[e]) ? NAN : fminf(acc[e], v); break;
+                default: acc[e] = acc[e] + v;
+            }
+        }
+        count += 1.0f;
+    }
+    T *o = out + (b * out_ld + out_row0 + j) * C + c * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        T v = round_to<T>(acc[e]);
+        if (mode == RED_MEAN) v = round_to<T>(vtm::to_f32(v) / count);
+        o[e] = v;
+    }
+}
+
 inline int esize(int dtype) { return dtype == VTM_F32 ? 4 : (dtype == VTM_F16 || dtype == VTM_BF16) ? 2 : 0; }
 
 inline unsigned grid_for(int64_t total) {
@@ -138,4 +197,31 @@ VTM_EXPORT int vtm_unmerge_add(const void *y, int64_t M, const int32_t *inv, con
     }
 #undef VTM_UNMERGE
     return vtm::launch_status("vtm_unmerge_add");
+}
+
+VTM_EXPORT int vtm_merge_reduce(const void *x, int dtype, int64_t B, int64_t N, int64_t C, const int32_t *src_rows,
+                                const int32_t *dst_rows, const int32_t *seg_dst, const int32_t *seg_order, int64_t r,
+                                int64_t Nd, int mode, void *out, int64_t out_ld, int64_t out_row0, vtm_stream_t stream) {
+    VTM_REQUIRE(x && dst_rows && out && (r == 0 || (src_rows && seg_dst && seg_order)), "vtm_merge_reduce: null pointer");
+    VTM_REQUIRE(esize(dtype), "vtm_merge_reduce: unsupported dtype %d", dtype);
+    VTM_REQUIRE(B > 0 && N > 0 && C > 0 && C % 8 == 0 && r >= 0 && Nd > 0 && out_ld >= out_row0 + Nd && out_row0 >= 0,
+                "vtm_merge_reduce: bad sizes");
+    VTM_REQUIRE(mode >= VTM_REDUCE_SUM && mode <= VTM_REDUCE_AMIN, "vtm_merge_reduce: unknown reduce mode %d", mode);
+    const int64_t total = B * Nd * (C / 8);
+    const dim3 grid((unsigned)vtm::cdiv(total, 256)), block(256);
+    hipStream_t s = vtm::as_stream(stream);
+    switch (dtype) {
+        case VTM_F32:
+            hipLaunchKernelGGL(merge_reduce_kernel<float>, grid, block, 0, s, (const float *)x, N, C, B, src_rows, dst_rows,
+                               seg_dst, seg_order, r, Nd, mode, (float *)out, out_ld, out_row0);
+            break;
+        case VTM_F16:
+            hipLaunchKernelGGL(merge_reduce_kernel<__half>, grid, block, 0, s, (const __half *)x, N, C, B, src_rows, dst_rows,
+                               seg_dst, seg_order, r, Nd, mode, (__half *)out, out_ld, out_row0);
+            break;
+        default:
+            hipLaunchKernelGGL(merge_reduce_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x, N, C, B, src_rows,
+                               dst_rows, seg_dst, seg_order, r, Nd, mode, (vtm_bf16 *)out, out_ld, out_row0);
+    }
+    return vtm::launch_status("vtm_merge_reduce");
 }

@@ -21,8 +21,8 @@
 // massively duplicated dst rows) is put on a per-sample list and recomputed by exact_rows_kernel: fp32-MFMA score tiles
 // [128 listed rows x all Nd] -- the arithmetic of vtm_match (v_mfma_f32_32x32x2_f32 = the canonical k-ascending fmaf
 // chain), operands normalised on the fly from the token rows and the canonical norms; any row without a finite positive
-// norm (zero token -> 0/0, merge.py:84 has no eps) raises a device flag (survivors_kernel) that makes that kernel
-// recompute EVERY row of the call.  Worst case = the cost of the exact matcher (~8 ms at the cfg-2 top level), not the
+// norm (zero token -> 0/0, merge.py:84 has no eps) is recognised by refine_kernel: a src row of that kind joins the list, a
+// dst row of that kind raises a device flag that makes exact_rows_kernel recompute EVERY row of the call.  Worst case = the cost of the exact matcher (~8 ms at the cfg-2 top level), not the
 // ~1000x of a scalar row pass (rounds 1-3).  A row stops collecting the moment its list overflows (the overflowing lane
 // publishes +inf as the row's running maximum, which every other lane / split of the row picks up), so flat regions do not
 // flood the filter with candidate pushes either.
@@ -122,7 +122,7 @@ __device__ __forceinline__ float vmax2(float a, float b) {
 // hipcc expands x / n (fp32, denormals on) to  d = div_scale(n), m = div_scale(x), r = rcp(d), e = fma(-d, r, 1), r1 = fma(e, r, r),
 // q = m * r1, t = fma(-d, q, m), q1 = fma(t, r1, q), t2 = fma(-d, q1, m), div_fmas(t2, r1, q1), div_fixup -- 11 instructions, the
 // reciprocal refinement redone for every x because v_div_scale looks at both operands.  When neither operand needs scaling
-// (n in [2^-100, 2^100]: guaranteed on the filtered path, survivors_kernel; x = 0, or |x| >= 2^-102 and x / n >= 2^-124: checked,
+// (n in [2^-100, 2^100]: guaranteed on the filtered path, refine_kernel; x = 0, or |x| >= 2^-102 and x / n >= 2^-124: checked,
 // `div_ok`) div_scale returns its input, div_fmas is a plain fma and div_fixup passes the value through (a zero quotient may
 // lose its sign, which a fused multiply-add chain starting from +0 cannot see), so the SAME operations with the SAME roundings can
 // be issued with r1 computed once per row: 5 instructions per quotient.
@@ -165,7 +165,7 @@ __device__ __forceinline__ float from_orderable(uint32_t o) {   // 0 (never writ
 // few rows there are -- r02_b.)  The launch also clears the call's counters and zero-fills `best` (nothing in this
 // kernel reads them: no ordering needed).
 // A row whose norm is not a finite positive number (zero token -> 0/0, merge.py:84 has no eps; inf / NaN inputs) has
-// non-finite xhat components; survivors_kernel recognises it by the stored norm.
+// non-finite xhat components; refine_kernel recognises it by the stored norm / the tile's rest-norm mark.
 struct SplitArgs {   // one operand: gathered rows, their norms (out), the panel outputs
     const int32_t *rows;
     int64_t n;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
     // <= 5e-7 to the score error, inside the 7e-5 the window keeps in reserve), so it multiplies by ONE reciprocal per row
     // instead of dividing 320-1280 times (~10 instructions each).  The refine pass has its own IEEE divisions; norms
     // outside [2^-100, 2^100] (where the reciprocal could leave the normal range) send the call down the exact path like
-    // non-finite ones (survivors_kernel).
+    // non-finite ones (refine_kernel).
     const float rscale = SCALE * __builtin_amdgcn_rcpf(nrm);
     uint4 *__restrict__ out_hi = in_range ? A.out_hi + (b * G) * n_pad + i : nullptr;
     uint4 *__restrict__ out_lo = (in_range && A.out_lo) ? A.out_lo + (b * G) * n_pad + i : nullptr;
@@ -317,7 +317,11 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
     // rest norms for the filter's partial-sum pruning, rounded UP a little (1 + 2^-16 each: the Cauchy-Schwarz bound must
     // also cover the fp32 rounding of this sum and of the MFMA's own accumulation, ~1e-6 relative).  Non-finite values
     // (bad rows) make every comparison against them false or true-forever; such calls are recomputed exactly anyway.
-    const float rnorm = real ? __builtin_sqrtf(rest) * (1.0f + 0x1p-16f) : 0.0f;
+    // A row whose norm is not a finite number in [2^-100, 2^100] (zero token -> NaN xhat, merge.py:84; overflow; a
+    // reciprocal that leaves the normal range) reports +inf: refine_kernel recognises the call / the row by it, and the
+    // pruning test can never declare a block dead against it.
+    const bool bad_row = real && !(nrm >= 0x1p-100f && nrm <= 0x1p100f);
+    const float rnorm = !real ? 0.0f : bad_row ? INFINITY : __builtin_sqrtf(rest) * (1.0f + 0x1p-16f);
     if (in_range && A.rest) A.rest[b * n_pad + i] = rnorm;
     float wm = rnorm;
 #pragma unroll
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     float rest_l[2];
     uint32_t live = 0xffu;
     // candidate lists are slot-major, [slot][row] (cand_rows rows): the first entries of neighbouring rows -- all that most
-    // rows ever have -- share cache lines for the lanes of survivors_kernel; 32-bit index (the launcher checks the size)
+    // rows ever have -- share cache lines for the lanes of refine_kernel; 32-bit index (the launcher checks the size)
     // The row's list is full: the row goes to exact_rows_kernel whatever else is found, so it stops collecting -- +inf
     // becomes its published running maximum (nothing is ever within the window of +inf) and every lane / split of the row
     // picks that up with its next re-read (a flat image region would otherwise push thousands of candidates per row).
@@ -871,45 +875,70 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     }
 }
 
-// ---- refine, step 1: per row, keep the candidates inside the window of the row's global approximate max ----
-__global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const unsigned int *__restrict__ amax,
-                                                        const int *__restrict__ cnt, const uint2 *__restrict__ cand,
-                                                        int *__restrict__ flags, int *__restrict__ ovf_cnt,
-                                                        int *__restrict__ ovf_rows, int64_t Ns, int align,
-                                                        uint2 *__restrict__ pairs, const float *__restrict__ na,
-                                                        int64_t n_na, const float *__restrict__ nb, int64_t n_nb) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // any row of either operand without a finite positive norm (zero token -> NaN xhat, merge.py:84), or with one so
-    // small / large that prep_operand's reciprocal is not a normal number: the filter's
-    // error window means nothing for this call -> exact_rows_kernel recomputes EVERY row (flags[0]).  The scan
-    // rides on this launch (a kernel boundary separates it from the reader).
+// ---- refine: the candidates inside the window of each row's final approximate maximum, re-evaluated exactly ----
+// One launch (rounds 1-3: a compaction kernel + a pair kernel).  A workgroup owns 256 rows:
+//   1. it decides what kind of call this is -- every workgroup scans the same few hundred per-tile values prep_operand left
+//      (tile_rest: +inf marks a dst tile holding a row without a finite positive norm in [2^-100, 2^100]; zero token -> NaN
+//      xhat, merge.py:84 has no eps) and reaches the same answer without a grid-wide exchange: such a call is recomputed as a
+//      whole by exact_rows_kernel (flags[0]), the filter's error window means nothing for it;
+//   2. per row: the list entries inside the window of the row's final maximum are counted (the first 16 in ONE batch of
+//      loads); rows whose list overflowed -- or whose OWN norm is out of range -- go on their sample's list for
+//      exact_rows_kernel (one atomic per wave and list);
+//   3. the workgroup reserves ONE contiguous slice of the pair list (one atomic), writes its (row, column) pairs there
+//      and, behind a barrier, works them off itself, a pair per thread and round: the canonical fp32 chain (x / norm with
+//      the operations and roundings of the IEEE expansion, the reciprocal refinement hoisted out of the channel loop),
+//      combined with the packed atomicMax of vtm_match.
+template <typename T>
+__global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1,
+                                                     int64_t P1, int64_t B, int64_t C,
+                                                     const int32_t *__restrict__ a_rows, int64_t Ns,
+                                                     const int32_t *__restrict__ b_rows, int64_t Nd,
+                                                     const float *__restrict__ na, const float *__restrict__ nb,
+                                                     int align, int *__restrict__ flags, int64_t rows_out,
+                                                     const unsigned int *__restrict__ amax, const int *__restrict__ cnt,
+                                                     const uint2 *__restrict__ cand, int *__restrict__ ovf_cnt,
+                                                     int *__restrict__ ovf_rows, uint2 *__restrict__ pairs,
+                                                     const float *__restrict__ tile_rest, int64_t n_tile_rest,
+                                                     unsigned long long *__restrict__ best) {
+    __shared__ int wave_tot[4];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- 1. a dst row without a usable norm anywhere?
     {
-        const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
         bool bad = false;
-        for (int64_t t = row; t < n_na; t += gsz) bad |= !(na[t] >= 0x1p-100f && na[t] <= 0x1p100f);
-        for (int64_t t = row; t < n_nb; t += gsz) bad |= !(nb[t] >= 0x1p-100f && nb[t] <= 0x1p100f);
-        if (bad) { flags[0] = 1; flags[1] = 1; }
+        for (int64_t t = tid; t < n_tile_rest; t += 256) bad |= !(tile_rest[t] < INFINITY);
+        if (__syncthreads_or(bad)) {
+            if (blockIdx.x == 0 && tid == 0) {
+                flags[0] = 1;
+                flags[1] = 1;
+            }
+            return;
+        }
     }
-    // per row: count the candidates inside the window of the row's final approximate maximum.  The first PRE list entries
-    // are fetched in ONE batch (a loop that waits for every entry costs a memory latency per entry, twice: ~16 entries per
-    // row at 8 dst splits); longer lists continue with a loop.  The wave reserves its slice of the pair list with ONE atomic.
+    // ---- 2. per row
+    const int64_t row = (int64_t)blockIdx.x * 256 + tid;
     const bool live = row < rows_out;
     const int n = live ? cnt[row] : 0;
     const float thr = live ? from_orderable(amax[row]) - WINDOW : 0.0f;
+    bool bad_src = false;
+    if (live) {
+        if (align) {
+            for (int64_t bi = 0; bi < B; ++bi) bad_src |= !(na[bi * Ns + row] >= 0x1p-100f && na[bi * Ns + row] <= 0x1p100f);
+        } else {
+            bad_src = !(na[row] >= 0x1p-100f && na[row] <= 0x1p100f);
+        }
+    }
+    const bool ovf = live && (n > CAP || bad_src);
     constexpr int PRE = 16;
     uint2 pre[PRE];
 #pragma unroll
-    for (int c = 0; c < PRE; ++c) pre[c] = c < n && n <= CAP ? cand[(int64_t)c * rows_out + row] : make_uint2(0x7fc00000u, 0u);
+    for (int c = 0; c < PRE; ++c) pre[c] = (c < n && !ovf) ? cand[(int64_t)c * rows_out + row] : make_uint2(0x7fc00000u, 0u);
     int ns = 0;
 #pragma unroll
     for (int c = 0; c < PRE; ++c) ns += __uint_as_float(pre[c].x) >= thr;   // NaN (not fetched) never counts
-    if (n <= CAP)
+    if (!ovf)
         for (int c = PRE; c < n; ++c) ns += __uint_as_float(cand[(int64_t)c * rows_out + row].x) >= thr;
-    // the list overflowed (a flat region / a dst row duplicated more than ~CAP times): the row goes on its sample's list
-    // for exact_rows_kernel (one list per sample -- a tile of listed rows shares its dst operand; aligned: one list).
-    // One atomic per wave and list.
-    const bool ovf = live && n > CAP;
-    if (ovf) ns = 0;
+    if (bad_src) flags[1] = 1;
     {
         const int l = (ovf && !align) ? (int)(row / Ns) : 0;
         unsigned long long todo = __ballot(ovf);
@@ -918,27 +947,35 @@ __global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const 
             const int l0 = __shfl(l, lead, 64);
             const unsigned long long grp = __ballot(ovf && l == l0);
             int base = 0;
-            if ((int)(threadIdx.x & 63) == lead) {
+            if (lane == lead) {
                 base = atomicAdd(&ovf_cnt[l0], __popcll(grp));
                 atomicAdd(&flags[2], __popcll(grp));
             }
             base = __shfl(base, lead, 64);
             if (ovf && l == l0)
-                ovf_rows[(int64_t)l0 * Ns + base + __popcll(grp & ((1ull << (threadIdx.x & 63)) - 1ull))] = (int)(row - (int64_t)l0 * Ns);
+                ovf_rows[(int64_t)l0 * Ns + base + __popcll(grp & ((1ull << lane) - 1ull))] = (int)(row - (int64_t)l0 * Ns);
             todo &= ~grp;
         }
     }
-    const int lane = threadIdx.x & 63;
+    // ---- 3. the workgroup's slice of the pair list
     int incl = ns;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int t = __shfl_up(incl, off, 64);
         if (lane >= off) incl += t;
     }
-    int base = 0;
-    if (lane == 63 && incl > 0) base = atomicAdd(&flags[3], incl);
-    base = __shfl(base, 63, 64);
-    int at = base + incl - ns;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        before += w < wave ? wave_tot[w] : 0;
+        total += wave_tot[w];
+    }
+    if (tid == 0) s_base = total > 0 ? atomicAdd(&flags[3], total) : 0;
+    __syncthreads();
+    const int base = s_base;
+    int at = base + before + incl - ns;
     if (ns > 0) {
 #pragma unroll
         for (int c = 0; c < PRE; ++c)
@@ -948,27 +985,14 @@ __global__ __launch_bounds__(256) void survivors_kernel(int64_t rows_out, const 
             if (__uint_as_float(cd.x) >= thr) pairs[at++] = make_uint2((uint32_t)row, cd.y);
         }
     }
-}
-
-// ---- refine, step 2: one thread per surviving (row, column) pair runs the canonical fp32 chain ----
-template <typename T>
-__global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1,
-                                                     int64_t P1, int64_t B, int64_t C,
-                                                     const int32_t *__restrict__ a_rows, int64_t Ns,
-                                                     const int32_t *__restrict__ b_rows, int64_t Nd,
-                                                     const float *__restrict__ na, const float *__restrict__ nb,
-                                                     int align, const int *__restrict__ flags,
-                                                     const uint2 *__restrict__ pairs,
-                                                     unsigned long long *__restrict__ best) {
-    // a call with a norm outside [2^-100, 2^100] (flags[0]) is recomputed by exact_rows_kernel: its pairs are skipped, the
-    // fast division is only ever used inside that range
-    const int npairs = flags[0] ? 0 : flags[3];
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (int64_t)gridDim.x * blockDim.x) {
+    __threadfence_block();
+    __syncthreads();
+    for (int p = base + tid; p < base + total; p += 256) {
         const uint2 pr = pairs[p];
-        const int64_t row = pr.x;
+        const int64_t prow = pr.x;
         const uint32_t col = pr.y;
-        const int64_t i = align ? row : row % Ns;
-        const int64_t bi = align ? (int64_t)(col / (uint32_t)Nd) : row / Ns;
+        const int64_t i = align ? prow : prow % Ns;
+        const int64_t bi = align ? (int64_t)(col / (uint32_t)Nd) : prow / Ns;
         const int64_t j = align ? (int64_t)(col % (uint32_t)Nd) : (int64_t)col;
         const T *pa = pool_row(x0, P0, x1, P1, bi, a_rows[bi * Ns + i], C);
         const T *pb = pool_row(x0, P0, x1, P1, bi, b_rows[bi * Nd + j], C);
@@ -990,7 +1014,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
             }
         };
         // 32 channels per step: 4 + 4 independent 16-byte loads in flight per lane (a lane walks its own two rows; with one
-        // load per row and step every step costs a cache round trip)
+        // load per row and step every step costs a cache round trip).  (Fetching the next step's pieces behind this step's
+        // chain -- 16 more loads in flight, 192 VGPRs -- measured slower: 53 vs 48 us per call, profiles/r04_e.)
         int64_t k = 0;
         for (; k + 32 <= C; k += 32) {
             float fa[4][8], fb[4][8];
@@ -1008,9 +1033,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
             load8(pb + k, fb);
             chain8(fa, fb);
         }
-        atomicMax(&best[row], ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col));
+        atomicMax(&best[prow], ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col));
     }
-
 }
 
 // ---- escape: exact fp32-MFMA score tiles for the listed rows (or, flags[0], for every row of the call) ----
@@ -1127,7 +1151,9 @@ __global__ __launch_bounds__(256, 2) void exact_rows_kernel(
             if (!valid) {                              // rows past the list / past Nd: zero operands (never published)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = 0.0f;
-            } else if (all) {                          // some norm of the call is out of range: IEEE division throughout
+            } else if (all || !(d.n >= 0x1p-100f && d.n <= 0x1p100f)) {
+                // a norm outside the range where the per-row reciprocal form is the IEEE quotient (whole-call mode, or a
+                // listed row that is here BECAUSE of its norm): IEEE division
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = f[j] / d.n;
             } else {
@@ -1295,7 +1321,8 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         if (VTM_FILTER_PRODUCTS == 1 && v >= 0 && v < KT) KP = v;
     }
     const bool prune = KP > 0 && KP < KT;
-    float *rest_a = prune ? (float *)(w + L.rest_a) : nullptr, *rest_bt = prune ? (float *)(w + L.rest_bt) : nullptr;
+    // (the per-tile values are written for every call: refine_kernel reads the "row without a usable norm" mark from them)
+    float *rest_a = (float *)(w + L.rest_a), *rest_bt = (float *)(w + L.rest_bt);
     const int64_t cut = prune ? (int64_t)KP * FBK : L.C64;
     {
         // one launch: canonical norms + fp16 panels of both operands; it also clears amax / cnt / flags (contiguous)
@@ -1365,14 +1392,15 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         const int64_t grid = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit;
         hipLaunchKernelGGL(filter_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
                            L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles, amax,
-                           cnt, cand, (int)rows_out, flags, (const float *)rest_a, (const float *)rest_bt, prune ? KP : 0x7fffffff);
+                           cnt, cand, (int)rows_out, flags, prune ? (const float *)rest_a : nullptr,
+                           prune ? (const float *)rest_bt : nullptr, prune ? KP : 0x7fffffff);
     }
     {
-        hipLaunchKernelGGL(survivors_kernel, dim3((unsigned)vtm::cdiv(rows_out, 256)), dim3(256), 0, s, rows_out, amax, cnt,
-                           cand, flags, ovf_cnt, ovf_rows, Ns, align, pairs, (const float *)na, B * Ns, (const float *)nb, B * Nd);
-        // one thread per surviving pair; the count lives on the device, so a fixed grid strides over the list
-        const dim3 grid((unsigned)std::min<int64_t>(vtm::cdiv(rows_out * 2, 256), 4096)), block(256);
+        const dim3 grid((unsigned)vtm::cdiv(rows_out, 256)), block(256);
         unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
+        const int64_t n_tile_rest = B * (L.Nd_pad / FBD);
+#define VTM_REFINE_ARGS a_rows, Ns, b_rows, Nd, na, nb, align, flags, rows_out, amax, cnt, cand, ovf_cnt, ovf_rows, pairs, \
+                        (const float *)rest_bt, n_tile_rest, bp
         // the escape: a fixed grid strides over the (device-side) lists of overflowed rows -- normally empty, then the
         // workgroups leave at once; dst splits of >= 8 tiles so that a short list still spreads over the chip
         const int xd_tiles = (int)vtm::cdiv(Nd, XD);
@@ -1384,19 +1412,19 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(refine_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
+                                   B, C, VTM_REFINE_ARGS);
                 hipLaunchKernelGGL(exact_rows_kernel<float>, xgrid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
                                    B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt, ovf_rows, bp, xsplit, xtps);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(refine_kernel<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
+                                   P1, B, C, VTM_REFINE_ARGS);
                 hipLaunchKernelGGL(exact_rows_kernel<__half>, xgrid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
                                    P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt, ovf_rows, bp, xsplit, xtps);
                 break;
             default:
                 hipLaunchKernelGGL(refine_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, pairs, bp);
+                                   (const vtm_bf16 *)x1, P1, B, C, VTM_REFINE_ARGS);
                 hipLaunchKernelGGL(exact_rows_kernel<vtm_bf16>, xgrid, block, 0, s, (const vtm_bf16 *)x0, P0,
                                    (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt,
                                    ovf_rows, bp, xsplit, xtps);

@@ -109,14 +109,23 @@ def _check_metric(metric: torch.Tensor) -> torch.Tensor:
     return metric.contiguous()
 
 
+def _merge_with_mode(level: Level, x: torch.Tensor, mode: str) -> torch.Tensor:
+    """merge.py:119-133 / 423-437: ``cat([unm, dst])``; in the modes other than "replace" the matched src rows are first
+    folded into their dst rows (``scatter_reduce(..., reduce=mode, include_self=True)``, merge.py:127-131) -- never reached
+    from compute_merge, provided for code written against the closure protocol."""
+    x = x.contiguous()
+    out = _lib.gather_rows(x, None, level.new_cur)                  # [unm | dst]: the replace-mode result
+    if mode == "replace":
+        return out
+    B = x.shape[0]
+    src_rows = level.a_pos.long()[level.src_idx.long()].to(torch.int32).contiguous()       # (B, r) rows of x
+    dst_rows = level.b_pos.to(torch.int32).expand(B, -1).contiguous()                       # (B, Nd)
+    return _lib.merge_reduce(x, src_rows, dst_rows, level.dst_idx.contiguous(), mode, out, level.Ns - level.r)
+
+
 def _make_closures(level: Level, N: int, out_slice: Optional[Tuple[int, int]] = None, merge_mode="replace"):
     def merge(x: torch.Tensor, mode=None) -> torch.Tensor:
-        mode = mode if mode is not None else merge_mode
-        if mode != "replace":
-            # the reference's other modes (scatter_reduce, merge.py:127-131) are never reached from
-            # compute_merge and are outside the hot path
-            raise NotImplementedError(f"merge mode {mode!r}: only 'replace' is implemented")
-        return _lib.gather_rows(x.contiguous(), None, level.new_cur)
+        return _merge_with_mode(level, x, mode if mode is not None else merge_mode)
 
     def unmerge(x: torch.Tensor, **kwarg) -> torch.Tensor:
         inv = level.inv
@@ -164,10 +173,7 @@ def bipartite_soft_matching_2s(metric: torch.Tensor, src_len: int, ratio: float,
     sl = (0, src_len) if unmerge_chunk == 0 else (src_len, N)
 
     def merge(x: torch.Tensor, mode=None) -> torch.Tensor:
-        mode = mode if mode is not None else merge_mode
-        if mode != "replace":
-            raise NotImplementedError(f"merge mode {mode!r}: only 'replace' is implemented")
-        return _lib.gather_rows(x.contiguous(), None, level.new_cur)
+        return _merge_with_mode(level, x, mode if mode is not None else merge_mode)
 
     def unmerge(x: torch.Tensor, **kwarg) -> torch.Tensor:
         return _lib.unmerge_add(x.contiguous(), level.inv[:, sl[0]:sl[1]].contiguous(), None)
