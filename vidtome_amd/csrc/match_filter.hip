@@ -1015,7 +1015,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
         };
         // 32 channels per step: 4 + 4 independent 16-byte loads in flight per lane (a lane walks its own two rows; with one
         // load per row and step every step costs a cache round trip).  (Fetching the next step's pieces behind this step's
-        // chain -- 16 more loads in flight, 192 VGPRs -- measured slower: 53 vs 48 us per call, profiles/r04_e.)
+        // chain -- 16 more loads in flight, 192 VGPRs -- measured slower, 53 vs 48 us per call; 64 channels per step, 210 VGPRs: 46.5 vs
+        // 47.8 us, inside the noise of a step: neither shipped.)
         int64_t k = 0;
         for (; k + 32 <= C; k += 32) {
             float fa[4][8], fb[4][8];

@@ -540,6 +540,11 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
         x = F.pad(x, (0, 0, 0, pad))
         Mp = x.shape[1]
     core = x.dtype
+    if x.dtype != torch.float32 and PROJ_MODE != "blas":
+        # an fp16 / bf16 model normally never gets here: say once that (and why) this module's projections are library GEMMs
+        _warn_once("lib-proj", f"vidtome_amd: attn1 projections of a {x.dtype} model run as library GEMMs (C = {C}: the "
+                               "hand-written projection kernels take C % 32 == 0 with all four projection weights in the "
+                               "tokens' dtype and no bias on to_v at C > 320)")
     if x.dtype == torch.float32:
         core = torch.float16
         _warn_once("fp32-core", "vidtome_amd: fp32 model -- the self-attention core (QK^T, softmax, PV) runs on the "
@@ -607,6 +612,8 @@ def norm_cross_attention_residual(norm: torch.nn.Module, attn: torch.nn.Module, 
         k = _lib.linear_panels(ep, B * Mkp, wk, C, bk).view(B, Mkp, C)
         vt = _lib.linear_panels(ep, B * Mkp, wv, C, bv).view(B, Mkp, C).transpose(1, 2).contiguous()   # (B, C, Mkp)
     else:
+        _warn_once("lib-cross-kv", f"vidtome_amd: attn2's k / v projections run as library GEMMs (conditioning width "
+                                   f"{enc.shape[2]} is not a multiple of 64, or to_k / to_v are not of the tokens' dtype)")
         lin = lambda m, t: F.linear(t, m.weight.to(t.dtype), None if m.bias is None else m.bias.to(t.dtype))
         k = lin(attn.to_k, enc)
         vt = lin(attn.to_v, enc).transpose(1, 2).contiguous()
