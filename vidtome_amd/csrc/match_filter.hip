@@ -19,7 +19,7 @@
 //
 // Escapes (all exact, no host round trip, BOUNDED cost): a row whose candidate list overflows CAP (flat image regions,
 // massively duplicated dst rows) is put on a per-sample list and recomputed by exact_rows_kernel: fp32-MFMA score tiles
-// [128 listed rows x all Nd] -- the arithmetic of vtm_match (v_mfma_f32_32x32x2_f32 = the canonical k-ascending fmaf
+// [256 listed rows x all Nd] -- the arithmetic of vtm_match (v_mfma_f32_32x32x2_f32 = the canonical k-ascending fmaf
 // chain), operands normalised on the fly from the token rows and the canonical norms; any row without a finite positive
 // norm (zero token -> 0/0, merge.py:84 has no eps) is recognised by refine_kernel: a src row of that kind joins the list, a
 // dst row of that kind raises a device flag that makes exact_rows_kernel recompute EVERY row of the call.  Worst case = the cost of the exact matcher (~8 ms at the cfg-2 top level), not the
@@ -1048,25 +1048,30 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
 // the range where that form is valid) -- into LDS as the k-panel image [g][kh][row][4] the MFMA fragments are read from.
 // Per 32-channel step a thread fetches 2 + 2 row pieces (next step's, in flight behind this step's 64 MFMAs), and the
 // dst operand is normalised once per 128 listed rows (the scalar row pass this replaces normalised it once per ROW).
-// Work items = (list, 128-row tile of the list, sample [aligned: every sample's dst set], dst split); the counts live on
+// Work items = (list, XS-row tile of the list, sample [aligned: every sample's dst set], dst split); the counts live on
 // the device, so a fixed grid strides over the items and leaves at once when there are none.
-constexpr int XS = 128;   // listed src rows per workgroup, 32 per wave
+#ifndef VTM_XS
+#define VTM_XS 128          // (A/B build switch: 256 = 64 src rows per wave, one workgroup per CU: profiles/r04_escape_tile.txt)
+#endif
+constexpr int XS = VTM_XS;   // listed src rows per workgroup: 32 (or two 32-row MFMA blocks) per wave
 constexpr int XD = 128;   // dst rows per tile
 constexpr int XK = 32;    // channels per step
-constexpr int XP = XD + 1;   // rows per LDS panel (+1: the 4 pieces of a row land in different bank groups)
-static_assert(XS == XD, "one panel stride for both operands");
+constexpr int XPD = XD + 1, XPS = XS + 1;   // rows per LDS panel (+1: the 4 pieces of a row land in different bank groups)
+constexpr int XSB = XS / 128;                // 32-row src blocks per wave
+constexpr int XSU = XS / 64;                 // src rows a thread stages per step
+static_assert(XS == 128 || XS == 256, "src tile");
 
 __device__ __forceinline__ int64_t xcdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void exact_rows_kernel(
+__global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
     const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
     const int32_t *__restrict__ a_rows, int64_t Ns, const int32_t *__restrict__ b_rows, int64_t Nd,
     const float *__restrict__ na, const float *__restrict__ nb, int align, const int *__restrict__ flags,
     const int *__restrict__ ovf_cnt, const int *__restrict__ ovf_rows, unsigned long long *__restrict__ best, int nsplit,
     int tiles_per_split) {
-    __shared__ __attribute__((aligned(16))) float sD[8 * XP * 4];
-    __shared__ __attribute__((aligned(16))) float sS[8 * XP * 4];
+    __shared__ __attribute__((aligned(16))) float sD[8 * XPD * 4];
+    __shared__ __attribute__((aligned(16))) float sS[8 * XPS * 4];
     constexpr int RAW = sizeof(T) == 4 ? 2 : 1;      // 16-byte loads per 8-channel piece
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1100,12 +1105,12 @@ __global__ __launch_bounds__(256, 2) void exact_rows_kernel(
             return all ? at : (int64_t)ovf_rows[l * Ns + at];
         };
 
-        // ---- this thread's two src rows (fixed for the item) ----
-        const T *ps[2];
-        RowDivisor ds[2];
-        bool vs[2];
+        // ---- this thread's src rows (fixed for the item) ----
+        const T *ps[XSU];
+        RowDivisor ds[XSU];
+        bool vs[XSU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < XSU; ++u) {
             const int64_t i = listed(prow + 64 * u);
             vs[u] = i >= 0;
             const int64_t ii = vs[u] ? i : 0;
@@ -1125,21 +1130,22 @@ __global__ __launch_bounds__(256, 2) void exact_rows_kernel(
                 dd[u] = row_divisor(nb[bi * Nd + jj]);
             }
         };
-        uint4 raw[4][RAW];                             // pieces in flight: dst rows 0 / 1, src rows 0 / 1
+        uint4 raw[2 + XSU][RAW];                       // pieces in flight: dst rows 0 / 1, then the src rows
         auto fetch = [&](int kt) {
             const int64_t k = (int64_t)kt * XK + pg * 8;
             const bool kin = k < C;                    // C % 8 == 0: a piece is inside or outside as a whole
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int h = 0; h < RAW; ++h) {
 #pragma unroll
-                for (int h = 0; h < RAW; ++h) {
+                for (int u = 0; u < 2; ++u)
                     raw[u][h] = (kin && vd[u]) ? *reinterpret_cast<const uint4 *>(pd[u] + k + h * (8 / RAW)) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < XSU; ++u)
                     raw[2 + u][h] = (kin && vs[u]) ? *reinterpret_cast<const uint4 *>(ps[u] + k + h * (8 / RAW)) : make_uint4(0, 0, 0, 0);
-                }
             }
         };
         // one piece: 8 token values -> xhat (bit-identical to x / norm) -> the two k-halves of its panel group
-        auto stage = [&](const uint4 (&rw)[RAW], const RowDivisor &d, bool valid, float *panel, int row) {
+        auto stage = [&](const uint4 (&rw)[RAW], const RowDivisor &d, bool valid, float *panel, int XP, int row) {
             float f[8], o[8];
             if constexpr (sizeof(T) == 4) {
                 f[0] = __uint_as_float(rw[0].x); f[1] = __uint_as_float(rw[0].y); f[2] = __uint_as_float(rw[0].z); f[3] = __uint_as_float(rw[0].w);
@@ -1176,9 +1182,14 @@ __global__ __launch_bounds__(256, 2) void exact_rows_kernel(
             *reinterpret_cast<float4 *>(&panel[((pg * 2 + 1) * XP + row) * 4]) = make_float4(o[1], o[3], o[5], o[7]);
         };
 
-        f32x16 acc[4];
-        float bestv = -INFINITY;
-        uint32_t besti = 0xffffffffu;
+        f32x16 acc[4][XSB];
+        float bestv[XSB];
+        uint32_t besti[XSB];
+#pragma unroll
+        for (int sb = 0; sb < XSB; ++sb) {
+            bestv[sb] = -INFINITY;
+            besti[sb] = 0xffffffffu;
+        }
         const int steps = (jt1 - jt0) * KT;
         dst_rows(jt0);
         fetch(0);
@@ -1186,10 +1197,9 @@ __global__ __launch_bounds__(256, 2) void exact_rows_kernel(
         for (int st = 0; st < steps; ++st) {
             __syncthreads();                           // everybody has read the previous step's panels
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                stage(raw[u], dd[u], vd[u], sD, prow + 64 * u);
-                stage(raw[2 + u], ds[u], vs[u], sS, prow + 64 * u);
-            }
+            for (int u = 0; u < 2; ++u) stage(raw[u], dd[u], vd[u], sD, XPD, prow + 64 * u);
+#pragma unroll
+            for (int u = 0; u < XSU; ++u) stage(raw[2 + u], ds[u], vs[u], sS, XPS, prow + 64 * u);
             __syncthreads();
             const bool wrap = kt + 1 == KT;
             if (st + 1 < steps) {                      // next step's pieces fly behind this step's MFMAs
@@ -1200,20 +1210,27 @@ __global__ __launch_bounds__(256, 2) void exact_rows_kernel(
             for (int g = 0; g < 4; ++g) {
                 float4 af[4];
 #pragma unroll
-                for (int ib = 0; ib < 4; ++ib) af[ib] = *reinterpret_cast<const float4 *>(&sD[((g * 2 + kh) * XP + ib * 32 + l31) * 4]);
-                const float4 bf = *reinterpret_cast<const float4 *>(&sS[((g * 2 + kh) * XP + wave * 32 + l31) * 4]);
-                const float bv[4] = {bf.x, bf.y, bf.z, bf.w};
+                for (int ib = 0; ib < 4; ++ib) af[ib] = *reinterpret_cast<const float4 *>(&sD[((g * 2 + kh) * XPD + ib * 32 + l31) * 4]);
+                float bv[XSB][4];
+#pragma unroll
+                for (int sb = 0; sb < XSB; ++sb) {
+                    const float4 bf = *reinterpret_cast<const float4 *>(&sS[((g * 2 + kh) * XPS + wave * (32 * XSB) + sb * 32 + l31) * 4]);
+                    bv[sb][0] = bf.x; bv[sb][1] = bf.y; bv[sb][2] = bf.z; bv[sb][3] = bf.w;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
 #pragma unroll
                     for (int ib = 0; ib < 4; ++ib) {
                         const float av = e == 0 ? af[ib].x : e == 1 ? af[ib].y : e == 2 ? af[ib].z : af[ib].w;
-                        f32x16 c = acc[ib];
-                        if (kt == 0 && g == 0 && e == 0) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+                        for (int sb = 0; sb < XSB; ++sb) {
+                            f32x16 c = acc[ib][sb];
+                            if (kt == 0 && g == 0 && e == 0) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+                            }
+                            acc[ib][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[sb][e], c, 0, 0, 0);
                         }
-                        acc[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e], c, 0, 0, 0);
                     }
                 }
             }
@@ -1221,16 +1238,23 @@ __global__ __launch_bounds__(256, 2) void exact_rows_kernel(
                 const int dst0 = jt * XD + 4 * kh;
                 const bool full = (int64_t)(jt + 1) * XD <= Nd;
 #pragma unroll
-                for (int ib = 0; ib < 4; ++ib) {
+                for (int sb = 0; sb < XSB; ++sb) {
+                    float bv_ = bestv[sb];
+                    uint32_t bi_ = besti[sb];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int d = dst0 + ib * 32 + (r & 3) + 8 * (r >> 2);
-                        const float sc = acc[ib][r];
-                        bool upd = !(sc <= bestv) && (bestv == bestv);   // greater, or the first NaN (torch.max)
-                        if (!full) upd = upd && (d < Nd);
-                        bestv = upd ? sc : bestv;
-                        besti = upd ? (uint32_t)d : besti;
+                    for (int ib = 0; ib < 4; ++ib) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int d = dst0 + ib * 32 + (r & 3) + 8 * (r >> 2);
+                            const float sc = acc[ib][sb][r];
+                            bool upd = !(sc <= bv_) && (bv_ == bv_);   // greater, or the first NaN (torch.max)
+                            if (!full) upd = upd && (d < Nd);
+                            bv_ = upd ? sc : bv_;
+                            bi_ = upd ? (uint32_t)d : bi_;
+                        }
                     }
+                    bestv[sb] = bv_;
+                    besti[sb] = bi_;
                 }
                 ++jt;
                 kt = 0;
@@ -1238,10 +1262,13 @@ __global__ __launch_bounds__(256, 2) void exact_rows_kernel(
                 ++kt;
             }
         }
-        const int64_t i = listed(wave * 32 + l31);
-        if (i >= 0 && besti != 0xffffffffu) {
-            const uint32_t col = besti + (align ? (uint32_t)(bi * Nd) : 0u);
-            atomicMax(&best[align ? i : l * Ns + i], ((unsigned long long)orderable(bestv) << 32) | (uint32_t)(~col));
+#pragma unroll
+        for (int sb = 0; sb < XSB; ++sb) {
+            const int64_t i = listed(wave * (32 * XSB) + sb * 32 + l31);
+            if (i >= 0 && besti[sb] != 0xffffffffu) {
+                const uint32_t col = besti[sb] + (align ? (uint32_t)(bi * Nd) : 0u);
+                atomicMax(&best[align ? i : l * Ns + i], ((unsigned long long)orderable(bestv[sb]) << 32) | (uint32_t)(~col));
+            }
         }
     }
 }
@@ -1409,7 +1436,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         xsplit = xsplit < 1 ? 1 : xsplit > 16 ? 16 : xsplit;
         const int xtps = (int)vtm::cdiv(xd_tiles, xsplit);
         xsplit = (int)vtm::cdiv(xd_tiles, xtps);
-        const dim3 xgrid((unsigned)(2 * vtm::device_cus()));
+        const dim3 xgrid((unsigned)((XS == 128 ? 2 : 1) * vtm::device_cus()));
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(refine_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
