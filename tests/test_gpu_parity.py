@@ -366,7 +366,7 @@ def test_match_filtered_mid_global_size(L):
     _filtered_vs_exact(L, x, Ns, Nd, False, expect_flag=0)
 
 
-@pytest.mark.parametrize("n", [1, 17, 1000, 1024, 5000, 49152, 110592])
+@pytest.mark.parametrize("n", [1, 2, 17, 1000, 1024, 3072, 5000, 8704, 12288, 16384, 16385, 49152, 110592])
 def test_sort_desc(L, oracle, n):
     rng = np.random.default_rng(n)
     k = rng.standard_normal((2, n)).astype(np.float32)
