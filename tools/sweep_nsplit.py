@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Sweep the dst-split count of the filtered matcher (VTM_DEBUG_NSPLIT hook) over the cfg-2 shapes.
-    python tools/sweep_nsplit.py            (needs an MI355X)"""
+    python tools/sweep_nsplit.py [--shuffle] [--kp]           (needs an MI355X)
+--shuffle: the src and the dst rows are handed over in a random order (what level 2 and the global level look like in a real
+pass: the merged sequence is sorted by similarity rank, a row's matches are scattered over the dst range) instead of position order;
+--kp: sweep the pruning depth (VTM_DEBUG_KP) at the default split count instead."""
 import os
 import sys
 
@@ -29,6 +32,7 @@ def timeit(fn, iters=7):
 
 
 def main():
+    shuffle, kp = "--shuffle" in sys.argv, "--kp" in sys.argv
     g = torch.Generator(device="cuda").manual_seed(0)
     for name, (B, Ns, Nd, C) in SHAPES.items():
         # frame-correlated tokens like bench.py's: every src row has a near copy among the dst rows
@@ -37,7 +41,21 @@ def main():
         x = (base[:, idx] + 0.1 * torch.randn(B, Ns + Nd, C, generator=g, device="cuda")).half()
         ra = torch.arange(Ns, dtype=torch.int32, device="cuda").expand(B, Ns).contiguous()
         rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device="cuda").expand(B, Nd).contiguous()
+        if shuffle:
+            ra = torch.stack([torch.randperm(Ns, generator=g, device="cuda") for _ in range(B)]).to(torch.int32).contiguous()
+            rb = (Ns + torch.stack([torch.randperm(Nd, generator=g, device="cuda") for _ in range(B)])).to(torch.int32).contiguous()
         os.environ.pop("VTM_DEBUG_NSPLIT", None)
+        os.environ.pop("VTM_DEBUG_KP", None)
+        if kp:
+            ref = _lib.match_filtered(x, None, ra, rb, False)
+            out = [f"default {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}"]
+            for v in range(0, C // 64):
+                os.environ["VTM_DEBUG_KP"] = str(v)
+                assert torch.equal(_lib.match_filtered(x, None, ra, rb, False), ref)
+                out.append(f"kp{v}: {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}")
+            os.environ.pop("VTM_DEBUG_KP", None)
+            print(f"{name:7s} us  " + "  ".join(out), flush=True)
+            continue
         ref = _lib.match_filtered(x, None, ra, rb, False)
         out = [f"default {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}"]
         for ns in range(2, 15):
