@@ -269,7 +269,7 @@ class KernelTimer:
         self._wrap("attention_kv", "attention", kv_flops)
         # match_filtered(x0, x1, a_rows, b_rows, align): 2 * B * Ns * Nd * C algorithmic flops
         self._wrap("match_filtered", "matching",
-                   lambda x0, x1, ar, br, align, want_flag=False: 2.0 * x0.shape[0] * ar.shape[1] * br.shape[1] * x0.shape[2])
+                   lambda x0, x1, ar, br, align, want_flag=False, seed=None: 2.0 * x0.shape[0] * ar.shape[1] * br.shape[1] * x0.shape[2])
         # the matcher's device-side counters (refined pairs, escaped rows) come from ONE extra, untimed pass after the timed
         # region (`count`): the read-back is a small device copy per call that must not sit inside the event brackets
         timed_match = self.lib_mod.match_filtered
@@ -277,10 +277,10 @@ class KernelTimer:
 
         self.count = False             # set for ONE untimed pass after the timed region
 
-        def match_with_counters(x0, x1, ar, br, align, want_flag=False):
+        def match_with_counters(x0, x1, ar, br, align, want_flag=False, seed=None):
             if not self.count or want_flag:
-                return timed_match(x0, x1, ar, br, align, want_flag)
-            best, flag = timed_match(x0, x1, ar, br, align, True)
+                return timed_match(x0, x1, ar, br, align, want_flag, seed=seed)
+            best, flag = timed_match(x0, x1, ar, br, align, True, seed=seed)
             self.match_flags.append((flag, ar.shape[1] if align else x0.shape[0] * ar.shape[1]))
             return best
         self.lib_mod.match_filtered = match_with_counters

@@ -92,24 +92,38 @@ int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd,
  * vtm_match_filtered -- the same packed result as vtm_normalize_gather x2 + vtm_match, BIT FOR BIT, several
  * times faster: an fp16-MFMA filter pass (operands hi = fp16(1024*xhat), one product hi_dst * hi_src;
  * the residual lo terms are a build-time option) collects for every src row the dst rows whose approximate score lies within a
- * rigorous error window of the row's running maximum, and an fp32 refine pass evaluates the canonical
- * fmaf chain on those candidates only.  A row with more than 64 candidates (massively duplicated dst
- * rows) is recomputed exactly on its own; a row without a finite positive norm (zero token -> NaN xhat,
- * merge.py:84 has no eps), or with a norm outside [2^-100, 2^100], raises a device flag that makes the refine pass recompute EVERY row of the call
- * exactly (no host round trip).  Four launches per call: operand preparation (canonical norms + fp16 panels),
- * filter, survivor compaction, refine.  C > 1280 is rejected (the error budget is derived for C <= 1280; use
- * vtm_match).
+ * rigorous error window of the row's running maximum -- skipping the rest of a 32 x 32 block once a Cauchy-Schwarz bound on
+ * the channels still to come says that none of its pairs can reach that window -- and an fp32 refine pass evaluates the
+ * canonical fmaf chain on those candidates only.  Bounded escapes: a row with more than 64 candidates (flat image
+ * regions, massively duplicated dst rows), or whose own norm is not a finite positive number in [2^-100, 2^100], is recomputed
+ * by exact fp32-MFMA score tiles against all dst rows; a DST row of that kind (zero token -> NaN xhat, merge.py:84 has no eps)
+ * makes that kernel recompute every row of the call (device flag, no host round trip).  Four launches per call (operand
+ * preparation, filter, refine, escape).  C > 1280 is rejected (the error budget is derived for C <= 1280; use vtm_match).
  * Inputs are the token pool (x0 | x1, as vtm_normalize_gather) and the gathered pool ids a_rows (B, Ns),
- * b_rows (B, Nd).  ws: >= vtm_match_filtered_ws_bytes(...) bytes.  flags_out (optional, 4 int32,
- * device): [0] = [1] = 1 if every row was recomputed exactly (non-finite component), [2] = number of
- * rows recomputed exactly because their candidate list overflowed, [3] = number of (row, dst) pairs the
- * refine pass evaluated.  Derivation of the window: vidtome_amd/csrc/match_filter.hip.
+ * b_rows (B, Nd); B * Nd < 2^31.  ws: >= vtm_match_filtered_ws_bytes(...) bytes.  flags_out (optional, 4 int32,
+ * device): [0] = 1 if every row was recomputed exactly (a dst row without a usable norm), [1] = 1 if any row without a
+ * usable norm was seen, [2] = number of rows recomputed by the escape because their candidate list overflowed or their own
+ * norm was unusable, [3] = number of (row, dst) pairs the refine pass evaluated.  Derivation of the window:
+ * vidtome_amd/csrc/match_filter.hip.
+ *
+ * vtm_match_filtered_seeded -- the same result, usually faster on video tokens: before the filter starts every src row gets
+ * a starting maximum from ONE guessed pair, the dst row at the same token position (one more small launch).  seed_N =
+ * tokens per frame (0 = no seeds = vtm_match_filtered); pool rows < seed_L are tokens of the joined chunk (position =
+ * row % seed_N), the rows of x1 have the positions seed_pos1 (B, P1) or, NULL, none; seed_table (B, seed_N) maps a position to
+ * a dst index (vtm_partition_global writes it), NULL = identity (a local level: the first dst frame's rows are dst
+ * indices 0 .. seed_N-1).  The score of an actual pair is a valid running maximum, so the result cannot change; a useless
+ * guess only fails to help.
  * ---------------------------------------------------------------------------------------------- */
 size_t vtm_match_filtered_ws_bytes(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align);
 int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
                        int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
                        int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
                        vtm_stream_t stream);
+int vtm_match_filtered_seeded(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                              int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
+                              int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
+                              int64_t seed_L, int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table,
+                              vtm_stream_t stream);
 
 /* node_max (fp32, -0 canonicalised to +0) and node_idx (int32) out of packed keys; either output may
  * be NULL. */
@@ -147,10 +161,21 @@ int vtm_partition_local(const int32_t *cur, int64_t B, int64_t N_in, int64_t unm
  * `cat([local, global])` (local_is_src != 0, patch.py:63-66) or `cat([global, local])`
  * (patch.py:68-71).  cur_local (B, Ml) pool ids of the local merged tokens; the anchors are pool
  * rows [anchor_base, anchor_base + Mg).  Outputs a_pos/b_pos/a_rows/b_rows as above with
- * Ns = src_len, Nd = Ml + Mg - src_len. */
+ * Ns = src_len, Nd = Ml + Mg - src_len.
+ * seed_table (optional, (B, tokens) int32, tokens = tokens per frame): filled with, for every token position, the index of
+ * ONE dst row holding that position (-1: none) -- what vtm_match_filtered_seeded takes; local tokens have position
+ * pool id % tokens, anchor j has anchor_pos[b, j] ((B, Mg), optional: without it anchors have no position). */
 int vtm_partition_global(const int32_t *cur_local, int64_t B, int64_t Ml, int64_t anchor_base,
                          int64_t Mg, int local_is_src, int32_t *a_pos, int32_t *b_pos,
-                         int32_t *a_rows, int32_t *b_rows, vtm_stream_t stream);
+                         int32_t *a_rows, int32_t *b_rows, int32_t *seed_table, int64_t tokens,
+                         const int32_t *anchor_pos, vtm_stream_t stream);
+
+/* vtm_anchor_pos -- token positions of a new anchor set (the host tracks them next to module.global_tokens so that the
+ * next global level can be seeded): anchors_out[b, p] = pool[b, amap[b, p]] (patch.py:80; amap == NULL: the first M pool
+ * rows, patch.py:82), pool = [joined chunk: L rows, position = row % tokens | old anchors: old_pos (B, Mg) or NULL].
+ * out (B, M) int32, -1 where the position is unknown. */
+int vtm_anchor_pos(const int32_t *amap, int64_t B, int64_t M, int64_t L, int64_t tokens, const int32_t *old_pos,
+                   int64_t Mg, int32_t *out, vtm_stream_t stream);
 
 /* vtm_plan_apply -- the index split after the sort (merge.py:100-117 / 404-421) and the bookkeeping
  * of the merge / unmerge closures (merge.py:119-155 / 423-460) as composed maps:

@@ -267,6 +267,50 @@ def test_match_filtered_escape_rows_equal_exact(L, dtype, align):
         _filtered_vs_exact(L, x, Ns, Nd, align, expect_flag=1)
 
 
+def test_match_filtered_seeds_never_change_the_result(L):
+    """vtm_match_filtered_seeded starts every src row from the score of ONE guessed pair (the dst row at the same token
+    position).  Any pair's score is a valid running maximum, so the packed result must equal the exact matcher's bit for
+    bit WHATEVER the guesses are: the right ones (identity table on frame-ordered rows), a random table, positions for the x1
+    rows, out-of-range and missing entries, aligned batches -- and with the right ones a flat-region input sends only its flat
+    rows to the exact escape (the rows that merely MEET the flat region first no longer overflow)."""
+    from vidtome_amd import sites
+    g = torch.Generator().manual_seed(33)
+    B, F, N, C, fs = 2, 8, 256, 320, 6
+    x = sites.regime_tokens("flat25", B, F, N, C, g)
+    x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, F * N, C).half().to(DEV)
+    Ns, Nd = fs * N, (F - fs) * N
+    ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+    rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+    a_op, _ = L.normalize_gather(x, None, ra)
+    b_op, _ = L.normalize_gather(x, None, rb)
+    for align in (False, True):
+        exact = L.match(a_op, b_op, Ns, Nd, align)
+        plain, f0 = L.match_filtered(x, None, ra, rb, align, want_flag=True)
+        assert torch.equal(plain, exact)
+        # the right guesses: src row i is token (i // N, i % N), dst index p is the token at position p of the first dst frame
+        seeded, f1 = L.match_filtered(x, None, ra, rb, align, want_flag=True, seed=(N, F * N, None, None))
+        assert torch.equal(seeded, exact)
+        if not align:
+            assert f1[2].item() <= f0[2].item() and f1[2].item() <= 0.3 * B * Ns, (f0.tolist(), f1.tolist())
+        # garbage guesses
+        table = torch.randint(-3, Nd + 50, (B, N), generator=g, dtype=torch.int32).to(DEV)
+        assert torch.equal(L.match_filtered(x, None, ra, rb, align, seed=(N, F * N, None, table)), exact)
+        assert torch.equal(L.match_filtered(x, None, ra, rb, align, seed=(N, 100, None, table)), exact)       # most rows: no position
+    # two-part pool: the dst rows live in x1 and carry positions
+    x0, x1 = x[:, :Ns].contiguous(), x[:, Ns:].contiguous()
+    rb1 = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+    pos1 = (torch.arange(Nd, dtype=torch.int32, device=DEV) % N).expand(B, Nd).contiguous()
+    table = torch.arange(N, dtype=torch.int32, device=DEV).expand(B, N).contiguous()
+    exact = L.match(a_op, b_op, Ns, Nd, False)
+    assert torch.equal(L.match_filtered(x0, x1, ra, rb1, False, seed=(N, Ns, pos1, table)), exact)
+    # ... and the src rows in x1 (anchors as the src side): positions come from pos1
+    ra1 = rb1
+    rb0 = torch.arange(0, Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+    e2 = L.match(b_op, a_op, Nd, Ns, False)
+    t2 = torch.arange(N, dtype=torch.int32, device=DEV).expand(B, N).contiguous()
+    assert torch.equal(L.match_filtered(x0, x1, ra1, rb0, False, seed=(N, Ns, pos1, t2)), e2)
+
+
 def test_match_filtered_worst_cases_are_bounded(L):
     """TIME, not only bits: the escapes of the filtered matcher must cost what the exact fp32-MFMA matcher
     costs, not the ~1000x of the scalar row pass rounds 1-3 fell back to.  cfg-2 top-block level 1 (2 x 49 152 x 16 384 x

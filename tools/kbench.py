@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--B", type=int, default=2)
     ap.add_argument("--n", type=int, default=49152)
     ap.add_argument("--align", action="store_true")
+    ap.add_argument("--seed", action="store_true", help="match: seed the filtered matcher with same-position guesses (the rows of a "
+                    "kbench call are frame-ordered: dst index = position in the first dst frame)")
     ap.add_argument("--C", type=int, default=320)
     ap.add_argument("--data", default="random", help="attn: random | zeros | const (operand values); match: n01 | corr01 | "
                     "corr05 | flat25 | dup | zero | all (token regime; random = n01 in fp16 straight from the device generator)")
@@ -62,12 +64,14 @@ def main():
         ra = torch.arange(Ns, dtype=torch.int32, device=dev).expand(B, Ns).contiguous()
         rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=dev).expand(B, Nd).contiguous()
 
+        N = 4096
+        while Ns % N or Nd % N:
+            N //= 2
+        seed = (N, Ns + Nd, None, None) if a.seed else None
+
         def tokens(regime):
             if regime == "random":
                 return torch.randn(B, Ns + Nd, C, generator=g, device=dev, dtype=torch.float16)
-            N = 4096
-            while Ns % N or Nd % N:
-                N //= 2
             gc = torch.Generator().manual_seed(0)
             x = sites.regime_tokens("corr05" if regime == "zero" else regime, B, (Ns + Nd) // N, N, C, gc)
             x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, Ns + Nd, C).half()   # the matcher sees norm1's output
@@ -77,15 +81,15 @@ def main():
 
         regimes = ["n01", "corr01", "corr05", "flat25", "dup", "zero"] if a.data == "all" else [a.data]
         fl = 2.0 * B * Ns * Nd * C
-        print(f"match {a.shape} B={B} Ns={Ns} Nd={Nd} C={C} align={a.align}")
+        print(f"match {a.shape} B={B} Ns={Ns} Nd={Nd} C={C} align={a.align} seeded={bool(seed)}")
         print(f"{'data':8s} {'filtered ms':>12s} {'alg TFLOP/s':>12s} {'exact ms':>9s} {'pairs/row':>10s} {'escape rows':>12s} {'whole-call':>10s} equal")
         for regime in regimes:
             x = tokens(regime)
             aop, _ = _lib.normalize_gather(x, None, ra)
             bop, _ = _lib.normalize_gather(x, None, rb)
             med, best = timeit(lambda: _lib.match(aop, bop, Ns, Nd, a.align), a.iters)
-            medf, bestf = timeit(lambda: _lib.match_filtered(x, None, ra, rb, a.align), a.iters)
-            out, fl_ = _lib.match_filtered(x, None, ra, rb, a.align, want_flag=True)
+            medf, bestf = timeit(lambda: _lib.match_filtered(x, None, ra, rb, a.align, seed=seed), a.iters)
+            out, fl_ = _lib.match_filtered(x, None, ra, rb, a.align, want_flag=True, seed=seed)
             same = bool(torch.equal(out, _lib.match(aop, bop, Ns, Nd, a.align)))
             f = fl_.tolist()                # [whole-call exact, non-finite, escape rows, refined pairs]
             rows = Ns if a.align else B * Ns

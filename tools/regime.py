@@ -45,10 +45,10 @@ def main():
     flags = []
     orig_mf = _lib.match_filtered
 
-    def mf(x0, x1, ar, br, align, want_flag=False):
+    def mf(x0, x1, ar, br, align, want_flag=False, seed=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        best, flag = orig_mf(x0, x1, ar, br, align, want_flag=True)
+        best, flag = orig_mf(x0, x1, ar, br, align, want_flag=True, seed=seed)
         e1.record()
         flags.append((ar.shape[1], br.shape[1], flag, e0, e1))
         return best

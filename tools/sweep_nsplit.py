@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sweep the dst-split count of the filtered matcher (VTM_DEBUG_NSPLIT hook) over the cfg-2 shapes.
-    python tools/sweep_nsplit.py [--shuffle] [--kp]           (needs an MI355X)
+    python tools/sweep_nsplit.py [--shuffle] [--kp] [--regime NAME]           (needs an MI355X)
 --shuffle: the src and the dst rows are handed over in a random order (what level 2 and the global level look like in a real
 pass: the merged sequence is sorted by similarity rank, a row's matches are scattered over the dst range) instead of position order;
 --kp: sweep the pruning depth (VTM_DEBUG_KP) at the default split count instead."""
@@ -39,6 +39,14 @@ def main():
         base = torch.randn(B, Nd, C, generator=g, device="cuda")
         idx = torch.arange(Ns + Nd, device="cuda") % Nd
         x = (base[:, idx] + 0.1 * torch.randn(B, Ns + Nd, C, generator=g, device="cuda")).half()
+        if "--regime" in sys.argv:       # the bench's token regimes (sites.DATA_REGIMES) after a LayerNorm, frames of N tokens
+            from vidtome_amd import sites
+            regime = sys.argv[sys.argv.index("--regime") + 1]
+            N = 4096
+            while Ns % N or Nd % N:
+                N //= 2
+            xx = sites.regime_tokens(regime, B, (Ns + Nd) // N, N, C, torch.Generator().manual_seed(0))
+            x = torch.nn.functional.layer_norm(xx, (C,)).reshape(B, Ns + Nd, C).half().cuda()
         ra = torch.arange(Ns, dtype=torch.int32, device="cuda").expand(B, Ns).contiguous()
         rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device="cuda").expand(B, Nd).contiguous()
         if shuffle:

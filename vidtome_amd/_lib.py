@@ -38,12 +38,15 @@ _SIGNATURES = {
     "vtm_match_filtered_ws_bytes": ([_i64, _i64, _i64, _i64, _int], ctypes.c_size_t),
     "vtm_match_filtered": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
                             _vp, _vp, _vp], _int),
+    "vtm_match_filtered_seeded": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
+                                   _vp, _vp, _i64, _i64, _vp, _vp, _vp], _int),
+    "vtm_anchor_pos": ([_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp], _int),
     "vtm_decode_best": ([_vp, _i64, _vp, _vp, _vp], _int),
     "vtm_sort_ws_bytes": ([_i64, _i64], ctypes.c_size_t),
     "vtm_sort_desc": ([_vp, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_partition_counts": ([_i64, _i64, _i64, _i64, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)], _int),
     "vtm_partition_local": ([_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp], _int),
-    "vtm_partition_global": ([_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp], _int),
+    "vtm_partition_global": ([_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp], _int),
     "vtm_plan_apply": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp,
                         _vp, _vp], _int),
     "vtm_compose": ([_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp], _int),
@@ -207,8 +210,11 @@ def match(a: torch.Tensor, b: torch.Tensor, Ns: int, Nd: int, align: bool) -> to
 
 @_on_device
 def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.Tensor, b_rows: torch.Tensor,
-                   align: bool, want_flag: bool = False):
-    """Same packed result as normalize_gather x2 + match, through the fp16-filter / fp32-refine path."""
+                   align: bool, want_flag: bool = False, seed=None):
+    """Same packed result as normalize_gather x2 + match, through the fp16-filter / fp32-refine path.  ``seed`` (optional,
+    never changes the result): (tokens per frame N, L = pool rows that are chunk tokens, pos1 (B, P1) int32 positions of the
+    x1 rows or None, table (B, N) int32 position -> dst index or None for identity) -- every src row then starts from the
+    score of the dst row at its own token position (vtm_match_filtered_seeded)."""
     _req(x0, "x0"), _req(a_rows, "a_rows"), _req(b_rows, "b_rows")
     B, P0, C = x0.shape
     P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
@@ -217,6 +223,17 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
     ws = _workspace("match", nbytes, x0.device)
     best = torch.empty((1 if align else B, Ns), dtype=torch.int64, device=x0.device)
     flag = torch.zeros((4,), dtype=torch.int32, device=x0.device) if want_flag else None   # any, special, fifo, cap
+    if seed is not None and SEED_MATCHER:
+        sN, sL, pos1, table = seed
+        if pos1 is not None and (pos1.dtype != torch.int32 or tuple(pos1.shape) != (B, P1) or not pos1.is_contiguous()):
+            raise RuntimeError("match_filtered: seed positions must be a contiguous (B, P1) int32 tensor")
+        if table is not None and (table.dtype != torch.int32 or tuple(table.shape) != (B, sN) or not table.is_contiguous()):
+            raise RuntimeError("match_filtered: the seed table must be a contiguous (B, N) int32 tensor")
+        _check(lib().vtm_match_filtered_seeded(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(a_rows), Ns,
+                                               _ptr(b_rows), Nd, int(align), _ptr(ws), nbytes, _ptr(best), _ptr(flag),
+                                               int(sL), int(sN), _ptr(pos1), _ptr(table), _stream()),
+               "vtm_match_filtered_seeded")
+        return (best, flag) if want_flag else best
     _check(lib().vtm_match_filtered(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(a_rows), Ns, _ptr(b_rows),
                                     Nd, int(align), _ptr(ws), nbytes, _ptr(best), _ptr(flag), _stream()),
            "vtm_match_filtered")
@@ -261,8 +278,21 @@ def partition_local(cur: Optional[torch.Tensor], B: int, N_in: int, unm_pre: int
 
 
 @_on_device
-def partition_global(cur_local: torch.Tensor, anchor_base: int, Mg: int, local_is_src: bool
+def anchor_pos(amap: Optional[torch.Tensor], B: int, M: int, L: int, tokens: int, old_pos: Optional[torch.Tensor],
+               device) -> torch.Tensor:
+    """Token positions (B, M) int32 of a new anchor set = pool[amap] (amap None: the first M pool rows), pool = [chunk of L
+    rows | old anchors with positions old_pos]; -1 = unknown."""
+    out = torch.empty((B, M), dtype=torch.int32, device=device)
+    Mg = 0 if old_pos is None else old_pos.shape[1]
+    _check(lib().vtm_anchor_pos(_ptr(amap), B, M, L, tokens, _ptr(old_pos), Mg, _ptr(out), _stream()), "vtm_anchor_pos")
+    return out
+
+
+@_on_device
+def partition_global(cur_local: torch.Tensor, anchor_base: int, Mg: int, local_is_src: bool, seed_table: Optional[torch.Tensor] = None,
+                     tokens: int = 0, anchor_positions: Optional[torch.Tensor] = None
                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``seed_table`` (B, tokens) int32 (optional) is filled with position -> dst index for the matcher's seeds."""
     B, Ml = cur_local.shape
     src_len = Ml if local_is_src else Mg
     Nd = Ml + Mg - src_len
@@ -270,7 +300,8 @@ def partition_global(cur_local: torch.Tensor, anchor_base: int, Mg: int, local_i
     a_pos, b_pos = torch.empty((src_len,), **i32), torch.empty((Nd,), **i32)
     a_rows, b_rows = torch.empty((B, src_len), **i32), torch.empty((B, Nd), **i32)
     _check(lib().vtm_partition_global(_ptr(cur_local), B, Ml, anchor_base, Mg, int(local_is_src), _ptr(a_pos),
-                                      _ptr(b_pos), _ptr(a_rows), _ptr(b_rows), _stream()), "vtm_partition_global")
+                                      _ptr(b_pos), _ptr(a_rows), _ptr(b_rows), _ptr(seed_table), int(tokens),
+                                      _ptr(anchor_positions), _stream()), "vtm_partition_global")
     return a_pos, b_pos, a_rows, b_rows
 
 
@@ -355,6 +386,10 @@ def unmerge_add(y: torch.Tensor, inv: torch.Tensor, resid: Optional[torch.Tensor
            "vtm_unmerge_add")
     return out
 
+
+# A/B switch: seed the filtered matcher's running maxima from same-position guesses (profiles/r04_seeds.txt); results are
+# identical either way
+SEED_MATCHER = os.environ.get("VIDTOME_SEED", "1") != "0"
 
 # A/B switch (profiles/r04_attention_split_all.txt): split every work item of a query-bounded attention launch in two
 SPLIT_ALL_BOUNDED = os.environ.get("VIDTOME_ATT_SPLIT_ALL", "1") != "0"

@@ -262,6 +262,21 @@ class _BlockState:
         self.pool = None        # neighbour mode, early hand-over: the predecessor's joined chunk on its way here
 
 
+def _with_positions(tokens: torch.Tensor, row_map: Optional[torch.Tensor], tsize: int) -> torch.Tensor:
+    """Attach the token positions of an anchor set to its tensor (`_vtm_pos`, (B, M) int32: what compute_merge hands the
+    matcher's seed kernel; never changes a result).  The anchors are rows `row_map` (B, M) of a joined chunk whose frames hold
+    `tsize` tokens each (None: the chunk's rows themselves)."""
+    if not tokens.is_cuda:
+        return tokens
+    B, M = tokens.shape[0], tokens.shape[1]
+    if row_map is None:
+        pos = (torch.arange(M, dtype=torch.int32, device=tokens.device) % tsize).expand(B, M).contiguous()
+    else:
+        pos = (row_map.to(torch.int32) % tsize).contiguous()
+    tokens._vtm_pos = pos
+    return tokens
+
+
 class AnchorExchange:
     """See the module docstring.  Protocol, per denoising step::
 
@@ -451,8 +466,9 @@ class AnchorExchange:
                 if i == 0:
                     return None
                 self.bytes_received += pool.numel() * pool.element_size() + (0 if got_map is None else got_map.numel() * 4)
-                return pool if got_map is None else _lib.gather_rows(pool, None, got_map) if pool.is_cuda else \
+                got = pool if got_map is None else _lib.gather_rows(pool, None, got_map) if pool.is_cuda else \
                     torch.gather(pool, 1, got_map.long()[:, :, None].expand(-1, -1, C))
+                return _with_positions(got, got_map, st.tsize)
             local = local_tokens_fn().contiguous()
             st.lens[i] = local.shape[1]
             spec = ((B, st.lens[i - 1], C), like.dtype, like.device) if i > 0 else None
@@ -462,7 +478,7 @@ class AnchorExchange:
                 self.bytes_received += got.numel() * got.element_size()
             return got
         if self.world == 1:                                # the predecessor ran here: hand over in place (both parallel modes)
-            local = local_tokens_fn().contiguous()
+            local = _with_positions(local_tokens_fn().contiguous(), local_map, st.tsize)
             st.lens[i] = local.shape[1]
             got, st.carry = st.carry, local
             return got if i > 0 else None
@@ -495,8 +511,9 @@ class AnchorExchange:
             return None
         # chunk i-1 ran on rank W-1 in the previous round (rank 0), else on rank - 1 in this one
         pmap = (prev_round_last if self.rank == 0 else gathered[self.rank - 1][:, :st_lens[i - 1]]).contiguous()
-        return _lib.gather_rows(pool, None, pmap) if pool.is_cuda else \
+        got = _lib.gather_rows(pool, None, pmap) if pool.is_cuda else \
             torch.gather(pool, 1, pmap.long()[:, :, None].expand(-1, -1, C))
+        return _with_positions(got, pmap, st.tsize)
 
     def _skip_own_draws(self, gen: torch.Generator, st: _BlockState, i: int) -> None:
         """all-gather only: `gen` is a copy taken after this chunk's LOCAL draws; the coin of its global level (made by

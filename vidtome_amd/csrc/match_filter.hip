@@ -875,6 +875,56 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     }
 }
 
+// ---- seeds: a good running maximum for every src row BEFORE the filter starts ----
+// The filter collects candidates against a row's RUNNING maximum and prunes blocks against it, so what it costs depends on
+// how early that maximum is good: with the rows of level 2 / the global level arriving in similarity-sorted order a row's
+// true match sits anywhere in the dst range and most of the scan runs against a low maximum (more candidates, no pruning;
+// a flat image region seen first floods the row's list).  In a video the best match of a token is almost always a token
+// at the SAME spatial position of another frame, and positions are known: pool rows below `seed_L` are tokens of the joined
+// chunk (position = row % N), the rest carry their position in `pos1` (the anchors' positions, tracked by the host), and
+// `table` maps a position to one dst row holding it (identity when nullptr: the first dst frame of a local level).  A
+// workgroup's 8-lane groups each take a src row, fetch it and its guess row (5 + 5 coalesced 16-byte pieces per lane at
+// C = 320), and publish  (a . b) / (|a| |b|)  -- the score of a REAL pair, fp32, error ~1e-6 -- as the row's starting
+// maximum.  Exactness is untouched: any score of an actual pair is a valid running maximum (the window argument needs
+// t_ij* >= runmax - W, and t_ij* >= s_ij* - EPS >= s_ig - EPS); a useless guess only fails to help.
+template <typename T>
+__global__ __launch_bounds__(256) void seed_kernel(const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1, int64_t P1,
+                                                   int64_t B, int64_t C, const int32_t *__restrict__ a_rows, int64_t Ns,
+                                                   const int32_t *__restrict__ b_rows, int64_t Nd,
+                                                   const float *__restrict__ na, const float *__restrict__ nb, int align,
+                                                   int64_t seed_L, int64_t N, const int32_t *__restrict__ pos1,
+                                                   const int32_t *__restrict__ table, unsigned int *__restrict__ amax) {
+    constexpr int LPR = 8;                                   // lanes per row
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;     // (sample, src row)
+    const int sub = threadIdx.x & (LPR - 1);
+    if (g >= B * Ns) return;
+    const int64_t b = g / Ns, i = g % Ns;
+    const int32_t ra = a_rows[b * Ns + i];
+    int64_t pos = -1;
+    if (ra < seed_L) pos = ra % N;
+    else if (pos1 != nullptr && ra - P0 >= 0 && ra - P0 < P1) pos = pos1[b * P1 + (ra - P0)];
+    int64_t j = -1;
+    if (pos >= 0 && pos < N) j = table ? (int64_t)table[b * N + pos] : pos;
+    if (j < 0 || j >= Nd) return;                            // (uniform over the row's 8 lanes)
+    const T *pa = pool_row(x0, P0, x1, P1, b, ra, C);
+    const T *pb = pool_row(x0, P0, x1, P1, b, b_rows[b * Nd + j], C);
+    float acc = 0.0f;
+    for (int64_t k = sub * 8; k < C; k += LPR * 8) {
+        float fa[8], fb[8];
+        load8(pa + k, fa);
+        load8(pb + k, fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(fa[e], fb[e], acc);
+    }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub == 0) {
+        const float s = acc / (na[b * Ns + i] * nb[b * Nd + j]);
+        if (s == s && __builtin_fabsf(s) <= 1.5f)            // (a row without a usable norm publishes nothing)
+            atomicMax(&amax[align ? i : b * Ns + i], orderable(s));
+    }
+}
+
 // ---- refine: the candidates inside the window of each row's final approximate maximum, re-evaluated exactly ----
 // One launch (rounds 1-3: a compaction kernel + a pair kernel).  A workgroup owns 256 rows:
 //   1. it decides what kind of call this is -- every workgroup scans the same few hundred per-tile values prep_operand left
@@ -1314,10 +1364,11 @@ VTM_EXPORT size_t vtm_match_filtered_ws_bytes(int64_t B, int64_t C, int64_t Ns, 
     return make_layout(B, C, Ns, Nd, align).total;
 }
 
-VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
-                                  int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
-                                  int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
-                                  vtm_stream_t stream) {
+static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                               int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
+                               int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
+                               int64_t seed_L, int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table,
+                               vtm_stream_t stream) {
     VTM_REQUIRE(x0 && a_rows && b_rows && ws && best, "vtm_match_filtered: null pointer");
     VTM_REQUIRE(B > 0 && C > 0 && C % 8 == 0 && Ns > 0 && Nd > 0, "vtm_match_filtered: bad sizes");
     VTM_REQUIRE(P1 == 0 || x1, "vtm_match_filtered: x1 is null but P1 > 0");
@@ -1377,6 +1428,22 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         }
     }
 
+    if (seed_N > 0) {   // starting maxima from same-position guesses (a kernel boundary behind prep_operand: norms, cleared amax)
+        const dim3 grid((unsigned)vtm::cdiv(B * Ns * 8, 256)), block(256);
+        switch (dtype) {
+            case VTM_F32:
+                hipLaunchKernelGGL(seed_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1, B, C, a_rows,
+                                   Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax);
+                break;
+            case VTM_F16:
+                hipLaunchKernelGGL(seed_kernel<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1, P1, B, C,
+                                   a_rows, Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax);
+                break;
+            default:
+                hipLaunchKernelGGL(seed_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0, (const vtm_bf16 *)x1, P1, B,
+                                   C, a_rows, Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax);
+        }
+    }
     {
         const int ns_tiles = (int)(L.Ns_pad / FBS), nd_tiles = (int)(L.Nd_pad / FBD);
         const int total_src_tiles = (int)(B * ns_tiles);
@@ -1465,4 +1532,22 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
         if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: copy: %s", hipGetErrorString(e));
     }
     return VTM_OK;
+}
+
+VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                                  int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
+                                  int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
+                                  vtm_stream_t stream) {
+    return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, b_rows, Nd, align, ws, ws_bytes, best, flags_out, 0, 0,
+                               nullptr, nullptr, stream);
+}
+
+VTM_EXPORT int vtm_match_filtered_seeded(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                                         int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
+                                         int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
+                                         int64_t seed_L, int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table,
+                                         vtm_stream_t stream) {
+    VTM_REQUIRE(seed_N >= 0 && seed_L >= 0, "vtm_match_filtered_seeded: bad seed description");
+    return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, b_rows, Nd, align, ws, ws_bytes, best, flags_out, seed_L,
+                               seed_N, seed_pos1, seed_table, stream);
 }

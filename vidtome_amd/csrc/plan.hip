@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void partition_local_kernel(
 __global__ __launch_bounds__(256) void partition_global_kernel(
     const int32_t *__restrict__ cur_local, int64_t B, int64_t Ml, int64_t anchor_base, int64_t Mg,
     int local_is_src, int32_t *__restrict__ a_pos, int32_t *__restrict__ b_pos,
-    int32_t *__restrict__ a_rows, int32_t *__restrict__ b_rows) {
+    int32_t *__restrict__ a_rows, int32_t *__restrict__ b_rows, int32_t *__restrict__ table, int64_t tokens,
+    const int32_t *__restrict__ anchor_pos) {
     const int64_t N = Ml + Mg;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * N) return;
@@ -67,7 +68,32 @@ __global__ __launch_bounds__(256) void partition_global_kernel(
         const int64_t j = p - src_len;
         if (b == 0) b_pos[j] = (int32_t)p;
         b_rows[b * (N - src_len) + j] = row;
+        // the matcher's seeds (match_filter.hip, seed_kernel): token position -> ONE dst row holding that position (several
+        // frames hold it; whichever write lands last is as good as any other).  Local tokens: pool row % tokens per
+        // frame; anchors: the positions the host tracks with them.
+        if (table != nullptr) {
+            int64_t pos = -1;
+            if (row < anchor_base) pos = row % tokens;
+            else if (anchor_pos != nullptr) pos = anchor_pos[b * Mg + (row - anchor_base)];
+            if (pos >= 0 && pos < tokens) table[b * tokens + pos] = (int32_t)j;
+        }
     }
+}
+
+// positions of the rows of a new anchor set (patch.py:80,82): anchors_out[b, p] = pool[b, amap[b, p]] with pool =
+// [joined chunk (L rows, position = row % tokens) | old anchors (their tracked positions)]; amap == nullptr: rows 0 .. M-1
+// of the pool themselves
+__global__ __launch_bounds__(256) void anchor_pos_kernel(const int32_t *__restrict__ amap, int64_t B, int64_t M, int64_t L,
+                                                         int64_t tokens, const int32_t *__restrict__ old_pos, int64_t Mg,
+                                                         int32_t *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * M) return;
+    const int64_t b = idx / M;
+    const int64_t row = amap ? amap[idx] : idx % M;
+    int32_t pos = -1;
+    if (row < L) pos = (int32_t)(row % tokens);
+    else if (old_pos != nullptr && row - L < Mg) pos = old_pos[b * Mg + (row - L)];
+    out[idx] = pos;
 }
 
 // merge.py:100-117 (index split) + 119-155 (closure bookkeeping as maps).
@@ -280,13 +306,27 @@ VTM_EXPORT int vtm_partition_local(const int32_t *cur, int64_t B, int64_t N_in, 
 
 VTM_EXPORT int vtm_partition_global(const int32_t *cur_local, int64_t B, int64_t Ml, int64_t anchor_base,
                                     int64_t Mg, int local_is_src, int32_t *a_pos, int32_t *b_pos,
-                                    int32_t *a_rows, int32_t *b_rows, vtm_stream_t stream) {
+                                    int32_t *a_rows, int32_t *b_rows, int32_t *seed_table, int64_t tokens,
+                                    const int32_t *anchor_pos, vtm_stream_t stream) {
     VTM_REQUIRE(cur_local && a_pos && b_pos && a_rows && b_rows, "vtm_partition_global: null pointer");
     VTM_REQUIRE(B > 0 && Ml > 0 && Mg > 0, "vtm_partition_global: bad sizes");
+    VTM_REQUIRE(seed_table == nullptr || tokens > 0, "vtm_partition_global: seed table without a token count");
+    if (seed_table) {     // "no dst row holds this position" = -1
+        const hipError_t e = hipMemsetAsync(seed_table, 0xff, (size_t)B * tokens * sizeof(int32_t), vtm::as_stream(stream));
+        if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_partition_global: memset: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(partition_global_kernel, dim3(blocks_for(B * (Ml + Mg))), dim3(256), 0,
                        vtm::as_stream(stream), cur_local, B, Ml, anchor_base, Mg, local_is_src, a_pos,
-                       b_pos, a_rows, b_rows);
+                       b_pos, a_rows, b_rows, seed_table, tokens, anchor_pos);
     return vtm::launch_status("vtm_partition_global");
+}
+
+VTM_EXPORT int vtm_anchor_pos(const int32_t *amap, int64_t B, int64_t M, int64_t L, int64_t tokens, const int32_t *old_pos,
+                              int64_t Mg, int32_t *out, vtm_stream_t stream) {
+    VTM_REQUIRE(out && B > 0 && M > 0 && L >= 0 && tokens > 0, "vtm_anchor_pos: bad arguments");
+    hipLaunchKernelGGL(anchor_pos_kernel, dim3(blocks_for(B * M)), dim3(256), 0, vtm::as_stream(stream), amap, B, M, L, tokens,
+                       old_pos, Mg, out);
+    return vtm::launch_status("vtm_anchor_pos");
 }
 
 VTM_EXPORT int vtm_plan_apply(const uint64_t *best, const int32_t *perm, const int32_t *a_pos,

@@ -58,7 +58,7 @@ class Level:
 
 
 def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float, align_batch: bool,
-               want_indices: bool) -> Level:
+               want_indices: bool, seed=None) -> Level:
     """normalise+split -> fused score/top-1 -> argsort -> index split  (merge.py:84-117 / 389-421)."""
     a_pos, b_pos, a_rows, b_rows = parts
     Ns, Nd = a_rows.shape[1], b_rows.shape[1]
@@ -68,7 +68,7 @@ def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float
         b_op, _ = _lib.normalize_gather(x0, x1, b_rows)
         best = _lib.match(a_op, b_op, Ns, Nd, align_batch)
     else:                                              # fp16 filter + fp32 refine: same bits, ~4x faster
-        best = _lib.match_filtered(x0, x1, a_rows, b_rows, align_batch)
+        best = _lib.match_filtered(x0, x1, a_rows, b_rows, align_batch, seed=seed)
     perm = _lib.sort_desc(best)
     new_cur, inv, unm_idx, src_idx, dst_idx = _lib.plan_apply(best, perm, a_pos, b_pos, a_rows, b_rows, r,
                                                               align_batch, want_indices)
@@ -76,24 +76,34 @@ def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float
 
 
 def local_level(x0: torch.Tensor, cur: Optional[torch.Tensor], N_in: int, F: int, ratio: float, unm_pre: int,
-                randf: int, target_stride: int, align_batch: bool, want_indices: bool = False) -> Level:
+                randf: int, target_stride: int, align_batch: bool, want_indices: bool = False,
+                tokens: Optional[int] = None) -> Level:
     """One level of local merging on the joined chunk x0 (B, L, C); ``cur`` maps the current sequence to
-    rows of x0 (None = identity)."""
+    rows of x0 (None = identity).  ``tokens`` = tokens per frame of the joined chunk when its rows are (frame, position)
+    ordered: the matcher is then seeded with, for every src token, the token at the same position of the first dst frame
+    (dst index = position; never changes the result)."""
     B = x0.shape[0]
     tnum = (N_in - unm_pre) // F                       # merge.py:43
     ts = min(target_stride, F)                         # merge.py:56
     parts = _lib.partition_local(cur, B, N_in, unm_pre, tnum, ts, randf, x0.device)
-    return _run_level(x0, None, parts, ratio, align_batch, want_indices)
+    seed = (tokens, x0.shape[1], None, None) if (tokens and tokens == tnum) else None
+    return _run_level(x0, None, parts, ratio, align_batch, want_indices, seed)
 
 
 def global_level(x0: torch.Tensor, anchors: torch.Tensor, cur_local: Optional[torch.Tensor], Ml: int,
-                 local_is_src: bool, ratio: float, align_batch: bool, want_indices: bool = False) -> Level:
-    """Global merging of the chunk's local tokens against the block's anchor tokens (patch.py:59-82)."""
+                 local_is_src: bool, ratio: float, align_batch: bool, want_indices: bool = False,
+                 tokens: Optional[int] = None, anchor_positions: Optional[torch.Tensor] = None) -> Level:
+    """Global merging of the chunk's local tokens against the block's anchor tokens (patch.py:59-82).  ``tokens`` (tokens
+    per frame) / ``anchor_positions`` (B, Mg) int32 seed the matcher with the dst token at every src token's position."""
     B, L, _ = x0.shape
     if cur_local is None:
         cur_local = torch.arange(Ml, dtype=torch.int32, device=x0.device).expand(B, Ml).contiguous()
-    parts = _lib.partition_global(cur_local, L, anchors.shape[1], local_is_src)
-    return _run_level(x0, anchors, parts, ratio, align_batch, want_indices)
+    seed = table = None
+    if tokens and _lib.SEED_MATCHER and (anchor_positions is not None or not local_is_src):
+        table = torch.empty((B, tokens), dtype=torch.int32, device=x0.device)
+        seed = (tokens, L, anchor_positions, table)
+    parts = _lib.partition_global(cur_local, L, anchors.shape[1], local_is_src, table, tokens or 0, anchor_positions)
+    return _run_level(x0, anchors, parts, ratio, align_batch, want_indices, seed)
 
 
 def draw_randf(generator: torch.Generator, ts: int) -> int:
@@ -149,7 +159,8 @@ def bipartite_soft_matching_randframe(metric: torch.Tensor, F: int, ratio: float
         return do_nothing, do_nothing, {"unm_num": tnum}          # merge.py:45-46
     with torch.no_grad():
         randf = draw_randf(generator, min(target_stride, F))
-        level = local_level(metric, None, N, F, ratio, unm_pre, randf, target_stride, align_batch, True)
+        level = local_level(metric, None, N, F, ratio, unm_pre, randf, target_stride, align_batch, True,
+                            tokens=tnum if unm_pre == 0 else None)
     merge, unmerge = _make_closures(level, N, None, merge_mode)
     ret_dict = {"unm_num": level.unm_num, "a_idx": level.a_pos, "b_idx": level.b_pos,
                 "unm_idx": level.unm_idx, "src_idx": level.src_idx, "dst_idx": level.dst_idx,

@@ -150,7 +150,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
             else:
                 randf = merge.draw_randf(generator, min(args["target_stride"], curF))
                 lv = merge.local_level(xj, cur, n_cur, curF, ratio, unm, randf, args["target_stride"],
-                                       args["align_batch"], want_indices)
+                                       args["align_batch"], want_indices, tokens=tsize)
                 plan.levels.append(lv)
                 unm += lv.unm_num
                 cur = lv.new_cur
@@ -159,12 +159,17 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
             curF = (n_cur - unm) // tsize                                          # patch.py:54
         Ml = n_cur
 
-        anchors_out = None
+        anchors_out = anchors_pos = None
         if args["merge_global"]:                                                   # patch.py:59-82
             if exchange is not None:
                 gt = exchange.anchors_for(xkey, lambda: xj if cur is None else _lib.gather_rows(xj, None, cur), xj, cur)
             else:
                 gt = getattr(module, "global_tokens", None)
+            # token positions of the anchors (the matcher's seeds) ride on the tensor THIS function stored (an attribute of the
+            # tensor object: they live and die with it); anchors that came from anywhere else (the user, an exchange) have none
+            gt_pos = getattr(gt, "_vtm_pos", None) if gt is not None else None
+            if gt_pos is not None and (tuple(gt_pos.shape) != tuple(gt.shape[:2]) or gt_pos.device != xj.device):
+                gt_pos = None
             if gt is not None:
                 gt = gt.to(xj).contiguous()                                        # patch.py:65,70
                 coin = _draw_coin(generator)
@@ -174,14 +179,16 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                     # merge.py:364-365 returns a 2-tuple which patch.py:73 unpacks into 3 names
                     raise ValueError("not enough values to unpack (expected 3, got 2)")
                 gl = merge.global_level(xj, gt, cur, Ml, local_is_src, res_ratio, args["align_batch"],
-                                        want_indices)
+                                        want_indices, tokens=tsize, anchor_positions=gt_pos)
                 plan.global_level, plan.local_chunk = gl, (0 if local_is_src else 1)
                 plan.anchors_in = gt
                 off = 0 if local_is_src else gt.shape[1]                           # merge.py:459
                 loc = _lib.compose(None, gl.inv, Ml, off)      # local position -> merged position
                 # patch.py:80: new anchors = u(merged) = the local tokens with every merged local src row
                 # replaced by its matched global row -> one gather from [chunk | old anchors]
-                anchors_out = _lib.gather_rows(xj, gt, _lib.compose(loc, gl.new_cur, Ml))
+                amap = _lib.compose(loc, gl.new_cur, Ml)
+                anchors_out = _lib.gather_rows(xj, gt, amap)
+                anchors_pos = _lib.anchor_pos(amap, B, Ml, L, tsize, gt_pos, xj.device) if _lib.SEED_MATCHER else None
                 if local_is_src and COMPACT_QUERIES and gl.Nd <= 131072:      # (vtm_compact_queries' bitmap lives in LDS)
                     qc, tmap, plan.q_count = _lib.compact_queries(loc, gl.Ns - gl.r, gl.Nd)
                     plan.q_rows = qc
@@ -198,12 +205,16 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
         if args["merge_global"]:
             if anchors_out is not None:
                 module.global_tokens = anchors_out
+                if anchors_pos is not None:
+                    anchors_out._vtm_pos = anchors_pos
             elif plan.global_level is None:
                 # patch.py:82: first chunk of a step stores its local tokens (device-resident, shared
                 # with `merged`, which nothing mutates)
                 if merged is None:
                     merged = plan.merged
                 module.global_tokens = merged[:, :Ml] if merged.shape[1] != Ml else merged
+                if _lib.SEED_MATCHER:      # (cur None: a single-frame chunk, the local tokens are the chunk's rows themselves)
+                    module.global_tokens._vtm_pos = _lib.anchor_pos(cur, B, Ml, L, tsize, None, xj.device)
             if exchange is not None:
                 exchange.publish(xkey, module.global_tokens)
 
