@@ -258,14 +258,25 @@ class KernelTimer:
         # attention_kv(q, k, vt, heads, Mq, Mk, scale): 4 * B * Mq * Mk * C executed flops
         # (with a device-side query bound the executed rows are the per-sample counts, rounded up to whole query blocks
         # of 256 (d <= 48) / 512 (d <= 96) / 128 queries: read back AFTER the timed region)
-        def kv_flops(q, k, vt, heads, Mq, Mk, scale, use_workspace=True, q_count=None):
+        def kv_flops(q, k, vt, heads, Mq, Mk, scale, use_workspace=True, q_count=None, k_fold=None):
             self.ref_flops += 4.0 * q.shape[0] * (Mk * Mk if Mq > 256 and Mk > Mq else Mq * Mk) * q.shape[2]
-            if q_count is None:
+            if q_count is None and k_fold is None:
                 return 4.0 * q.shape[0] * Mq * Mk * q.shape[2]
             d = q.shape[2] // heads
             qb = 256 if d <= 48 else 512 if d <= 96 else 128
-            keep = q_count.clone()          # the workspace-free tensor may be recycled by the allocator
-            return lambda: 4.0 * float(((keep.cpu().long() + qb - 1) // qb * qb).clamp(max=Mq).sum()) * Mk * q.shape[2]
+            # (clones: the workspace-free tensors may be recycled by the allocator before the read-back)
+            keep = q_count.clone() if q_count is not None else None
+            kkeep = k_fold[0].clone() if k_fold is not None else None     # folded keys: a device-side KEY count too
+
+            def executed():
+                B = q.shape[0]
+                qn = ((keep.cpu().long() + qb - 1) // qb * qb).clamp(max=Mq) if keep is not None else torch.full((B,), Mq)
+                kn = ((kkeep.cpu().long() + 63) // 64 * 64).clamp(max=Mk) if kkeep is not None else torch.full((B,), Mk)
+                if kkeep is not None:
+                    self.folded_keys.append((int(kkeep.cpu().long().sum()), B * Mk))
+                return 4.0 * float((qn * kn).sum()) * q.shape[2]
+            return executed
+        self.folded_keys = []
         self._wrap("attention_kv", "attention", kv_flops)
         # match_filtered(x0, x1, a_rows, b_rows, align): 2 * B * Ns * Nd * C algorithmic flops
         self._wrap("match_filtered", "matching",
@@ -303,7 +314,7 @@ class KernelTimer:
         # everything else the path launches (index algebra, sort, panel writers, query compaction): time only, so that the
         # components of the line add up to the step
         for name in ("sort_desc", "partition_local", "partition_global", "plan_apply", "compose", "decode_best",
-                     "compact_queries", "to_panels", "gather_panels", "geglu", "normalize_gather"):
+                     "compact_queries", "fold_keys", "anchor_pos", "to_panels", "gather_panels", "geglu", "normalize_gather"):
             if hasattr(self.lib_mod, name):
                 self.records[name] = []
                 self._wrap(name, name, lambda *a, **k: 0.0)
@@ -745,6 +756,11 @@ def main():
                          # live / distinct Mq x M): the same time expressed in those flops
                          "reference_equivalent_tflops": round(mt.ref_flops / (ams * 1e-3) / 1e12, 1) if ams > 0 else 0.0,
                          "event_passes": timed_passes,
+                         # duplicate keys folded away (vtm_fold_keys): keys the event-timed launches really scanned / keys of
+                         # the merged sequences (launches whose anchors carried content ids only)
+                         "folded_launches": len(mt.folded_keys),
+                         "folded_key_fraction": round(1.0 - sum(a for a, _ in mt.folded_keys) / sum(t for _, t in mt.folded_keys), 4)
+                         if mt.folded_keys else 0.0,
                          "sustained_sclk_mhz": sclk,
                          "frac_at_sustained_clock": round(att_tf / roof_at_clock, 4) if roof_at_clock else None,
                          "note": box_note},

@@ -274,6 +274,29 @@ int vtm_attention_kv_bounded(const void *q, int64_t ldq, const void *k, int64_t 
  * workspace than this the launch falls back to the plain plan of vtm_attention_ws_bytes */
 size_t vtm_attention_kv_bounded_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64_t Mk, int64_t d);
 
+/* vtm_fold_keys / vtm_attention_kv_folded -- the anchors' exact duplicates as ONE key each.  patch.py:80 stores
+ * u(merged_tokens) as the next chunk's global tokens: every local token that merged into an anchor row carries that
+ * row's content, so the anchors hold groups of identical rows, and so does the merged sequence they join
+ * (patch.py:63-71).  Identical key / value rows weigh in softmax(q k^T) v exactly like one key whose (base-2) score carries
+ * + log2(multiplicity).  vtm_fold_keys: cur (B, M) pool row of every merged position (rows >= L are anchor rows cur - L of
+ * Ma), cid (B, Ma) a content id in [0, n_ids) per anchor row (equal ids <=> identical rows; vtm_compact_queries' tmap of
+ * the block that produced the anchors).  Outputs: key_sel (B, M) the surviving merged positions in ascending order (the
+ * first copy of every group; entries past the count are 0), k_bias (B, ldkb) per surviving key log2(copies present) as
+ * a (hi, lo) pair of the keys' 16-bit type (dtype VTM_F16 / VTM_BF16), k_count (B) the number of surviving keys.
+ * vtm_attention_kv_folded is vtm_attention_kv_bounded (q_count may be NULL) over such a key list: k / vt hold the
+ * projections of the key_sel rows, only the first k_count[b] (<= Mk, a device value) are keys, and the bias pair rides
+ * in the spare k-slots of the contraction -- head dims with d % 16 == 8 only (SD's 40).  Same block output as the
+ * unfolded call up to the rounding of log2(m) (2^-21 relative). */
+size_t vtm_fold_keys_ws_bytes(int64_t B, int64_t M, int64_t n_ids);
+int vtm_fold_keys(const int32_t *cur, int64_t B, int64_t M, int64_t L, const int32_t *cid, int64_t Ma, int64_t n_ids,
+                  int dtype, void *ws, size_t ws_bytes, int32_t *key_sel, uint32_t *k_bias, int64_t ldkb,
+                  int32_t *k_count, vtm_stream_t stream);
+int vtm_attention_kv_folded(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+                            void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
+                            int64_t Mk, int64_t Mkp, int64_t d, float scale, const int32_t *q_count,
+                            const int32_t *k_count, const uint32_t *k_bias, int64_t ldkb, void *ws, size_t ws_bytes,
+                            vtm_stream_t stream);
+
 /* vtm_compact_queries -- which attention outputs a global level with the local chunk on the src side actually needs
  * (bipartite_soft_matching_2s's unmerge, merge.py:439-460, returns for every merged local token the output row of the
  * anchor token it merged into: `src = gather(dst, dst_idx)`; several local tokens may share one).  loc (B, Ml): merged

@@ -941,6 +941,9 @@ E2E_CASES = {
     "pnp_b3_aligned_shared": (4, 16, 320, 8, (0.0, 1.0), "auto", torch.float16, 3, True, (0.5, 0.5), 1e-3),  # cfg-3
     "single_frame_chunks": (1, 16, 320, 8, (0.0, 1.0), "auto", torch.float16, 2, False, (0.5, 0.5), 1e-3),   # no local level
     "bf16": (8, 16, 320, 8, (1.0, 0.0), "auto", torch.bfloat16, 2, False, (0.5, 0.5), 8e-3),                 # bf16: 8 mantissa bits
+    # duplicate-key folding: anchors with copies on the dst side (src, src), then on the src side (dst)
+    "c320_d40_fold": (8, 16, 320, 8, (0.0, 0.0, 1.0), "auto", torch.float16, 2, False, (0.5, 0.5), 1e-3),
+    "bf16_fold": (4, 16, 320, 8, (0.0, 0.0, 1.0), "auto", torch.bfloat16, 2, False, (0.5, 0.5), 8e-3),
 }
 
 
@@ -999,7 +1002,8 @@ def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, case, monkeypatch):
     state = {"global_tokens": None}
     args = dict(unet._tome_info["args"])
     seen = set()
-    for ck in range(3):
+    folded = 0
+    for ck in range(1 + len(coins)):
         if ck > 0:
             unet._tome_info["args"]["global_rand"] = args["global_rand"] = coins[ck - 1]
         hidden = sites.synthetic_hidden(site, B, F, latent, dtype, DEV, seed=50 + ck, clip_seed=7)
@@ -1023,7 +1027,23 @@ def test_default_fp16_block_vs_oracle_end_to_end(L, oracle, case, monkeypatch):
         ref = u_o(attn_o) + f32(hidden)
         err = np.abs(f32(out) - ref).max()
         assert err < tol * max(1.0, np.abs(ref).max()), (ck, err)
+        if plan.fold_args is not None and proj == "auto" and C == 320 and heads == 8 and not pnp:
+            # the block behind a local-is-src block: its anchors carried content ids, attn1 ran over the folded key list
+            assert plan._key_fold is not None
+            key_sel, k_bias, k_count = plan._key_fold
+            cur = plan.gather_map.cpu().numpy()
+            kc = k_count.cpu().numpy()
+            for b in range(B):      # every dropped key is an exact copy of a kept one (same pool row content)
+                pool = np.concatenate([f32(plan.x_joined[b]), f32(plan.anchors_in[b])])
+                rows_all = pool[cur[b]]
+                kept = key_sel[b, :kc[b]].cpu().numpy()
+                assert np.all(np.diff(kept) > 0)
+                uniq = {r.tobytes() for r in rows_all[kept]}
+                assert all(r.tobytes() in uniq for r in rows_all)
+            folded += int((kc < plan.M).any())
     assert seen == {0, 1}
+    if case.endswith("_fold"):
+        assert folded >= 2          # copies existed on both kinds of pass (otherwise the case tests nothing)
     vidtome_amd.remove_patch(unet)
 
 
@@ -1045,6 +1065,159 @@ def test_attention_core_vs_oracle(L, oracle, shape, dtype):
         ref = oracle.attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), h, share_groups=share)
         tol = 1e-3 if dtype == torch.float16 else 8e-3
         assert np.abs(o - ref).max() < tol * max(1.0, np.abs(ref).max())
+
+
+def _fold_reference(cur, L, cid):
+    """numpy restatement of vtm_fold_keys: first copy of every content id survives, with the number of copies present."""
+    B, M = cur.shape
+    sel, cnt = [], []
+    for b in range(B):
+        first, n = {}, {}
+        for m in range(M):
+            if cur[b, m] >= L:
+                c = int(cid[b, cur[b, m] - L])
+                first.setdefault(c, m)
+                n[c] = n.get(c, 0) + 1
+        keep = [m for m in range(M) if cur[b, m] < L or first[int(cid[b, cur[b, m] - L])] == m]
+        sel.append(keep)
+        cnt.append([1 if cur[b, m] < L else n[int(cid[b, cur[b, m] - L])] for m in keep])
+    return sel, cnt
+
+
+@pytest.mark.parametrize("shape", [(2, 500, 300, 260), (1, 70, 10, 64), (3, 4099, 1000, 3000)])
+def test_fold_keys_vs_numpy(L, shape):
+    """vtm_fold_keys (the anchors' exact copies -> one key each): surviving positions, counts and the log2 bias pair."""
+    B, M, Lrows, Ma = shape
+    rng = np.random.default_rng(M)
+    n_ids = Ma
+    cid = rng.integers(0, max(2, Ma // 3), size=(B, Ma)).astype(np.int32)
+    cur = np.stack([rng.permutation(Lrows + Ma)[:M] for _ in range(B)]).astype(np.int32)
+    for dtype in (torch.float16, torch.bfloat16):
+        key_sel, k_bias, k_count = L.fold_keys(_t(cur), Lrows, _t(cid), n_ids, dtype)
+        sel, cnt = _fold_reference(cur, Lrows, cid)
+        kb = k_bias.cpu().numpy().view(np.uint32)
+        for b in range(B):
+            n = int(k_count[b])
+            assert n == len(sel[b])
+            assert np.array_equal(key_sel[b, :n].cpu().numpy(), np.array(sel[b], dtype=np.int32))
+            assert not key_sel[b, n:].any()
+            words = torch.from_numpy(kb[b, :n].astype(np.int64))
+            hi = (words & 0xffff).to(torch.int16).view(dtype).float().numpy()
+            lo = (words >> 16).to(torch.int16).view(dtype).float().numpy()
+            want = np.log2(np.array(cnt[b], dtype=np.float64))
+            assert np.abs(hi + lo - want).max() < (2e-6 if dtype == torch.float16 else 4e-5)
+            assert np.all((hi + lo)[np.array(cnt[b]) == 1] == 0.0)
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.float16, 40), (torch.bfloat16, 40), (torch.float16, 8)])
+def test_attention_folded_keys_equal_the_duplicated_ones(L, oracle, dtype, d):
+    """vtm_attention_kv_folded: m identical keys weigh like one key with + log2(m) on its score -- the folded launch (device-side
+    key count, bias pair in the spare k-slots) against the oracle's attention over the sequence WITH the copies, and against
+    the unfolded kernel on the same sequence; with and without a device-side query count, ragged last tile, split tails."""
+    B, h, Mq, Mu = 2, 8, 333, 1500
+    C = h * d
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, Mq, C, generator=g).to(dtype)
+    ku = torch.randn(B, Mu, C, generator=g).to(dtype)
+    vu = torch.randn(B, Mu, C, generator=g).to(dtype)
+    rng = np.random.default_rng(5)
+    mult = rng.choice([1, 1, 1, 2, 3, 5, 17], size=(B, Mu))
+    mult[1, Mu - 200:] = 0                        # sample 1 has fewer distinct keys than sample 0: per-sample device counts
+    Mk = int(mult.sum(1).max())
+    Mkp, Mup, Mqp = (Mk + 7) // 8 * 8, (Mu + 7) // 8 * 8, (Mq + 7) // 8 * 8
+    kd = torch.zeros(B, Mkp, C, dtype=dtype)
+    vd = torch.zeros(B, Mkp, C, dtype=dtype)
+    counts_full = []
+    for b in range(B):
+        idx = np.repeat(np.arange(Mu), mult[b])
+        idx = idx[rng.permutation(len(idx))]
+        counts_full.append(len(idx))
+        kd[b, :len(idx)] = ku[b, idx]
+        vd[b, :len(idx)] = vu[b, idx]
+    pad = lambda t, n: torch.nn.functional.pad(t, (0, 0, 0, n - t.shape[1]))
+    qd = pad(q, Mqp).to(DEV)
+    scale = d ** -0.5
+    # folded operands: the distinct keys (those with mult > 0) in front, bias words, counts
+    kf = torch.zeros(B, Mup, C, dtype=dtype)
+    vf = torch.zeros(B, Mup, C, dtype=dtype)
+    bias = torch.zeros(B, Mup, dtype=torch.int32)
+    kc = []
+    for b in range(B):
+        live = np.nonzero(mult[b])[0]
+        kc.append(len(live))
+        kf[b, :len(live)] = ku[b, live]
+        vf[b, :len(live)] = vu[b, live]
+        kf[b, len(live):] = 7.0                   # rows past the count: finite garbage nobody may read as a key
+        lg = torch.log2(torch.from_numpy(mult[b, live].astype(np.float32)))
+        hi = lg.to(dtype)
+        lo = (lg - hi.float()).to(dtype)
+        bias[b, :len(live)] = (hi.view(torch.int16).int() & 0xffff) | (lo.view(torch.int16).int() << 16)
+    k_count = torch.tensor(kc, dtype=torch.int32, device=DEV)
+    tol = (1e-3 if dtype == torch.float16 else 8e-3)
+    for b in range(B):      # the oracle on each sample's own duplicated sequence
+        n = counts_full[b]
+        ref = oracle.attention_qkv(q[b:b + 1].float().numpy(), kd[b:b + 1, :n].float().numpy(), vd[b:b + 1, :n].float().numpy(), h)
+        of = L.attention_kv(qd, kf.to(DEV), vf.to(DEV).transpose(1, 2).contiguous(), h, Mq, Mu, scale,
+                            k_fold=(k_count, bias.to(DEV)))[b, :Mq].float().cpu().numpy()
+        assert np.abs(of - ref[0]).max() < tol * max(1.0, np.abs(ref).max()), b
+        ou = L.attention_kv(qd[b:b + 1], kd[b:b + 1].to(DEV), vd[b:b + 1].to(DEV).transpose(1, 2).contiguous(), h, Mq, n,
+                            scale)[0, :Mq].float().cpu().numpy()
+        assert np.abs(of - ou).max() < tol * max(1.0, np.abs(ref).max()), b
+    # + a device-side query count (the split-all launch plan reads the device-side key count in every split)
+    q_count = torch.tensor([Mq, Mq - 77], dtype=torch.int32, device=DEV)
+    oq = L.attention_kv(qd, kf.to(DEV), vf.to(DEV).transpose(1, 2).contiguous(), h, Mq, Mu, scale, q_count=q_count,
+                        k_fold=(k_count, bias.to(DEV)))
+    of = L.attention_kv(qd, kf.to(DEV), vf.to(DEV).transpose(1, 2).contiguous(), h, Mq, Mu, scale, k_fold=(k_count, bias.to(DEV)))
+    for b in range(B):
+        n = int(q_count[b])
+        assert torch.equal(oq[b, :n], of[b, :n])
+
+
+def test_attention_folded_keys_under_the_split_plans(L):
+    """The launch plans that split work items along the key axis (every item in two for query-bounded launches, the last
+    round otherwise) cut the DEVICE-side key count, not the host bound: a folded launch big enough to take them against
+    the unfolded kernel over the sequence with the copies (kernel against kernel; the oracle anchors the small case)."""
+    B, h, d, Mq, Mu = 2, 8, 40, 16640, 4800
+    C = h * d
+    dtype = torch.float16
+    g = torch.Generator(device=DEV).manual_seed(3)
+    q = torch.randn(B, Mq, C, generator=g, device=DEV).to(dtype)
+    ku = torch.randn(B, Mu, C, generator=g, device=DEV).to(dtype)
+    vu = torch.randn(B, Mu, C, generator=g, device=DEV).to(dtype)
+    rng = np.random.default_rng(9)
+    mult = rng.choice([1, 1, 2, 4], size=(B, Mu))
+    mult[1, Mu - 333:] = 0
+    Mk = int(mult.sum(1).max())
+    Mkp = (Mk + 7) // 8 * 8
+    scale = d ** -0.5
+    bias = torch.zeros(B, Mu, dtype=torch.int32)
+    kf, vf = torch.zeros_like(ku), torch.zeros_like(vu)
+    kc, outs_u = [], []
+    for b in range(B):
+        live = np.nonzero(mult[b])[0]
+        kc.append(len(live))
+        kf[b, :len(live)] = ku[b, live]
+        vf[b, :len(live)] = vu[b, live]
+        lg = torch.log2(torch.from_numpy(mult[b, live].astype(np.float32)))
+        hi = lg.to(dtype)
+        lo = (lg - hi.float()).to(dtype)
+        bias[b, :len(live)] = (hi.view(torch.int16).int() & 0xffff) | (lo.view(torch.int16).int() << 16)
+        idx = torch.from_numpy(np.repeat(np.arange(Mu), mult[b])).to(DEV)
+        n = len(idx)
+        kd = torch.zeros(1, Mkp, C, dtype=dtype, device=DEV)
+        vd = torch.zeros(1, Mkp, C, dtype=dtype, device=DEV)
+        kd[0, :n], vd[0, :n] = ku[b, idx], vu[b, idx]
+        outs_u.append(L.attention_kv(q[b:b + 1], kd, vd.transpose(1, 2).contiguous(), h, Mq, n, scale)[0].float())
+    k_count = torch.tensor(kc, dtype=torch.int32, device=DEV)
+    vft = vf.transpose(1, 2).contiguous()
+    q_count = torch.tensor([Mq, Mq - 1000], dtype=torch.int32, device=DEV)
+    o_plain = L.attention_kv(q, kf, vft, h, Mq, Mu, scale, k_fold=(k_count, bias.to(DEV))).float()
+    o_bound = L.attention_kv(q, kf, vft, h, Mq, Mu, scale, q_count=q_count, k_fold=(k_count, bias.to(DEV))).float()
+    for b in range(B):
+        n = int(q_count[b])
+        sc = max(1.0, float(outs_u[b].abs().max()))
+        assert float((o_plain[b] - outs_u[b]).abs().max()) < 1e-3 * sc
+        assert float((o_bound[b, :n] - outs_u[b][:n]).abs().max()) < 1e-3 * sc
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])

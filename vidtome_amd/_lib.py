@@ -61,6 +61,10 @@ _SIGNATURES = {
     "vtm_attention_kv_bounded": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _f32, _vp, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_attention_kv_bounded_ws_bytes": ([_i64, _i64, _i64, _i64, _i64], ctypes.c_size_t),
+    "vtm_fold_keys_ws_bytes": ([_i64, _i64, _i64], ctypes.c_size_t),
+    "vtm_fold_keys": ([_vp, _i64, _i64, _i64, _vp, _i64, _i64, _int, _vp, ctypes.c_size_t, _vp, _vp, _i64, _vp, _vp], _int),
+    "vtm_attention_kv_folded": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                 _f32, _vp, _vp, _vp, _i64, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_compact_queries_ws_bytes": ([_i64, _i64], ctypes.c_size_t),
     "vtm_compact_queries": ([_vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp], _int),
     "vtm_panel_rows": ([_i64], _i64),
@@ -394,6 +398,9 @@ SEED_MATCHER = os.environ.get("VIDTOME_SEED", "1") != "0"
 # A/B switch (profiles/r04_attention_split_all.txt): split every work item of a query-bounded attention launch in two
 SPLIT_ALL_BOUNDED = os.environ.get("VIDTOME_ATT_SPLIT_ALL", "1") != "0"
 
+# A/B switch: the anchors' exact duplicates enter attn1 as one key each (fold_keys / vtm_attention_kv_folded; d = 40 heads)
+FOLD_KEYS = os.environ.get("VIDTOME_FOLD_KEYS", "1") != "0"
+
 
 def _attention_ws(B: int, heads: int, Mq: int, Mk: int, d: int, device):
     """Workspace for the split last round of an attention launch (None when the shape needs none)."""
@@ -460,10 +467,13 @@ def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[to
 
 @_on_device
 def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, Mq: int, Mk: int, scale: float,
-                 use_workspace: bool = True, q_count: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 use_workspace: bool = True, q_count: Optional[torch.Tensor] = None,
+                 k_fold: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
     """Cross-attention core (patch.py:178-183): q (B, Mqp, C), k (B, Mkp, C) views contiguous along the last axis,
     vt (B, C, ldvt >= Mk) = v transposed.  Returns (B, Mqp, C).  ``q_count`` (B,) int32 on the device: only the first
-    q_count[b] query rows of sample b are meaningful (compact_queries); the other rows of the result are undefined."""
+    q_count[b] query rows of sample b are meaningful (compact_queries); the other rows of the result are undefined.
+    ``k_fold`` = (k_count (B,) int32, k_bias (B, >= Mk) uint32 pairs) from fold_keys: k / vt hold a duplicate-free key
+    list, only the first k_count[b] entries are keys, each standing for 2^bias identical ones (head dims 8 and 40)."""
     B, Mqp, C = q.shape
     Mkp = k.shape[1]
     d = C // heads
@@ -478,9 +488,19 @@ def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
         nb2 = int(lib().vtm_attention_kv_bounded_ws_bytes(B, heads, Mq, Mk, d))
         if nb2 > 0:
             ws, nb = _workspace("attention", nb2, q.device), nb2
+    if q_count is not None and (q_count.dtype != torch.int32 or q_count.numel() != B or not q_count.is_cuda):
+        raise RuntimeError("attention_kv: q_count must be a (B,) int32 device tensor")
+    if k_fold is not None:
+        k_count, k_bias = k_fold
+        if k_count.dtype != torch.int32 or k_count.numel() != B or k_bias.dtype != torch.int32 or k_bias.dim() != 2 \
+                or k_bias.shape[0] != B or k_bias.shape[1] < Mk or not k_bias.is_contiguous():
+            raise RuntimeError("attention_kv: k_fold must be ((B,) int32 counts, (B, >= Mk) int32 bias words)")
+        _check(lib().vtm_attention_kv_folded(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(), vt.stride(1),
+                                             out.data_ptr(), C, dtype_code(q), B, heads, Mq, Mqp, Mk, Mkp, d, float(scale),
+                                             _ptr(q_count), _ptr(k_count), _ptr(k_bias), k_bias.shape[1], _ptr(ws), nb,
+                                             _stream()), "vtm_attention_kv_folded")
+        return out
     if q_count is not None:
-        if q_count.dtype != torch.int32 or q_count.numel() != B or not q_count.is_cuda:
-            raise RuntimeError("attention_kv: q_count must be a (B,) int32 device tensor")
         _check(lib().vtm_attention_kv_bounded(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(),
                                               vt.stride(1), out.data_ptr(), C, dtype_code(q), B, heads, Mq, Mqp, Mk, Mkp,
                                               d, float(scale), _ptr(q_count), _ptr(ws), nb, _stream()),
@@ -505,6 +525,26 @@ def compact_queries(loc: torch.Tensor, U: int, Nd: int) -> Tuple[torch.Tensor, t
     _check(lib().vtm_compact_queries(_ptr(loc), B, Ml, U, Nd, _ptr(ws), nb, _ptr(qc), _ptr(tmap), _ptr(count), _stream()),
            "vtm_compact_queries")
     return qc, tmap, count
+
+
+@_on_device
+def fold_keys(cur: torch.Tensor, L: int, cid: torch.Tensor, n_ids: int, dtype: torch.dtype
+              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """cur (B, M) pool row of every merged position (rows >= L: anchor row cur - L), cid (B, Ma) content id of every anchor
+    row (< n_ids; equal ids = identical rows) -> (key_sel (B, M) surviving positions, k_bias (B, Mp) int32 words holding
+    log2(copies) as a 16-bit (hi, lo) pair of ``dtype``, k_count (B,)); see include/vidtome_hip.h."""
+    _req(cur, "cur")
+    _req(cid, "cid")
+    B, M = cur.shape
+    Mp = (M + 7) // 8 * 8
+    i32 = dict(dtype=torch.int32, device=cur.device)
+    key_sel, k_bias, k_count = torch.empty((B, M), **i32), torch.empty((B, Mp), **i32), torch.empty((B,), **i32)
+    code = {torch.float16: 1, torch.bfloat16: 2}[dtype]
+    nb = int(lib().vtm_fold_keys_ws_bytes(B, M, n_ids))
+    ws = _workspace("fold", nb, cur.device)
+    _check(lib().vtm_fold_keys(_ptr(cur), B, M, L, _ptr(cid), cid.shape[1], n_ids, code, _ptr(ws), nb, _ptr(key_sel),
+                               _ptr(k_bias), Mp, _ptr(k_count), _stream()), "vtm_fold_keys")
+    return key_sel, k_bias, k_count
 
 
 @_on_device

@@ -242,13 +242,13 @@ __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
     }
 }
 
-template <typename T, int D>
+template <typename T, int D, bool FOLD>
 __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1)) void attention_kernel(
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
-    int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t nwhole,
+    int64_t M, int64_t Mp, int64_t Mk_arg, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t nwhole,
     int nsplit_tail, float *__restrict__ partial_base, int xcd_groups, const int32_t *__restrict__ q_count,
-    int64_t split_major_items) {
+    int64_t split_major_items, const int32_t *__restrict__ k_count, const uint32_t *__restrict__ k_bias, int64_t ldkb) {
     // M / Mp: queries per sample and their row stride; Mk / Mkp: keys per sample and the row stride of k
     // (self-attention passes the same values; cross-attention, patch.py:178-183, has Mk = 77).
     // Work decomposition: work item = (query block, head, sample), query blocks fastest.  Workgroups [0, nwhole) take
@@ -273,6 +273,10 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     // rounding of q, the same size as the rounding the projection GEMM already applied).
     constexpr bool BIAS = (D % 16) != 0;
     constexpr int BIAS_HI = (D % 16) / 8, BIAS_E = D % 8;   // lane half / fragment element holding channel D
+    // FOLD (vtm_attention_kv_folded): the key list is duplicate-free, key j stands for 2^bias_j identical keys of the merged
+    // sequence (vtm_fold_keys); the bias rides in two more spare k-slots (channels D + 2, D + 3 of the K row = hi + lo of
+    // log2(multiplicity), against ones in the query), and the number of keys is a DEVICE value (k_count[b] <= Mk_arg).
+    static_assert(!FOLD || (BIAS && D % 8 == 0 && D % 16 == 8), "key folding needs the spare k-slots of a d % 16 == 8 head");
     constexpr int K_STRIDE = DK * 16 + 8;  // elements; (DK*8+4) words = 4 x odd -> conflict-free b128
     constexpr int DCH = D / 8;             // 16-byte chunks per K row
     constexpr int K_CHUNKS = KV * DCH;     // per tile
@@ -302,6 +306,11 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const int64_t bq = b % src_batch;  // PnP injection: q/k of the source sample (pnp_utils.py:57-67)
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
     const int64_t C = H * D;
+    int64_t Mk = Mk_arg;
+    if constexpr (FOLD) {
+        const int64_t kc = k_count[b];
+        Mk = kc < Mk_arg ? (kc > 0 ? kc : 1) : Mk_arg;
+    }
     // device-side query bound (compacted live queries, vtm_compact_queries): the launch is sized for the host-known
     // upper bound M; a query block that starts at or beyond its sample's count has nothing anybody reads
     if (q_count != nullptr && (lin % nqb) * QB >= (int64_t)q_count[b]) return;
@@ -336,6 +345,12 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
                 for (int e = 0; e < 8; ++e) qf[ks][e] = (elem)((float)qf[ks][e] * scale_log2e);
             }
         }
+        if constexpr (FOLD) {   // channels D + 2, D + 3 (lane half BIAS_HI, elements BIAS_E + 2, + 3) meet the key's bias pair
+            if (hi == BIAS_HI) {
+                qf[DK - 1][BIAS_E + 2] = (elem)1.0f;
+                qf[DK - 1][BIAS_E + 3] = (elem)1.0f;
+            }
+        }
     }
 
     // hoisted staging addresses: chunk c = tid + 256 i ; K: (row c / DCH, 16-byte piece c % DCH);
@@ -368,6 +383,10 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(vt + (b * C + h * D) * ldvt), 0, 0x7fffffff, 0x00020000);
     const uint32_t kstep = (uint32_t)(KV * ldk) * 2u, vstep = (uint32_t)KV * 2u;   // bytes per tile
     uint32_t so_k = 0, so_v = 0;                                                    // scalar tile offsets (bytes)
+    // FOLD: the first wave also stages the tile's 64 bias words (one per key) into the K rows
+    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(FOLD ? k_bias + b * ldkb : nullptr), 0, 0x7fffffff, 0x00020000);
+    uint32_t so_b = 0, rbias = 0;
+    [[maybe_unused]] const uint32_t bgo = (uint32_t)(tid & (KV - 1)) * 4u;
     auto fetch = [](const auto &rsrc, uint32_t voff_, uint32_t soff_) {
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_, soff_, 0));
     };
@@ -380,6 +399,10 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
         for (int i = 0; i < K_PER_T; ++i) rk[i] = fetch(rsrc_k, kgo[i], so_k);
 #pragma unroll
         for (int i = 0; i < V_PER_T; ++i) rv[i] = fetch(rsrc_v, vgo[i], so_v);
+        if constexpr (FOLD) {   // (every wave fetches the 64 words -- no load behind a branch, see above -- the first one stores them)
+            rbias = __builtin_amdgcn_raw_buffer_load_b32(rsrc_b, bgo, so_b, 0);
+            so_b += (uint32_t)KV * 4u;
+        }
         so_k += kstep;
         so_v += vstep;
     };
@@ -400,9 +423,16 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
             }
             rv[i] = v;
         }
+        if constexpr (FOLD) {
+            rbias = 0u;
+            if (key0 + (tid & (KV - 1)) < Mk) rbias = __builtin_amdgcn_raw_buffer_load_b32(rsrc_b, bgo, so_b, 0);
+        }
     };
     auto write_lds = [&](int buf) {
         elem *dk = sK + buf * SK_TILE, *dv = sV + buf * SV_TILE;
+        if constexpr (FOLD) {
+            if (wave == 0) *reinterpret_cast<uint32_t *>(dk + tid * K_STRIDE + D + 2) = rbias;
+        }
 #pragma unroll
         for (int i = 0; i < K_PER_T; ++i)
             if (kok[i]) *reinterpret_cast<uint4 *>(dk + koff[i]) = rk[i];
@@ -612,6 +642,7 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const int fe = te < nfull ? te : nfull;                                 // end of the full tiles of this range
     so_k = (uint32_t)tb * kstep;
     so_v = (uint32_t)tb * vstep;
+    so_b = (uint32_t)tb * (uint32_t)KV * 4u;
     if (tb < fe) issue_full(); else issue_tail((int64_t)tb * KV);
     write_lds(0);
     __syncthreads();
@@ -713,17 +744,18 @@ TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk, bool bounded = 
     return p;
 }
 
-template <typename T, int D>
+template <typename T, int D, bool FOLD = false>
 int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt, void *out,
            int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale, int share_groups,
-           void *ws, size_t ws_bytes, const int32_t *q_count, hipStream_t s) {
+           void *ws, size_t ws_bytes, const int32_t *q_count, hipStream_t s, const int32_t *k_count = nullptr,
+           const uint32_t *k_bias = nullptr, int64_t ldkb = 0) {
     constexpr int DK = (D + 15) / 16;
     constexpr size_t lds = (size_t)2 * (KV * (DK * 16 + 8) + vrows_for(D) * VT_STRIDE) * 2;
     if (lds > 64 * 1024) {   // opt in to > 64 KB of dynamic LDS once per (kernel instantiation, device)
-        static std::atomic<bool> attr_set[vtm::MAX_DEVICES];
+        static std::atomic<bool> attr_set[vtm::MAX_DEVICES];   // (one per instantiation of this function template)
         const int dev = vtm::current_device();
         if (!attr_set[dev].load(std::memory_order_acquire)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<T, D>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<T, D, FOLD>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess)
                 return vtm::fail(VTM_ELAUNCH, "vtm_attention: LDS attribute: %s", hipGetErrorString(e));
@@ -751,10 +783,10 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
 #else
     const int xcd_groups = ((B * h) % 8 == 0 && p.nqb >= 64) ? (int)(B * h / 8) : 0;
 #endif
-    hipLaunchKernelGGL((attention_kernel<T, D>), dim3((unsigned)(p.full + rem * p.nsplit)), dim3(WAVES * 64), lds, s,
+    hipLaunchKernelGGL((attention_kernel<T, D, FOLD>), dim3((unsigned)(p.full + rem * p.nsplit)), dim3(WAVES * 64), lds, s,
                        (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
                        scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws, xcd_groups, q_count,
-                       p.split_all ? rem : (int64_t)0);
+                       p.split_all ? rem : (int64_t)0, k_count, k_bias, ldkb);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem), dim3(WAVES * 64), 0, s,
                            (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups, q_count);
@@ -851,6 +883,27 @@ VTM_EXPORT int vtm_attention_kv_bounded(const void *q, int64_t ldq, const void *
     VTM_REQUIRE(q_count, "vtm_attention_kv_bounded: null q_count");
     return attention_any(q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, Mq, Mqp, Mk, Mkp, d, scale, 1, ws, ws_bytes,
                          q_count, stream);
+}
+
+VTM_EXPORT int vtm_attention_kv_folded(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+                                       void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
+                                       int64_t Mk, int64_t Mkp, int64_t d, float scale, const int32_t *q_count,
+                                       const int32_t *k_count, const uint32_t *k_bias, int64_t ldkb, void *ws, size_t ws_bytes,
+                                       vtm_stream_t stream) {
+    VTM_REQUIRE(q && k && vt && out && k_count && k_bias, "vtm_attention_kv_folded: null pointer");
+    VTM_REQUIRE(B > 0 && h > 0 && Mq > 0 && Mk > 0 && Mqp >= Mq && Mkp >= Mk && ldkb >= Mk, "vtm_attention_kv_folded: bad sizes");
+    VTM_REQUIRE(d == 40 || d == 8, "vtm_attention_kv_folded: head dim %lld has no spare k-slots for the bias (d = 8, 40 do)", (long long)d);
+    VTM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Mk,
+                "vtm_attention_kv_folded: leading dimensions must keep 16-byte alignment (ldvt >= Mk, %% 8)");
+    VTM_REQUIRE((Mkp * ldk + d) * 2 < (1ll << 31) && (d * ldvt + Mkp) * 2 < (1ll << 31) && Mkp * 4 < (1ll << 31),
+                "vtm_attention_kv_folded: a (sample, head) slice of K or V^T must stay below 2 GiB");
+    hipStream_t s = vtm::as_stream(stream);
+#define VTM_FOLDED(T, D) launch<T, D, true>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, 1, ws, ws_bytes, q_count, s, \
+                                            k_count, k_bias, ldkb)
+    if (dtype == VTM_F16) return d == 40 ? VTM_FOLDED(__half, 40) : VTM_FOLDED(__half, 8);
+    if (dtype == VTM_BF16) return d == 40 ? VTM_FOLDED(vtm_bf16, 40) : VTM_FOLDED(vtm_bf16, 8);
+#undef VTM_FOLDED
+    return vtm::fail(VTM_EINVAL, "vtm_attention_kv_folded: dtype must be VTM_F16 or VTM_BF16");
 }
 
 VTM_EXPORT int vtm_attention(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt,

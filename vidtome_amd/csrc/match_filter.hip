@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void seed_kernel(const T *__restrict__ x0, int
                                                    const int32_t *__restrict__ b_rows, int64_t Nd,
                                                    const float *__restrict__ na, const float *__restrict__ nb, int align,
                                                    int64_t seed_L, int64_t N, const int32_t *__restrict__ pos1,
-                                                   const int32_t *__restrict__ table, unsigned int *__restrict__ amax) {
+                                                   const int32_t *__restrict__ table, unsigned int *__restrict__ amax, int dry) {
     constexpr int LPR = 8;                                   // lanes per row
     const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;     // (sample, src row)
     const int sub = threadIdx.x & (LPR - 1);
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void seed_kernel(const T *__restrict__ x0, int
     for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (sub == 0) {
         const float s = acc / (na[b * Ns + i] * nb[b * Nd + j]);
-        if (s == s && __builtin_fabsf(s) <= 1.5f)            // (a row without a usable norm publishes nothing)
+        if (s == s && __builtin_fabsf(s) <= 1.5f && !dry)    // (a row without a usable norm publishes nothing)
             atomicMax(&amax[align ? i : b * Ns + i], orderable(s));
     }
 }
@@ -1429,19 +1429,20 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
     }
 
     if (seed_N > 0) {   // starting maxima from same-position guesses (a kernel boundary behind prep_operand: norms, cleared amax)
+        const int dry = getenv("VTM_DEBUG_SEED_DRY") != nullptr;   // A/B hook: the seeds are computed and thrown away
         const dim3 grid((unsigned)vtm::cdiv(B * Ns * 8, 256)), block(256);
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(seed_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1, B, C, a_rows,
-                                   Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax);
+                                   Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax, dry);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(seed_kernel<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1, P1, B, C,
-                                   a_rows, Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax);
+                                   a_rows, Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax, dry);
                 break;
             default:
                 hipLaunchKernelGGL(seed_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0, (const vtm_bf16 *)x1, P1, B,
-                                   C, a_rows, Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax);
+                                   C, a_rows, Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax, dry);
         }
     }
     {

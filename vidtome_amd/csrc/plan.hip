@@ -245,6 +245,116 @@ __global__ __launch_bounds__(CQ_THREADS) void compact_queries_kernel(const int32
     }
 }
 
+
+// ---- duplicate keys of the merged sequence (the anchors' exact copies) -> one key each + a multiplicity ----
+// patch.py:80 stores u(merged) as the next chunk's anchors: every local token that merged into an anchor row carries that
+// row's content, so the anchor set holds groups of IDENTICAL rows (cid = a content id per anchor row, equal ids <=> equal
+// rows; the host gets it for free: vtm_compact_queries' tmap).  Identical key rows give identical scores and identical
+// value rows: m copies weigh exactly like one key whose score carries + log2(m) (base-2 softmax).  Three launches behind one
+// memset: mark (first merged position and number of present copies per content id), keep (bitmap of the surviving
+// positions), compact (LDS prefix sums of the bitmap words like compact_queries_kernel).
+__global__ __launch_bounds__(256) void fold_mark_kernel(const int32_t *__restrict__ cur, int64_t B, int64_t M, int64_t L,
+                                                        const int32_t *__restrict__ cid, int64_t Ma, int64_t n_ids,
+                                                        uint32_t *__restrict__ firstinv, uint32_t *__restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * M) return;
+    const int64_t b = i / M, m = i % M;
+    const int64_t id = cur[i];
+    if (id < L) return;
+    const int64_t c = cid[b * Ma + (id - L)];
+    atomicMax(&firstinv[b * n_ids + c], 0xffffffffu - (uint32_t)m);      // zero-initialised: the smallest m wins
+    atomicAdd(&cnt[b * n_ids + c], 1u);
+}
+
+__global__ __launch_bounds__(256) void fold_keep_kernel(const int32_t *__restrict__ cur, int64_t M, int64_t L,
+                                                        const int32_t *__restrict__ cid, int64_t Ma, int64_t n_ids,
+                                                        const uint32_t *__restrict__ firstinv, int64_t words,
+                                                        uint32_t *__restrict__ bits) {
+    const int64_t b = blockIdx.y, m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // a wave = 64 consecutive positions
+    bool keep = false;
+    if (m < M) {
+        const int64_t id = cur[b * M + m];
+        keep = id < L || firstinv[b * n_ids + cid[b * Ma + (id - L)]] == 0xffffffffu - (uint32_t)m;
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 31) == 0 && (m >> 5) < words) bits[b * words + (m >> 5)] = (uint32_t)(bal >> (lane & 32));
+}
+
+__device__ __forceinline__ uint32_t split16(float v, int dtype) {     // v = hi + lo in the 16-bit type of the keys
+    if (dtype == VTM_F16) {
+        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+        return (uint32_t)__builtin_bit_cast(unsigned short, h) | ((uint32_t)__builtin_bit_cast(unsigned short, l) << 16);
+    }
+    const __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
+    return (uint32_t)__builtin_bit_cast(unsigned short, h) | ((uint32_t)__builtin_bit_cast(unsigned short, l) << 16);
+}
+
+__global__ __launch_bounds__(CQ_THREADS) void fold_compact_kernel(const int32_t *__restrict__ cur, int64_t M, int64_t L,
+                                                                 const int32_t *__restrict__ cid, int64_t Ma, int64_t n_ids,
+                                                                 const uint32_t *__restrict__ cnt, int64_t words,
+                                                                 const uint32_t *__restrict__ bits, int dtype,
+                                                                 int32_t *__restrict__ key_sel, uint32_t *__restrict__ k_bias,
+                                                                 int64_t ldkb, int32_t *__restrict__ k_count) {
+    __shared__ uint32_t sbits[CQ_MAX_WORDS];
+    __shared__ int32_t spre[CQ_MAX_WORDS];
+    __shared__ int32_t wave_sum[CQ_THREADS / 64];
+    __shared__ int32_t total_s;
+    const int64_t b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *bb = bits + b * words;
+    for (int64_t w = tid; w < words; w += CQ_THREADS) sbits[w] = bb[w];
+    __syncthreads();
+    const int per = (int)((words + CQ_THREADS - 1) / CQ_THREADS);
+    const int64_t w0 = (int64_t)tid * per, w1 = w0 + per < words ? w0 + per : words;
+    int32_t mine = 0;
+    for (int64_t w = w0; w < w1; ++w) mine += __popc(sbits[w]);
+    int32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t run = 0;
+        for (int w = 0; w < CQ_THREADS / 64; ++w) {
+            const int32_t v = wave_sum[w];
+            wave_sum[w] = run;
+            run += v;
+        }
+        total_s = run;
+    }
+    __syncthreads();
+    int32_t run = wave_sum[wave] + incl - mine;
+    for (int64_t w = w0; w < w1; ++w) {
+        spre[w] = run;
+        run += __popc(sbits[w]);
+    }
+    __syncthreads();
+    const int64_t kept = total_s;
+    if (blockIdx.x == 0 && tid == 0) k_count[b] = (int32_t)kept;
+    const int64_t gsz = (int64_t)gridDim.x * CQ_THREADS, g0 = (int64_t)blockIdx.x * CQ_THREADS + tid;
+    for (int64_t m = g0; m < M; m += gsz) {
+        if (sbits[m >> 5] >> (m & 31) & 1u) {
+            const int64_t j = spre[m >> 5] + __popc(sbits[m >> 5] & ((1u << (m & 31)) - 1u));
+            const int64_t id = cur[b * M + m];
+            key_sel[b * M + j] = (int32_t)m;
+            uint32_t bias = 0u;                                           // log2(1)
+            if (id >= L) {
+                const uint32_t c = cnt[b * n_ids + cid[b * Ma + (id - L)]];
+                if (c > 1u) bias = split16(log2f((float)c), dtype);
+            }
+            k_bias[b * ldkb + j] = bias;
+        }
+        if (m >= kept) {                                                  // past the count: valid rows nobody reads
+            key_sel[b * M + m] = 0;
+            k_bias[b * ldkb + m] = 0u;
+        }
+    }
+}
+
 }  // namespace
 
 VTM_EXPORT size_t vtm_compact_queries_ws_bytes(int64_t B, int64_t Nd) {
@@ -270,6 +380,33 @@ VTM_EXPORT int vtm_compact_queries(const int32_t *loc, int64_t B, int64_t Ml, in
     hipLaunchKernelGGL(compact_queries_kernel, dim3(per_sample, (unsigned)B), dim3(CQ_THREADS), 0, s, loc, Ml, U, Nd, words,
                        (const uint32_t *)bits, qc, tmap, count);
     return vtm::launch_status("vtm_compact_queries");
+}
+
+VTM_EXPORT size_t vtm_fold_keys_ws_bytes(int64_t B, int64_t M, int64_t n_ids) {
+    return (size_t)(B > 0 && M > 0 && n_ids > 0 ? B * (2 * n_ids + vtm::cdiv(M, 32)) * 4 : 0);
+}
+
+VTM_EXPORT int vtm_fold_keys(const int32_t *cur, int64_t B, int64_t M, int64_t L, const int32_t *cid, int64_t Ma,
+                             int64_t n_ids, int dtype, void *ws, size_t ws_bytes, int32_t *key_sel, uint32_t *k_bias,
+                             int64_t ldkb, int32_t *k_count, vtm_stream_t stream) {
+    VTM_REQUIRE(cur && cid && ws && key_sel && k_bias && k_count, "vtm_fold_keys: null pointer");
+    VTM_REQUIRE(B > 0 && M > 0 && L >= 0 && Ma > 0 && n_ids > 0 && ldkb >= M, "vtm_fold_keys: bad sizes");
+    VTM_REQUIRE(dtype == VTM_F16 || dtype == VTM_BF16, "vtm_fold_keys: the keys are fp16 or bf16");
+    if (ws_bytes < vtm_fold_keys_ws_bytes(B, M, n_ids))
+        return vtm::fail(VTM_EWORKSPACE, "vtm_fold_keys: workspace %zu < %zu bytes", ws_bytes, vtm_fold_keys_ws_bytes(B, M, n_ids));
+    const int64_t words = vtm::cdiv(M, 32);
+    VTM_REQUIRE(words <= CQ_MAX_WORDS, "vtm_fold_keys: more than %d merged rows per sample", CQ_MAX_WORDS * 32);
+    hipStream_t s = vtm::as_stream(stream);
+    uint32_t *firstinv = static_cast<uint32_t *>(ws), *cnt = firstinv + B * n_ids, *bits = cnt + B * n_ids;
+    const hipError_t e = hipMemsetAsync(ws, 0, vtm_fold_keys_ws_bytes(B, M, n_ids), s);
+    if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_fold_keys: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(fold_mark_kernel, dim3(blocks_for(B * M)), dim3(256), 0, s, cur, B, M, L, cid, Ma, n_ids, firstinv, cnt);
+    hipLaunchKernelGGL(fold_keep_kernel, dim3(blocks_for(M), (unsigned)B), dim3(256), 0, s, cur, M, L, cid, Ma, n_ids,
+                       (const uint32_t *)firstinv, words, bits);
+    const unsigned per_sample = (unsigned)std::min<int64_t>(vtm::cdiv(M, CQ_THREADS * 2), 64);
+    hipLaunchKernelGGL(fold_compact_kernel, dim3(per_sample, (unsigned)B), dim3(CQ_THREADS), 0, s, cur, M, L, cid, Ma, n_ids,
+                       (const uint32_t *)cnt, words, (const uint32_t *)bits, dtype, key_sel, k_bias, ldkb, k_count);
+    return vtm::launch_status("vtm_fold_keys");
 }
 
 VTM_EXPORT int vtm_partition_counts(int64_t N_in, int64_t unm_pre, int64_t tnum, int64_t ts,

@@ -53,7 +53,7 @@ class MergePlan:
     """What ``compute_merge`` produces for one block call: composed maps + the merged tokens."""
 
     __slots__ = ("fsize", "L", "M", "gather_map", "_inv", "_inv_parts", "_merged", "levels", "global_level", "local_chunk",
-                 "x_joined", "anchors_in", "q_rows", "inv_q", "q_count", "pad_to")
+                 "x_joined", "anchors_in", "q_rows", "inv_q", "q_count", "pad_to", "fold_args", "_key_fold")
 
     def __init__(self):
         self.levels = []
@@ -74,6 +74,11 @@ class MergePlan:
         self.q_rows = None
         self.inv_q = None
         self.q_count = None
+        # The anchors' exact duplicates (patch.py:80 copies an anchor row to every local token that merged into it) are
+        # duplicate KEYS of the next block: (merged-position -> pool row map, L, content id per anchor row, number of ids)
+        # when the anchors carry ids, folded on first use by the attention path that can take a per-key multiplicity
+        self.fold_args = None
+        self._key_fold = None
         self._merged = None
         self.pad_to = 8
 
@@ -86,6 +91,13 @@ class MergePlan:
             inv_local, loc = self._inv_parts
             self._inv = _lib.compose(inv_local, loc, self.L) if inv_local is not None else loc
         return self._inv
+
+    def key_fold(self, dtype) -> Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """(key_sel, k_bias, k_count) of _lib.fold_keys, or None when the anchors carried no content ids."""
+        if self._key_fold is None and self.fold_args is not None:
+            cur, L, cid, n_ids = self.fold_args
+            self._key_fold = _lib.fold_keys(cur, L, cid, n_ids, dtype)
+        return self._key_fold
 
     @property
     def merged(self) -> torch.Tensor:
@@ -170,6 +182,13 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
             gt_pos = getattr(gt, "_vtm_pos", None) if gt is not None else None
             if gt_pos is not None and (tuple(gt_pos.shape) != tuple(gt.shape[:2]) or gt_pos.device != xj.device):
                 gt_pos = None
+            # content ids (equal id = identical rows), same lifetime rule -- and, because RESULTS depend on them, only while
+            # nobody has written to the tensor since (in-place edits bump torch's version counter)
+            gt_cid = getattr(gt, "_vtm_cid", None) if gt is not None else None
+            if gt_cid is not None and (tuple(gt_cid[0].shape) != tuple(gt.shape[:2]) or gt_cid[0].device != xj.device
+                                       or gt_cid[1] != gt._version or gt.dtype != xj.dtype):
+                gt_cid = None
+            gt_cid = gt_cid[0] if gt_cid is not None else None
             if gt is not None:
                 gt = gt.to(xj).contiguous()                                        # patch.py:65,70
                 coin = _draw_coin(generator)
@@ -189,10 +208,17 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 amap = _lib.compose(loc, gl.new_cur, Ml)
                 anchors_out = _lib.gather_rows(xj, gt, amap)
                 anchors_pos = _lib.anchor_pos(amap, B, Ml, L, tsize, gt_pos, xj.device) if _lib.SEED_MATCHER else None
+                anchors_cid = None
+                if gt_cid is not None and _lib.FOLD_KEYS and gl.new_cur.shape[1] <= 131072:
+                    plan.fold_args = (gl.new_cur, L, gt_cid, gt.shape[1])
                 if local_is_src and COMPACT_QUERIES and gl.Nd <= 131072:      # (vtm_compact_queries' bitmap lives in LDS)
                     qc, tmap, plan.q_count = _lib.compact_queries(loc, gl.Ns - gl.r, gl.Nd)
                     plan.q_rows = qc
                     plan.inv_q = _lib.compose(inv, tmap, L) if inv is not None else tmap
+                    # local tokens that share a merged position become identical rows of the new anchors: tmap is an id
+                    # per distinct position (old anchor rows that were copies of each other keep distinct ids -- a
+                    # missed fold, never a wrong one)
+                    anchors_cid = tmap
                 else:
                     plan.q_rows, plan.inv_q = loc, inv
                 plan._inv_parts, inv = (inv, loc), None      # composed lazily (MergePlan.inv)
@@ -207,6 +233,8 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 module.global_tokens = anchors_out
                 if anchors_pos is not None:
                     anchors_out._vtm_pos = anchors_pos
+                if anchors_cid is not None:
+                    anchors_out._vtm_cid = (anchors_cid, anchors_out._version)
             elif plan.global_level is None:
                 # patch.py:82: first chunk of a step stores its local tokens (device-resident, shared
                 # with `merged`, which nothing mutates)
@@ -493,12 +521,14 @@ def _weight(m: torch.nn.Module, dtype) -> torch.Tensor:
 
 def self_attention_rows(attn: torch.nn.Module, x0: torch.Tensor, x1: Optional[torch.Tensor],
                         rows: Optional[torch.Tensor], q_rows: Optional[torch.Tensor] = None,
-                        q_count: Optional[torch.Tensor] = None) -> torch.Tensor:
+                        q_count: Optional[torch.Tensor] = None, plan: Optional["MergePlan"] = None) -> torch.Tensor:
     """``attn1(merged)`` (patch.py:157-162; arithmetic of pnp_utils.py:47-95) with ``merged[b, i] = pool[b, rows[b, i]]``
     never materialised: every projection is a vtm_linear_rows GEMM that fetches its A rows through the composed merge
     map (pool = x0 | x1, ``rows`` None = the rows of x0 as they are), k and v for all M rows (v channel-major, what the
     PV contraction reads), q -- and the output projection -- only for the ``q_rows`` positions when given (the rows
-    unmerge() reads).  Returns (B, Mq rounded up to 8, C); rows >= Mq are not meaningful."""
+    unmerge() reads).  Returns (B, Mq rounded up to 8, C); rows >= Mq are not meaningful.
+    With a ``plan`` whose anchors carried content ids and a head dim that has spare contraction slots (40), k and v are
+    projected for the duplicate-free key list only (MergePlan.key_fold) and every key carries log2 of its multiplicity."""
     B, _, C = x0.shape
     M = x0.shape[1] if rows is None else rows.shape[1]
     Mp = (M + 7) // 8 * 8
@@ -510,6 +540,19 @@ def self_attention_rows(attn: torch.nn.Module, x0: torch.Tensor, x1: Optional[to
     dt = x0.dtype
     wqk, bqk = _fused_weights(attn, dt, x0.device)
     bv = getattr(attn.to_v, "bias", None)
+    fold = None
+    if plan is not None and rows is not None and share == 1 and (C // heads) in (8, 40):
+        fold = plan.key_fold(dt)
+    if fold is not None:
+        key_sel, k_bias, k_count = fold
+        vt = _lib.linear_rows(x0, x1, rows, key_sel, M, _weight(attn.to_v, dt), None if bv is None else bv.to(dt),
+                              transposed=True)
+        k_op = _lib.linear_rows(x0, x1, rows, key_sel, M, wqk[C:], None if bqk is None else bqk[C:])
+        Mq = M if q_rows is None else q_rows.shape[1]
+        q_op = _lib.linear_rows(x0, x1, rows, q_rows, Mq, wqk[:C], None if bqk is None else bqk[:C])
+        o = _lib.attention_kv(q_op, k_op, vt, heads, Mq, M, scale, q_count=q_count, k_fold=(k_count, k_bias))
+        to_out = _out_linear(attn)
+        return _lib.linear_rows(o, None, None, None, Mq, _weight(to_out, dt), None if to_out.bias is None else to_out.bias.to(dt))
     vt = _lib.linear_rows(x0, x1, rows, None, M, _weight(attn.to_v, dt), None if bv is None else bv.to(dt),
                           transposed=True)                                                       # (B, C, Mp)
     if q_rows is None:
@@ -791,7 +834,8 @@ def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.
             if plan is None:                                              # block does not merge: per-frame attention
                 attn_output = sa(block.attn1, norm_hidden_states.contiguous(), None, None)
             else:
-                attn_output = sa(block.attn1, plan.x_joined, plan.anchors_in, plan.gather_map, q_rows, q_count)
+                attn_output = sa(block.attn1, plan.x_joined, plan.anchors_in, plan.gather_map, q_rows, q_count,
+                                 **({"plan": plan} if by_rows else {}))
         else:
             attn_output = self_attention(block.attn1, merged, plan.M if plan is not None else None, q_rows, q_count)
         if live:
