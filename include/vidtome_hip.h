@@ -274,6 +274,13 @@ int vtm_attention_kv_bounded(const void *q, int64_t ldq, const void *k, int64_t 
  * workspace than this the launch falls back to the plain plan of vtm_attention_ws_bytes */
 size_t vtm_attention_kv_bounded_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64_t Mk, int64_t d);
 
+/* vtm_transpose_cols -- V^T of a block that does not merge (patch.py:157-162 at the sites beyond max_downsample: per-frame
+ * attention): the q | k | v projection GEMM leaves v as columns of its token-major output, the attention core reads V
+ * channel-major.  x (BF, N, ldx) 16-bit, the C columns starting at `x` -> out (BF, C, ldo), tokens N .. ldo zero-filled.
+ * C, ldx, ldo multiples of 8, ldo >= N, 16-byte aligned pointers. */
+int vtm_transpose_cols(const void *x, int64_t ldx, int dtype, int64_t BF, int64_t N, int64_t C, void *out, int64_t ldo,
+                       vtm_stream_t stream);
+
 /* vtm_fold_keys / vtm_attention_kv_folded -- the anchors' exact duplicates as ONE key each.  patch.py:80 stores
  * u(merged_tokens) as the next chunk's global tokens: every local token that merged into an anchor row carries that
  * row's content, so the anchors hold groups of identical rows, and so does the merged sequence they join

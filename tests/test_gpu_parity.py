@@ -1067,6 +1067,19 @@ def test_attention_core_vs_oracle(L, oracle, shape, dtype):
         assert np.abs(o - ref).max() < tol * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("shape", [(32, 256, 3840, 2560, 1280), (3, 70, 192, 64, 64), (2, 1000, 960, 320, 640)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_transpose_cols_vs_torch(L, shape, dtype):
+    """vtm_transpose_cols: the V columns of a fused q | k | v projection, channel-major, token padding zero-filled."""
+    BF, N, ld, c0, C = shape
+    x = torch.randn(BF, N, ld, generator=torch.Generator().manual_seed(N)).to(dtype).to(DEV)
+    out = L.transpose_cols(x, c0, C)
+    Np = (N + 7) // 8 * 8
+    assert out.shape == (BF, C, Np)
+    assert torch.equal(out[:, :, :N], x[:, :, c0:c0 + C].transpose(1, 2))
+    assert not out[:, :, N:].any()
+
+
 def _fold_reference(cur, L, cid):
     """numpy restatement of vtm_fold_keys: first copy of every content id survives, with the number of copies present."""
     B, M = cur.shape

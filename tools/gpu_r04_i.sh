@@ -7,8 +7,8 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 for shape in top_l1 top_l2 top_g mid_l1 mid_g; do
-  timeout 200 python tools/kbench.py match --shape $shape --data corr05 --iters 9 2>&1 | grep -v amdgpu.ids >> $O/kbench_noseed.txt
-  timeout 200 python tools/kbench.py match --shape $shape --data corr05 --iters 9 --seed 2>&1 | grep -v amdgpu.ids >> $O/kbench_seed.txt
+  timeout 200 python tools/kbench.py match --shape $shape --data corr05 --iters 9 --no-seed 2>&1 | grep -v amdgpu.ids >> $O/kbench_noseed.txt
+  timeout 200 python tools/kbench.py match --shape $shape --data corr05 --iters 9 2>&1 | grep -v amdgpu.ids >> $O/kbench_seed.txt
 done
 for rep in 1 2; do
   VIDTOME_SEED=0 timeout 600 python bench.py --no-cpu-baseline --steps 30 > $O/bench_noseed$rep.json 2>> $O/bench.err

@@ -50,8 +50,9 @@ def main():
     ap.add_argument("--B", type=int, default=2)
     ap.add_argument("--n", type=int, default=49152)
     ap.add_argument("--align", action="store_true")
-    ap.add_argument("--seed", action="store_true", help="match: seed the filtered matcher with same-position guesses (the rows of a "
-                    "kbench call are frame-ordered: dst index = position in the first dst frame)")
+    ap.add_argument("--no-seed", action="store_true", help="match: the filtered matcher WITHOUT its same-position seeds (default: "
+                    "seeded like the product path -- the rows of a kbench call are frame-ordered: dst index = position in the "
+                    "first dst frame)")
     ap.add_argument("--C", type=int, default=320)
     ap.add_argument("--data", default="random", help="attn: random | zeros | const (operand values); match: n01 | corr01 | "
                     "corr05 | flat25 | dup | zero | all (token regime; random = n01 in fp16 straight from the device generator)")
@@ -67,7 +68,7 @@ def main():
         N = 4096
         while Ns % N or Nd % N:
             N //= 2
-        seed = (N, Ns + Nd, None, None) if a.seed else None
+        seed = None if a.no_seed else (N, Ns + Nd, None, None)
 
         def tokens(regime):
             if regime == "random":

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "vtm_attention_kv_bounded": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _f32, _vp, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_attention_kv_bounded_ws_bytes": ([_i64, _i64, _i64, _i64, _i64], ctypes.c_size_t),
+    "vtm_transpose_cols": ([_vp, _i64, _int, _i64, _i64, _i64, _vp, _i64, _vp], _int),
     "vtm_fold_keys_ws_bytes": ([_i64, _i64, _i64], ctypes.c_size_t),
     "vtm_fold_keys": ([_vp, _i64, _i64, _i64, _vp, _i64, _i64, _int, _vp, ctypes.c_size_t, _vp, _vp, _i64, _vp, _vp], _int),
     "vtm_attention_kv_folded": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
@@ -388,6 +389,21 @@ def unmerge_add(y: torch.Tensor, inv: torch.Tensor, resid: Optional[torch.Tensor
             raise RuntimeError("residual shape/dtype mismatch")
     _check(lib().vtm_unmerge_add(_ptr(y), Mp, _ptr(inv), _ptr(resid), dtype_code(y), B, L, C, _ptr(out), _stream()),
            "vtm_unmerge_add")
+    return out
+
+
+@_on_device
+def transpose_cols(x: torch.Tensor, c0: int, C: int) -> torch.Tensor:
+    """x (BF, N, ld) 16-bit, contiguous along the last axis -> (BF, C, Np) = columns [c0, c0 + C) channel-major, Np = N
+    rounded up to 8 (zero-filled): the V^T operand of the attention core from a fused q | k | v projection."""
+    _req(x, "x")
+    BF, N, ld = x.shape
+    if x.stride(2) != 1 or x.stride(1) != ld or x.stride(0) != N * ld or c0 % 8 or C % 8:
+        raise RuntimeError("transpose_cols: dense (BF, N, ld) input, column window aligned to 8")
+    Np = (N + 7) // 8 * 8
+    out = torch.empty((BF, C, Np), dtype=x.dtype, device=x.device)
+    _check(lib().vtm_transpose_cols(x.data_ptr() + c0 * x.element_size(), ld, dtype_code(x), BF, N, C, _ptr(out), Np, _stream()),
+           "vtm_transpose_cols")
     return out
 
 

@@ -153,6 +153,39 @@ inline unsigned grid_for(int64_t total) {
     return (unsigned)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap);
 }
 
+// V^T of an un-merged site: the q | k | v projection GEMM leaves v as columns [c0, c0 + C) of its (BF, N, ldx) output, the
+// attention core reads V channel-major (BF, C, ldo >= N).  64 x 64 tiles of 16-bit elements through LDS: 128-byte row
+// segments in, 128-byte channel segments out (a strided torch copy of the same 21 MB took 32 us at the C = 1280 sites).
+__global__ __launch_bounds__(256) void transpose_cols_kernel(const uint16_t *__restrict__ x, int64_t ldx, int64_t N, int64_t C,
+                                                             uint16_t *__restrict__ out, int64_t ldo) {
+    __shared__ uint16_t tile[64][64 + 2];      // 33 words per row: column reads step through the banks
+    const int64_t b = blockIdx.z, n0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const uint16_t *xb = x + b * N * ldx;
+    uint16_t *ob = out + b * C * ldo;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {              // 64 rows x 8 pieces of 8 elements
+        const int q = tid + 256 * t, r = q >> 3, p = q & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (n0 + r < N && c0 + p * 8 < C) v = *reinterpret_cast<const uint4 *>(xb + (n0 + r) * ldx + c0 + p * 8);
+        const uint16_t *e = reinterpret_cast<const uint16_t *>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[r][p * 8 + k] = e[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {              // 64 channels x 8 pieces of 8 tokens
+        const int q = tid + 256 * t, c = q >> 3, p = q & 7;
+        if (c0 + c < C && n0 + p * 8 < ldo) {  // (ldo is a multiple of 8: the piece stays inside the row; tokens >= N get zeros)
+            uint4 v;
+            uint16_t *e = reinterpret_cast<uint16_t *>(&v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = tile[p * 8 + k][c];
+            *reinterpret_cast<uint4 *>(ob + (c0 + c) * ldo + n0 + p * 8) = v;
+        }
+    }
+}
+
 }  // namespace
 
 VTM_EXPORT int vtm_gather_rows(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype,
@@ -224,4 +257,17 @@ VTM_EXPORT int vtm_merge_reduce(const void *x, int dtype, int64_t B, int64_t N, 
                                dst_rows, seg_dst, seg_order, r, Nd, mode, (vtm_bf16 *)out, out_ld, out_row0);
     }
     return vtm::launch_status("vtm_merge_reduce");
+}
+
+VTM_EXPORT int vtm_transpose_cols(const void *x, int64_t ldx, int dtype, int64_t BF, int64_t N, int64_t C, void *out,
+                                  int64_t ldo, vtm_stream_t stream) {
+    VTM_REQUIRE(x && out, "vtm_transpose_cols: null pointer");
+    VTM_REQUIRE(dtype == VTM_F16 || dtype == VTM_BF16, "vtm_transpose_cols: 16-bit tokens only");
+    VTM_REQUIRE(BF > 0 && N > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldx >= C && ldo % 8 == 0 && ldo >= N,
+                "vtm_transpose_cols: bad sizes (C, ldx, ldo multiples of 8; ldo >= N)");
+    VTM_REQUIRE(BF < 65536 && vtm::cdiv(C, 64) < 65536, "vtm_transpose_cols: grid too large");
+    VTM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, "vtm_transpose_cols: 16-byte aligned operands");
+    hipLaunchKernelGGL(transpose_cols_kernel, dim3((unsigned)vtm::cdiv(ldo, 64), (unsigned)vtm::cdiv(C, 64), (unsigned)BF), dim3(256), 0,
+                       vtm::as_stream(stream), (const uint16_t *)x, ldx, N, C, (uint16_t *)out, ldo);
+    return vtm::launch_status("vtm_transpose_cols");
 }

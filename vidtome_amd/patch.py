@@ -497,7 +497,7 @@ def unmerged_self_attention_residual(block: torch.nn.Module, hidden_states: torc
     wqkv, bqkv = _packed(attn, "qkv", pack_qkv)
     xp = _lib.layernorm_panels(hs, norm.weight, norm.bias, norm.eps)
     qkv = _lib.linear_panels(xp, n, wqkv, 3 * C, bqkv).view(BF, N, 3 * C)
-    vt = qkv[:, :, 2 * C:].transpose(1, 2).contiguous()                  # (BF, C, N): small (un-merged sites are the deep ones)
+    vt = _lib.transpose_cols(qkv, 2 * C, C)                              # (BF, C, N): V channel-major for the PV contraction
     o = _lib.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], vt, heads, N, scale, 1)
     wo, bo = _panel_weight(_out_linear(attn))
     op = _lib.to_panels(o.view(n, C))
