@@ -1576,7 +1576,7 @@ def test_attention_d40_wide_scores_fuzz(L):
         assert err <= 2e-3 * max(1.0, float(ref.abs().max())), (case, B, h, Mq, Mk, sq, sk, err)
 
 
-@pytest.mark.parametrize("d,Mq", [(80, 8704), (40, 8448)])
+@pytest.mark.parametrize("d,Mq", [(80, 8704), (40, 8448), (64, 8704), (160, 8704)])
 def test_attention_split_last_round_equals_single_launch(L, d, Mq):
     """A launch whose last round of workgroups is nearly empty runs those query blocks as key-split workgroups plus
     a combine kernel (attention.hip, plan_tail).  d = 80: shape of the cfg-2 mid blocks, 17 x 16 = 272 workgroups on

@@ -132,7 +132,8 @@ __device__ __forceinline__ void mask_keys(uint4 &v, int valid) {
 template <typename T, int D>
 __device__ __forceinline__ void write_output(const f32x16 (&o)[(D + 31) / 32], float l_run, T *__restrict__ out,
                                              int64_t ldo, int64_t b, int64_t h, int64_t q0, int64_t M, int64_t Mp,
-                                             int l31, int hi) {
+                                             int l31, int hi, int r_lo = 0, int r_hi = 16 * ((D + 31) / 32)) {
+    // [r_lo, r_hi): the accumulator registers (dv * 16 + g * 4 + e) this caller holds -- whole 4-channel groups
     using elem = typename Frag<T>::elem;
     constexpr int DV = (D + 31) / 32;
     constexpr bool SPARE = (D % 32) != 0;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void write_output(const f32x16 (&o)[(D + 31) / 32], f
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = dv * 32 + 8 * g + 4 * hi;
-                if (d0 < D) {  // D % 8 == 0 and d0 % 4 == 0 -> the 4 channels are all valid
+                if (d0 < D && dv * 16 + g * 4 >= r_lo && dv * 16 + g * 4 < r_hi) {  // D % 8 == 0, d0 % 4 == 0: 4 valid channels
                     elem w[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w[e] = (elem)(o[dv][g * 4 + e] * inv_l);
@@ -206,6 +207,12 @@ __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
     if (q_count != nullptr && (lin % nqb) * QB >= (int64_t)q_count[b]) return;   // its partial records were never written
+    // few items (the split tail of a mid block: 16 of them, 16 records each) leave most of the chip idle: blockIdx.y then
+    // shares an item's accumulator registers out (whole 4-channel groups; 32-row layout only), every part redoing the
+    // maxima / denominator bookkeeping
+    constexpr int LREG_ALL = (PV16 || (D % 32) == 0) ? -1 : (D / 32) * 16 + ((D % 32) & 3) + 4 * ((D % 32) >> 3);
+    const int nparts = PV16 ? 1 : (int)gridDim.y, part = PV16 ? 0 : (int)blockIdx.y;
+    const int r_lo = part * (NA / nparts), r_hi = part + 1 == nparts ? NA : r_lo + NA / nparts;
     float acc[NA], m[NM], l = 0.0f;
 #pragma unroll
     for (int r = 0; r < NA; ++r) acc[r] = 0.0f;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
             const int j = PV16 ? (r >> 2) & 1 : 0;   // PV16: accumulator (dv, qh, e) is register (dv * 2 + qh) * 4 + e
-            acc[r] = acc[r] * fa[j] + pp[r * NT] * fb[j];
+            if ((r >= r_lo && r < r_hi) || r == LREG_ALL) acc[r] = acc[r] * fa[j] + pp[r * NT] * fb[j];
         }
     }
     if constexpr (PV16) {
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
         f32x16 o[DV];
 #pragma unroll
         for (int r = 0; r < NA; ++r) o[r >> 4][r & 15] = acc[r];
-        write_output<T, D>(o, l, out, ldo, b, h, q0, M, Mp, l31, hi);
+        write_output<T, D>(o, l, out, ldo, b, h, q0, M, Mp, l31, hi, r_lo, r_hi);
     }
 }
 
@@ -787,8 +794,10 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
                        (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
                        scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws, xcd_groups, q_count,
                        p.split_all ? rem : (int64_t)0, k_count, k_bias, ldkb);
+    // (parts: NA / 8 register groups per item when the items alone would not fill a quarter of the chip)
+    const unsigned parts = (!pv16_for(D) && rem * 4 <= vtm::device_cus() && acc_floats(D) % 8 == 0) ? (unsigned)(acc_floats(D) / 8) : 1u;
     if (p.nsplit > 1)
-        hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem), dim3(WAVES * 64), 0, s,
+        hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem, parts), dim3(WAVES * 64), 0, s,
                            (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups, q_count);
     return vtm::launch_status("vtm_attention");
 }
