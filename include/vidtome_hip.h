@@ -287,7 +287,7 @@ int vtm_transpose_cols(const void *x, int64_t ldx, int dtype, int64_t BF, int64_
  * (patch.py:63-71).  Identical key / value rows weigh in softmax(q k^T) v exactly like one key whose (base-2) score carries
  * + log2(multiplicity).  vtm_fold_keys: cur (B, M) pool row of every merged position (rows >= L are anchor rows cur - L of
  * Ma), cid (B, Ma) a content id in [0, n_ids) per anchor row (equal ids <=> identical rows; vtm_compact_queries' tmap of
- * the block that produced the anchors).  Outputs: key_sel (B, M) the surviving merged positions in ascending order (the
+ * the block that produced the anchors; an id outside [0, n_ids), e.g. -1, = "no id": the row stands for itself).  Outputs: key_sel (B, M) the surviving merged positions in ascending order (the
  * first copy of every group; entries past the count are 0), k_bias (B, ldkb) per surviving key log2(copies present) as
  * a (hi, lo) pair of the keys' 16-bit type (dtype VTM_F16 / VTM_BF16), k_count (B) the number of surviving keys.
  * vtm_attention_kv_folded is vtm_attention_kv_bounded (q_count may be NULL) over such a key list: k / vt hold the

@@ -124,7 +124,7 @@ def test_cfg4_ring_fake_ranks_equal_sequential(oracle):
         for bi, blk in enumerate(unet.blocks):
             assert torch.equal(blk.generator.get_state(), ref_end[bi])
     # rank 0 ran chunk 0 (sent to rank 1) and chunk 3 (the last of the step: nothing to forward)
-    assert ranks[0][1].bytes_sent == B * (18432 * 320 + 4608 * 640) * 2
+    assert ranks[0][1].bytes_sent == B * (18432 * 320 + 4608 * 640) * 2 + B * (18432 + 4608) * 4      # tokens + content ids
 
 
 def _free_port():

@@ -250,7 +250,7 @@ class LocalTransport:
 # the exchange
 # ----------------------------------------------------------------------------------------------------
 class _BlockState:
-    __slots__ = ("module", "tsize", "args", "drawn", "lens", "recv", "carry", "steps_done", "pool")
+    __slots__ = ("module", "tsize", "args", "drawn", "lens", "recv", "recv_ids", "carry", "steps_done", "pool")
 
     def __init__(self, module, tsize, args, steps_done=0):
         self.module, self.tsize, self.args = module, tsize, args
@@ -258,6 +258,7 @@ class _BlockState:
         self.drawn = 0          # chunks of the current step whose draws this block's generator has consumed
         self.lens: Dict[int, int] = {}    # chunk index -> merged local length (simulated or own)
         self.recv = None        # pending receive of the predecessor's tokens
+        self.recv_ids = None    # ring mode: ... and of their content ids (patch.compute_merge's key folding)
         self.carry = None       # tokens of this rank's previous chunk (world == 1 / all-gather wrap-around)
         self.pool = None        # neighbour mode, early hand-over: the predecessor's joined chunk on its way here
 
@@ -328,7 +329,7 @@ class AnchorExchange:
             raise ValueError("the all-gather mode is a collective per round: the step needs a multiple of "
                              f"{self.world} chunks (got {len(self._frames)}); use 'neighbour' or 'ring'")
         for st in self._blocks.values():
-            st.drawn, st.lens, st.recv, st.carry, st.pool = 0, {}, None, None, None
+            st.drawn, st.lens, st.recv, st.recv_ids, st.carry, st.pool = 0, {}, None, None, None, None
         # The sequential run forks every block generator at the block's first forward of the FIRST step
         # (patch.py:215-231), i.e. right after that step's schedule was drawn.  A rank whose first chunk comes later
         # would fork later -- after further draws from the global generator (the next steps' schedules) -- and its
@@ -371,6 +372,9 @@ class AnchorExchange:
             if st.recv is not None:                       # a posted receive nobody consumed (cannot happen in a
                 st.recv.wait()                            # well-formed step; drain it rather than leak it)
                 st.recv = None
+            if st.recv_ids is not None:
+                st.recv_ids.wait()
+                st.recv_ids = None
         for work, _ in self._inflight:
             if work is not None:
                 work.wait()
@@ -432,6 +436,10 @@ class AnchorExchange:
             return
         B = like.shape[0]
         st.recv = self.t.irecv((B, st.lens[i - 1], like.shape[2]), like.dtype, like.device, src)
+        # ... and their content ids (equal id = identical rows; -1 = none): the sequential run folds the anchors' exact copies
+        # into one attention key each (patch.MergePlan.key_fold), so the exact mode has to know them too.  Always sent --
+        # a second message whose presence depended on the predecessor's coin would have to be predicted here
+        st.recv_ids = self.t.irecv((B, st.lens[i - 1]), torch.int32, like.device, src)
 
     def anchors_for(self, key: str, local_tokens_fn: Callable[[], torch.Tensor], like: torch.Tensor,
                     local_map: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -448,7 +456,10 @@ class AnchorExchange:
             if st.recv is None:
                 return st.carry                            # world == 1
             got, st.recv = st.recv.wait(), None
-            self.bytes_received += got.numel() * got.element_size()
+            ids, st.recv_ids = st.recv_ids.wait(), None
+            self.bytes_received += got.numel() * got.element_size() + ids.numel() * 4
+            if got.is_cuda:
+                got._vtm_cid = (ids, got._version)
             return got
         if self.mode == "neighbour" and self.world > 1:
             B, C = like.shape[0], like.shape[2]
@@ -535,6 +546,12 @@ class AnchorExchange:
             st.carry = anchors
             return
         self._send(anchors.contiguous(), dst, st)
+        cid = getattr(anchors, "_vtm_cid", None)
+        if cid is not None and (cid[1] != anchors._version or tuple(cid[0].shape) != tuple(anchors.shape[:2])):
+            cid = None
+        ids = cid[0].contiguous() if cid is not None else \
+            torch.full(tuple(anchors.shape[:2]), -1, dtype=torch.int32, device=anchors.device)
+        self._send(ids, dst, st)
 
     @staticmethod
     def _has_local_levels(frames: int, args: Dict) -> bool:

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void fold_mark_kernel(const int32_t *__restric
     const int64_t id = cur[i];
     if (id < L) return;
     const int64_t c = cid[b * Ma + (id - L)];
+    if (c < 0 || c >= n_ids) return;                                      // "no id": a row of its own
     atomicMax(&firstinv[b * n_ids + c], 0xffffffffu - (uint32_t)m);      // zero-initialised: the smallest m wins
     atomicAdd(&cnt[b * n_ids + c], 1u);
 }
@@ -274,7 +275,11 @@ __global__ __launch_bounds__(256) void fold_keep_kernel(const int32_t *__restric
     bool keep = false;
     if (m < M) {
         const int64_t id = cur[b * M + m];
-        keep = id < L || firstinv[b * n_ids + cid[b * Ma + (id - L)]] == 0xffffffffu - (uint32_t)m;
+        keep = id < L;
+        if (!keep) {
+            const int64_t c = cid[b * Ma + (id - L)];
+            keep = c < 0 || c >= n_ids || firstinv[b * n_ids + c] == 0xffffffffu - (uint32_t)m;
+        }
     }
     const unsigned long long bal = __ballot(keep);
     const int lane = threadIdx.x & 63;
@@ -343,7 +348,8 @@ __global__ __launch_bounds__(CQ_THREADS) void fold_compact_kernel(const int32_t 
             key_sel[b * M + j] = (int32_t)m;
             uint32_t bias = 0u;                                           // log2(1)
             if (id >= L) {
-                const uint32_t c = cnt[b * n_ids + cid[b * Ma + (id - L)]];
+                const int64_t ci = cid[b * Ma + (id - L)];
+                const uint32_t c = (ci < 0 || ci >= n_ids) ? 1u : cnt[b * n_ids + ci];
                 if (c > 1u) bias = split16(log2f((float)c), dtype);
             }
             k_bias[b * ldkb + j] = bias;
