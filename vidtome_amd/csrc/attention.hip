@@ -28,6 +28,7 @@
 //     with v_permlane16_swap -- 8 swaps per tile, still no LDS round trip (PV16 below).
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -132,8 +133,7 @@ __device__ __forceinline__ void mask_keys(uint4 &v, int valid) {
 template <typename T, int D>
 __device__ __forceinline__ void write_output(const f32x16 (&o)[(D + 31) / 32], float l_run, T *__restrict__ out,
                                              int64_t ldo, int64_t b, int64_t h, int64_t q0, int64_t M, int64_t Mp,
-                                             int l31, int hi, int r_lo = 0, int r_hi = 16 * ((D + 31) / 32)) {
-    // [r_lo, r_hi): the accumulator registers (dv * 16 + g * 4 + e) this caller holds -- whole 4-channel groups
+                                             int l31, int hi) {
     using elem = typename Frag<T>::elem;
     constexpr int DV = (D + 31) / 32;
     constexpr bool SPARE = (D % 32) != 0;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void write_output(const f32x16 (&o)[(D + 31) / 32], f
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = dv * 32 + 8 * g + 4 * hi;
-                if (d0 < D && dv * 16 + g * 4 >= r_lo && dv * 16 + g * 4 < r_hi) {  // D % 8 == 0, d0 % 4 == 0: 4 valid channels
+                if (d0 < D) {  // D % 8 == 0 and d0 % 4 == 0 -> the 4 channels are all valid
                     elem w[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w[e] = (elem)(o[dv][g * 4 + e] * inv_l);
@@ -207,12 +207,6 @@ __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
     if (q_count != nullptr && (lin % nqb) * QB >= (int64_t)q_count[b]) return;   // its partial records were never written
-    // few items (the split tail of a mid block: 16 of them, 16 records each) leave most of the chip idle: blockIdx.y then
-    // shares an item's accumulator registers out (whole 4-channel groups; 32-row layout only), every part redoing the
-    // maxima / denominator bookkeeping
-    constexpr int LREG_ALL = (PV16 || (D % 32) == 0) ? -1 : (D / 32) * 16 + ((D % 32) & 3) + 4 * ((D % 32) >> 3);
-    const int nparts = PV16 ? 1 : (int)gridDim.y, part = PV16 ? 0 : (int)blockIdx.y;
-    const int r_lo = part * (NA / nparts), r_hi = part + 1 == nparts ? NA : r_lo + NA / nparts;
     float acc[NA], m[NM], l = 0.0f;
 #pragma unroll
     for (int r = 0; r < NA; ++r) acc[r] = 0.0f;
@@ -233,7 +227,7 @@ __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
             const int j = PV16 ? (r >> 2) & 1 : 0;   // PV16: accumulator (dv, qh, e) is register (dv * 2 + qh) * 4 + e
-            if ((r >= r_lo && r < r_hi) || r == LREG_ALL) acc[r] = acc[r] * fa[j] + pp[r * NT] * fb[j];
+            acc[r] = acc[r] * fa[j] + pp[r * NT] * fb[j];
         }
     }
     if constexpr (PV16) {
@@ -245,7 +239,65 @@ __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
         f32x16 o[DV];
 #pragma unroll
         for (int r = 0; r < NA; ++r) o[r >> 4][r & 15] = acc[r];
-        write_output<T, D>(o, l, out, ldo, b, h, q0, M, Mp, l31, hi, r_lo, r_hi);
+        write_output<T, D>(o, l, out, ldo, b, h, q0, M, Mp, l31, hi);
+    }
+}
+
+// attention_combine_kernel for FEW items (the split tail of a mid block: 16 items x 16 records leave 240 CUs idle and
+// every thread walking 16 x 50 floats): blockIdx.y shares an item's accumulator registers out in groups of 8 (= two
+// 4-channel groups of one query; 32-row O^T layout only), every part redoing the maxima / denominator bookkeeping.  Two
+// passes -- the maxima first, then every record weighted by exp2(its maximum - the overall one) -- so that no load waits
+// for arithmetic on an earlier record; the register group is addressed at run time, the 8 accumulators are static.
+template <typename T, int D>
+__global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_parts_kernel(
+    const float *__restrict__ partial, T *__restrict__ out, int64_t ldo, int64_t H, int64_t M, int64_t Mp, int64_t nqb,
+    int64_t id0, int nsplit, int xcd_groups, const int32_t *__restrict__ q_count) {
+    using elem = typename Frag<T>::elem;
+    static_assert(!pv16_for(D), "32-row O^T layout");
+    constexpr int WAVES = waves_for(D), NT = WAVES * 64, QB = WAVES * QW;
+    constexpr int NA = acc_floats(D), REC = rec_floats(D);
+    constexpr bool SPARE = (D % 32) != 0;
+    constexpr int LREG_ALL = SPARE ? (D / 32) * 16 + ((D % 32) & 3) + 4 * ((D % 32) >> 3) : 0;
+    constexpr int LHI = ((D % 32) >> 2) & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int64_t lin = item_of(id0 + blockIdx.x, nqb, xcd_groups);
+    const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
+    const int64_t q0 = (lin % nqb) * QB + wave * QW;
+    if (q_count != nullptr && (lin % nqb) * QB >= (int64_t)q_count[b]) return;
+    const int r0 = (int)blockIdx.y * 8;
+    const float *p0 = partial + (int64_t)blockIdx.x * nsplit * REC * NT + tid;
+    float m = -INFINITY;
+#pragma unroll 4
+    for (int sp = 0; sp < nsplit; ++sp) m = fmaxf(m, p0[((int64_t)sp * REC + NA) * NT]);
+    float acc[8], den = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+#pragma unroll 4
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float *pp = p0 + (int64_t)sp * REC * NT;
+        const float ms = pp[NA * NT];
+        const float w = ms == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(ms - m);   // (a split that saw no key)
+        den = __builtin_fmaf(pp[(SPARE ? LREG_ALL : NA + 1) * NT], w, den);       // the O^T denominator row / the fp32 sum
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(pp[(r0 + i) * NT], w, acc[i]);
+    }
+    const float l_tot = SPARE ? __shfl(den, l31 + 32 * LHI, 64) : den + __shfl_xor(den, 32, 64);
+    const float inv_l = 1.0f / l_tot;
+    const int64_t qi = q0 + l31;
+    if (qi < M) {
+        T *op = out + (b * Mp + qi) * ldo + h * D;
+        const int dv = r0 >> 4, g0 = (r0 & 15) >> 2;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int d0 = dv * 32 + 8 * (g0 + gi) + 4 * hi;
+            if (d0 < D) {
+                elem w4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w4[e] = (elem)(acc[gi * 4 + e] * inv_l);
+                *reinterpret_cast<uint2 *>(op + d0) = *reinterpret_cast<uint2 *>(w4);
+            }
+        }
     }
 }
 
@@ -794,11 +846,20 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
                        (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
                        scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws, xcd_groups, q_count,
                        p.split_all ? rem : (int64_t)0, k_count, k_bias, ldkb);
-    // (parts: NA / 8 register groups per item when the items alone would not fill a quarter of the chip)
-    const unsigned parts = (!pv16_for(D) && rem * 4 <= vtm::device_cus() && acc_floats(D) % 8 == 0) ? (unsigned)(acc_floats(D) / 8) : 1u;
-    if (p.nsplit > 1)
-        hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem, parts), dim3(WAVES * 64), 0, s,
-                           (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups, q_count);
+    // (few items: their accumulator groups are shared out, attention_combine_parts_kernel)
+    bool parts = !pv16_for(D) && rem * 4 <= vtm::device_cus() && acc_floats(D) % 8 == 0;
+    if (getenv("VTM_DEBUG_COMBINE_PARTS")) parts = false;   // A/B hook
+    if (p.nsplit > 1) {
+        if constexpr (!pv16_for(D)) {
+            if (parts)
+                hipLaunchKernelGGL((attention_combine_parts_kernel<T, D>), dim3((unsigned)rem, (unsigned)(acc_floats(D) / 8)),
+                                   dim3(WAVES * 64), 0, s, (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit,
+                                   xcd_groups, q_count);
+        }
+        if (!parts)
+            hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem), dim3(WAVES * 64), 0, s,
+                               (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups, q_count);
+    }
     return vtm::launch_status("vtm_attention");
 }
 
