@@ -3,7 +3,8 @@
     python tools/sweep_nsplit.py [--shuffle] [--kp] [--regime NAME]           (needs an MI355X)
 --shuffle: the src and the dst rows are handed over in a random order (what level 2 and the global level look like in a real
 pass: the merged sequence is sorted by similarity rank, a row's matches are scattered over the dst range) instead of position order;
---kp: sweep the pruning depth (VTM_DEBUG_KP) at the default split count instead."""
+--kp: sweep the pruning depth (VTM_DEBUG_KP) at the default split count instead; --seed: with the same-position seeds of the
+product path (dst index = position in the first dst frame: meaningful for the position-ordered rows only, i.e. not with --shuffle)."""
 import os
 import sys
 
@@ -54,22 +55,28 @@ def main():
             rb = (Ns + torch.stack([torch.randperm(Nd, generator=g, device="cuda") for _ in range(B)])).to(torch.int32).contiguous()
         os.environ.pop("VTM_DEBUG_NSPLIT", None)
         os.environ.pop("VTM_DEBUG_KP", None)
+        seed = None
+        if "--seed" in sys.argv:
+            Nf = 4096
+            while Ns % Nf or Nd % Nf:
+                Nf //= 2
+            seed = (Nf, Ns + Nd, None, None)
         if kp:
-            ref = _lib.match_filtered(x, None, ra, rb, False)
-            out = [f"default {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}"]
+            ref = _lib.match_filtered(x, None, ra, rb, False, seed=seed)
+            out = [f"default {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False, seed=seed)) * 1e3:.0f}"]
             for v in range(0, C // 64):
                 os.environ["VTM_DEBUG_KP"] = str(v)
-                assert torch.equal(_lib.match_filtered(x, None, ra, rb, False), ref)
-                out.append(f"kp{v}: {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}")
+                assert torch.equal(_lib.match_filtered(x, None, ra, rb, False, seed=seed), ref)
+                out.append(f"kp{v}: {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False, seed=seed)) * 1e3:.0f}")
             os.environ.pop("VTM_DEBUG_KP", None)
             print(f"{name:7s} us  " + "  ".join(out), flush=True)
             continue
-        ref = _lib.match_filtered(x, None, ra, rb, False)
-        out = [f"default {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}"]
+        ref = _lib.match_filtered(x, None, ra, rb, False, seed=seed)
+        out = [f"default {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False, seed=seed)) * 1e3:.0f}"]
         for ns in range(2, 15):
             os.environ["VTM_DEBUG_NSPLIT"] = str(ns)
-            assert torch.equal(_lib.match_filtered(x, None, ra, rb, False), ref)
-            out.append(f"{ns}: {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False)) * 1e3:.0f}")
+            assert torch.equal(_lib.match_filtered(x, None, ra, rb, False, seed=seed), ref)
+            out.append(f"{ns}: {timeit(lambda: _lib.match_filtered(x, None, ra, rb, False, seed=seed)) * 1e3:.0f}")
         print(f"{name:7s} us  " + "  ".join(out), flush=True)
 
 
