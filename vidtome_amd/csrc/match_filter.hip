@@ -1395,6 +1395,10 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
     // builds (their lo products are not covered by the hi rest norms)
     const int KT = (int)(L.C64 / FBK);
     int KP = (VTM_FILTER_PRODUCTS == 1 && KT >= 4) ? (2 * KT + 2) / 5 : 0;   // 40 % depth (profiles/r04_kp_sweep.txt)
+    if (const char *dbg5 = getenv("VTM_DEBUG_KP5")) {    // tuning hook for the C = 320 levels alone (KT = 5)
+        const int v = atoi(dbg5);
+        if (VTM_FILTER_PRODUCTS == 1 && KT == 5 && v >= 0 && v < KT) KP = v;
+    }
     if (const char *dbg = getenv("VTM_DEBUG_KP")) {      // tuning hook: 0 = off, else the step after which blocks are tested
         const int v = atoi(dbg);
         if (VTM_FILTER_PRODUCTS == 1 && v >= 0 && v < KT) KP = v;
