@@ -314,7 +314,7 @@ class KernelTimer:
         # everything else the path launches (index algebra, sort, panel writers, query compaction): time only, so that the
         # components of the line add up to the step
         for name in ("sort_desc", "partition_local", "partition_global", "plan_apply", "compose", "decode_best",
-                     "compact_queries", "fold_keys", "anchor_pos", "to_panels", "gather_panels", "geglu", "normalize_gather"):
+                     "compact_queries", "fold_keys", "anchor_pos", "anchor_maps", "transpose_cols", "to_panels", "gather_panels", "geglu", "normalize_gather"):
             if hasattr(self.lib_mod, name):
                 self.records[name] = []
                 self._wrap(name, name, lambda *a, **k: 0.0)

@@ -177,6 +177,15 @@ int vtm_partition_global(const int32_t *cur_local, int64_t B, int64_t Ml, int64_
 int vtm_anchor_pos(const int32_t *amap, int64_t B, int64_t M, int64_t L, int64_t tokens, const int32_t *old_pos,
                    int64_t Mg, int32_t *out, vtm_stream_t stream);
 
+/* vtm_anchor_maps -- the maps behind a global level in one launch (they are vtm_compose x 2 + vtm_anchor_pos):
+ * loc (B, Ml) = merged position of every local token = inv_g[off + t] (merge.py:459: the local slice of the level's unmerge
+ * map inv_g (B, N_in)); amap (B, Ml) = new_cur[loc] = the pool row each token of u(merged) is a copy of (patch.py:80 as one
+ * gather from [chunk of L rows | old anchors]); pos (B, Ml), optional = the token position of that row (row % tokens for
+ * chunk rows, old_pos (B, Mg) for anchor rows, -1 unknown). */
+int vtm_anchor_maps(const int32_t *inv_g, int64_t N_in, int64_t off, const int32_t *new_cur, int64_t M, int64_t B,
+                    int64_t Ml, int64_t L, int64_t tokens, const int32_t *old_pos, int64_t Mg, int32_t *loc, int32_t *amap,
+                    int32_t *pos, vtm_stream_t stream);
+
 /* vtm_plan_apply -- the index split after the sort (merge.py:100-117 / 404-421) and the bookkeeping
  * of the merge / unmerge closures (merge.py:119-155 / 423-460) as composed maps:
  *   unm_idx = perm[r:], src_idx = perm[:r], dst_idx = node_idx[src_idx] (% Nd when align);

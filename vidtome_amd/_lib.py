@@ -61,6 +61,7 @@ _SIGNATURES = {
     "vtm_attention_kv_bounded": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _f32, _vp, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_attention_kv_bounded_ws_bytes": ([_i64, _i64, _i64, _i64, _i64], ctypes.c_size_t),
+    "vtm_anchor_maps": ([_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp], _int),
     "vtm_transpose_cols": ([_vp, _i64, _int, _i64, _i64, _i64, _vp, _i64, _vp], _int),
     "vtm_fold_keys_ws_bytes": ([_i64, _i64, _i64], ctypes.c_size_t),
     "vtm_fold_keys": ([_vp, _i64, _i64, _i64, _vp, _i64, _i64, _int, _vp, ctypes.c_size_t, _vp, _vp, _i64, _vp, _vp], _int),
@@ -291,6 +292,22 @@ def anchor_pos(amap: Optional[torch.Tensor], B: int, M: int, L: int, tokens: int
     Mg = 0 if old_pos is None else old_pos.shape[1]
     _check(lib().vtm_anchor_pos(_ptr(amap), B, M, L, tokens, _ptr(old_pos), Mg, _ptr(out), _stream()), "vtm_anchor_pos")
     return out
+
+
+@_on_device
+def anchor_maps(inv_g: torch.Tensor, off: int, new_cur: torch.Tensor, Ml: int, L: int, tokens: int,
+                old_pos: Optional[torch.Tensor], want_pos: bool) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """(loc, amap, pos) behind a global level: merged position of every local token, pool row of every new anchor, and
+    (``want_pos``) its token position; see include/vidtome_hip.h."""
+    _req(inv_g, "inv_g"), _req(new_cur, "new_cur")
+    B, N_in = inv_g.shape
+    i32 = dict(dtype=torch.int32, device=inv_g.device)
+    loc, amap = torch.empty((B, Ml), **i32), torch.empty((B, Ml), **i32)
+    pos = torch.empty((B, Ml), **i32) if want_pos else None
+    Mg = 0 if old_pos is None else old_pos.shape[1]
+    _check(lib().vtm_anchor_maps(_ptr(inv_g), N_in, off, _ptr(new_cur), new_cur.shape[1], B, Ml, L, tokens if want_pos else 0,
+                                 _ptr(old_pos), Mg, _ptr(loc), _ptr(amap), _ptr(pos), _stream()), "vtm_anchor_maps")
+    return loc, amap, pos
 
 
 @_on_device

@@ -96,6 +96,30 @@ __global__ __launch_bounds__(256) void anchor_pos_kernel(const int32_t *__restri
     out[idx] = pos;
 }
 
+// The three maps patch.py:80 needs behind a global level, in one launch (they were vtm_compose x 2 + vtm_anchor_pos):
+//   loc[t]  = inv_g[off + t]      merged position of local token t (merge.py:459: the local part of the level's unmerge map)
+//   amap[t] = new_cur[loc[t]]     pool row the new anchor t is a copy of   (u(merged) as ONE gather from [chunk | old anchors])
+//   pos[t]  = token position of that row (the matcher's seeds), optional
+__global__ __launch_bounds__(256) void anchor_maps_kernel(const int32_t *__restrict__ inv_g, int64_t N_in, int64_t off,
+                                                          const int32_t *__restrict__ new_cur, int64_t M, int64_t B, int64_t Ml,
+                                                          int64_t L, int64_t tokens, const int32_t *__restrict__ old_pos,
+                                                          int64_t Mg, int32_t *__restrict__ loc, int32_t *__restrict__ amap,
+                                                          int32_t *__restrict__ pos) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Ml) return;
+    const int64_t b = idx / Ml, t = idx % Ml;
+    const int32_t p = inv_g[b * N_in + off + t];
+    const int64_t row = new_cur[b * M + p];
+    loc[idx] = p;
+    amap[idx] = (int32_t)row;
+    if (pos != nullptr) {
+        int32_t q = -1;
+        if (row < L) q = (int32_t)(row % tokens);
+        else if (old_pos != nullptr && row - L < Mg) q = old_pos[b * Mg + (row - L)];
+        pos[idx] = q;
+    }
+}
+
 // merge.py:100-117 (index split) + 119-155 (closure bookkeeping as maps).
 // One thread per sorted rank e in [0, Ns) and one per dst index j in [0, Nd).
 __global__ __launch_bounds__(256) void plan_apply_kernel(
@@ -470,6 +494,17 @@ VTM_EXPORT int vtm_anchor_pos(const int32_t *amap, int64_t B, int64_t M, int64_t
     hipLaunchKernelGGL(anchor_pos_kernel, dim3(blocks_for(B * M)), dim3(256), 0, vtm::as_stream(stream), amap, B, M, L, tokens,
                        old_pos, Mg, out);
     return vtm::launch_status("vtm_anchor_pos");
+}
+
+VTM_EXPORT int vtm_anchor_maps(const int32_t *inv_g, int64_t N_in, int64_t off, const int32_t *new_cur, int64_t M, int64_t B,
+                               int64_t Ml, int64_t L, int64_t tokens, const int32_t *old_pos, int64_t Mg, int32_t *loc,
+                               int32_t *amap, int32_t *pos, vtm_stream_t stream) {
+    VTM_REQUIRE(inv_g && new_cur && loc && amap, "vtm_anchor_maps: null pointer");
+    VTM_REQUIRE(B > 0 && Ml > 0 && M > 0 && off >= 0 && off + Ml <= N_in && L >= 0 && (pos == nullptr || tokens > 0),
+                "vtm_anchor_maps: bad sizes");
+    hipLaunchKernelGGL(anchor_maps_kernel, dim3(blocks_for(B * Ml)), dim3(256), 0, vtm::as_stream(stream), inv_g, N_in, off, new_cur,
+                       M, B, Ml, L, tokens, old_pos, Mg, loc, amap, pos);
+    return vtm::launch_status("vtm_anchor_maps");
 }
 
 VTM_EXPORT int vtm_plan_apply(const uint64_t *best, const int32_t *perm, const int32_t *a_pos,

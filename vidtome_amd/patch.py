@@ -202,12 +202,11 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 plan.global_level, plan.local_chunk = gl, (0 if local_is_src else 1)
                 plan.anchors_in = gt
                 off = 0 if local_is_src else gt.shape[1]                           # merge.py:459
-                loc = _lib.compose(None, gl.inv, Ml, off)      # local position -> merged position
-                # patch.py:80: new anchors = u(merged) = the local tokens with every merged local src row
-                # replaced by its matched global row -> one gather from [chunk | old anchors]
-                amap = _lib.compose(loc, gl.new_cur, Ml)
+                # loc: local position -> merged position.  patch.py:80: new anchors = u(merged) = the local tokens with every
+                # merged local src row replaced by its matched global row -> one gather (amap) from [chunk | old anchors];
+                # their token positions ride along for the next chunk's seeds
+                loc, amap, anchors_pos = _lib.anchor_maps(gl.inv, off, gl.new_cur, Ml, L, tsize, gt_pos, _lib.SEED_MATCHER)
                 anchors_out = _lib.gather_rows(xj, gt, amap)
-                anchors_pos = _lib.anchor_pos(amap, B, Ml, L, tsize, gt_pos, xj.device) if _lib.SEED_MATCHER else None
                 anchors_cid = None
                 if gt_cid is not None and _lib.FOLD_KEYS and gl.new_cur.shape[1] <= 131072:
                     plan.fold_args = (gl.new_cur, L, gt_cid, gt.shape[1])
