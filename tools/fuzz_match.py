@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised check that vtm_match_filtered equals the exact fp32 matcher bit for bit, over random shapes, dtypes,
-data regimes (iid, frame-correlated, duplicated rows, scaled), aligned / non-aligned batches.
+data regimes (iid, frame-correlated, duplicated rows, scaled), aligned / non-aligned batches -- unseeded, and with a random
+SEED description (vtm_match_filtered_seeded: frame length, pool split, position tables with valid, random, missing and
+out-of-range entries; the guesses may be anything, the result may not change).
 
     python tools/fuzz_match.py [--cases 300] [--seed 0]
 """
@@ -49,6 +51,27 @@ def run(cases: int, seed: int, verbose: bool = True) -> int:
         exact = L.match(a_op, b_op, Ns, Nd, align)
         got, flag = L.match_filtered(x, None, ra, rb, align, want_flag=True)
         ok = bool(torch.equal(got, exact))
+        # a random seed description: frames of Nf tokens, rows below `seed_L` are (frame, position) rows, the rest carry a
+        # position in pos1 (two-part pools only), the table maps a position to any dst index or to nothing
+        Nf = ri(1, max(1, min(Ns, Nd)))
+        kind = ri(0, 3)
+        table = None
+        if kind == 1:
+            table = torch.randint(0, Nd, (B, Nf), generator=g, dtype=torch.int32).to(dev)
+        elif kind >= 2:
+            table = torch.randint(-5, Nd + 20, (B, Nf), generator=g, dtype=torch.int32).to(dev)
+        seed_L = ri(0, Ns + Nd) if kind == 3 else Ns + Nd
+        split = ri(0, 1) == 1 and Ns + Nd > 1
+        if split:      # pool = x0 | x1 with positions for the x1 rows
+            P0 = ri(1, Ns + Nd - 1)
+            x0, x1 = x[:, :P0].contiguous(), x[:, P0:].contiguous()
+            pos1 = torch.randint(-2, Nf + 3, (B, Ns + Nd - P0), generator=g, dtype=torch.int32).to(dev)
+            sgot = L.match_filtered(x0, x1, ra, rb, align, seed=(Nf, min(seed_L, P0), pos1, table))
+        else:
+            sgot = L.match_filtered(x, None, ra, rb, align, seed=(Nf, seed_L, None, table))
+        if not torch.equal(sgot, exact):
+            ok = False
+            print("SEEDED MISMATCH", dict(Nf=Nf, kind=kind, seed_L=seed_L, split=split, bad=int((sgot != exact).sum())))
         if not ok:
             fails += 1
             print("MISMATCH", dict(case=case, B=B, C=C, Ns=Ns, Nd=Nd, dtype=str(dtype), align=align, regime=regime,
