@@ -33,8 +33,10 @@ def main():
             b_op, _ = L.normalize_gather(x, None, rb)
             exact = L.match(a_op, b_op, Ns, Nd, False)
             diff = 0
-            for _ in range(a.reps):
-                diff += int(not torch.equal(L.match_filtered(x, None, ra, rb, False), exact))
+            Nf = Nd                        # every src row r has its near copy at dst index r % Nd: the seeds of the product path
+            for rep in range(a.reps):      # (odd repetitions seeded, even ones not: both must give the exact result)
+                seed = (Nf, Ns + Nd, None, None) if rep % 2 else None
+                diff += int(not torch.equal(L.match_filtered(x, None, ra, rb, False, seed=seed), exact))
             bad += diff
             print(f"B={B} Ns={Ns} Nd={Nd} C={C} {regime}: {a.reps} runs, {diff} differ from the exact matcher", flush=True)
     print("FAIL" if bad else "OK")
