@@ -57,6 +57,28 @@ FP16_PEAK_TFLOPS = 2500.0         # dense fp16/bf16 MFMA peak (not the 2:1-spars
 HBM_PEAK_GBPS = 8000.0            # HBM3E spec (~6300 achievable, MI355X_MICROARCH.md)
 BATCH, FRAMES, LATENT = 2, 16, (64, 64)
 LOCAL_RATIO, GLOBAL_RATIO = 0.5, 0.5
+# BASELINE.json's single-GPU configurations.  cfg2 is the one the metric is quoted on (the headline);
+# `--workload cfg3 | cfg5` are secondary lines with the same kernel split.  cfg-1 is the reference's CPU plumbing case and
+# cfg-4 is the 8-GPU case (`--frames 8` gives one of its chunks): parity-test cases, not bench lines.
+WORKLOADS = {
+    "cfg2": dict(sites="sd15", batch=2, frames=16, latent=(64, 64), local=0.5, glob=0.5, align=False, pnp=False,
+                 label="SD-1.5 16 frames 512x512 (cfg-2)"),
+    "cfg3": dict(sites="sd15", batch=3, frames=16, latent=(64, 64), local=0.5, glob=0.5, align=True, pnp=True,
+                 label="SD-1.5 + PnP injection, 16 frames 512x512, batch 3 [source | uncond | cond], align_batch, shared attention "
+                       "probabilities at the 8 decoder sites of pnp_utils.py:98-105 (cfg-3; the 7 un-patched ControlNet blocks are "
+                       "not on the path)"),
+    "cfg5": dict(sites="sd21", batch=2, frames=16, latent=(96, 96), local=0.6, glob=0.6, align=False, pnp=False,
+                 label="SD-2.1-768 16 frames 768x768, head dim 64, merge ratio 0.6 (cfg-5)"),
+}
+HEADLINE_REGIME = "corr01"        # SURVEY.md 8d names N(0,1) and base + 0.1 N(0,1); the harder of the two is the headline
+REGIME_NOTES = {
+    "n01": "h ~ N(0,1), frames uncorrelated (SURVEY 8d)",
+    "corr01": "h[f] = base + 0.1 N(0,1) (SURVEY 8d: realistic cross-frame cosine)",
+    "corr002": "h[f] = base + 0.02 N(0,1) (static shot: cross-frame cosine ~0.9996)",
+    "corr05": "h[f] = base + 0.5 N(0,1) (the headline regime of rounds 1-4)",
+    "smooth": "spatially low-passed field drifting sub-pixel per frame + 0.05 N(0,1)",
+    "flat25": "corr05 + a flat region over a quarter of every frame (candidate-list overflow -> exact escape)",
+    "dup": "corr05 + a fifth of the positions exact copies of others"}
 
 
 def parse():
@@ -88,10 +110,21 @@ def parse():
                          "(patch.py:171-199)")
     ap.add_argument("--same-chunk", action="store_true",
                     help="rounds 1-2's regime: every pass processes the same chunk (anchors = copies of its own rows)")
-    ap.add_argument("--data", default="corr05", choices=["n01", "corr01", "corr05", "flat25", "dup"],
-                    help="synthetic token regime (vidtome_amd/sites.DATA_REGIMES): n01 = N(0,1) and corr01 = base + 0.1 N(0,1) "
-                         "are the two SURVEY.md 8d names; corr05 = base + 0.5 N(0,1) (default: what rounds 1-3 measured); "
-                         "flat25 / dup load the matcher's candidate logic (profiles/r04_data_regimes.txt)")
+    ap.add_argument("--data", default=HEADLINE_REGIME, choices=sorted(REGIME_NOTES),
+                    help="synthetic token regime of the headline (vidtome_amd/sites.DATA_REGIMES): n01 = N(0,1) and corr01 = base + "
+                         "0.1 N(0,1) are the two SURVEY.md 8d names (corr01, the harder one, is the default); corr05 = base + 0.5 "
+                         "N(0,1) is what rounds 1-4 quoted; corr002 / smooth = static / smooth content; flat25 / dup load the "
+                         "matcher's candidate logic")
+    ap.add_argument("--regimes", default="all",
+                    help="N = 1: the other token regimes measured after the headline and reported under `regimes` "
+                         "(comma-separated names, `all`, or `none`)")
+    ap.add_argument("--regime-steps", type=int, default=10, help="timed passes per secondary regime")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
+                    help="cfg2 = the headline configuration; cfg3 / cfg5 = secondary lines (BASELINE.json configs[2] / [4])")
+    ap.add_argument("--exchange-modes", default="all",
+                    help="N > 1: after the headline's exchange mode, time the other modes too and report them under "
+                         "`exchange_modes` (comma-separated, `all`, or `none`); a mode that makes no progress is reported as such "
+                         "and the headline line is still printed")
     ap.add_argument("--watchdog-seconds", type=float, default=120.0,
                     help="N > 1: a rank that makes no progress for this long prints where it is stuck (pass, block, exchange "
                          "phase, peer) and exits with code 3 (0 = off)")
@@ -202,6 +235,8 @@ class Watchdog(threading.Thread):
         self.rank, self.limit, self.where = rank, limit_s, where
         self.last = time.monotonic()
         self.label = "start-up"
+        self.phase = None              # set while the SECONDARY exchange modes run
+        self.fallback = None           # ... together with what to do instead of failing (rank 0: print the headline line)
         self._halt = threading.Event()
 
     def tick(self, label: str) -> None:
@@ -214,6 +249,11 @@ class Watchdog(threading.Thread):
                 sys.stderr.write(f"bench.py watchdog: rank {self.rank} made no progress for {idle:.0f} s after '{self.label}'; "
                                  f"exchange state: {self.where()}\n")
                 sys.stderr.flush()
+                if self.fallback is not None:      # a secondary exchange mode hung: the headline was measured, keep it
+                    sys.stderr.write(f"bench.py watchdog: exchange mode '{self.phase}' abandoned, headline line kept\n")
+                    sys.stderr.flush()
+                    self.fallback()
+                    os._exit(0)
                 os._exit(3)
 
     def stop(self):
@@ -292,7 +332,7 @@ class KernelTimer:
             if not self.count or want_flag:
                 return timed_match(x0, x1, ar, br, align, want_flag, seed=seed)
             best, flag = timed_match(x0, x1, ar, br, align, True, seed=seed)
-            self.match_flags.append((flag, ar.shape[1] if align else x0.shape[0] * ar.shape[1]))
+            self.match_flags.append((flag, ar.shape[1] if align else x0.shape[0] * ar.shape[1], x0.shape[2]))
             return best
         self.lib_mod.match_filtered = match_with_counters
         self._wrap("match", "matching", lambda a, b, Ns, Nd, align: 2.0 * a.shape[0] * Ns * Nd * a.shape[1] * 8)
@@ -339,11 +379,30 @@ class KernelTimer:
         """(refined pairs per src row, escaped rows, whole-call escapes, src rows) of the counter pass."""
         if not getattr(self, "match_flags", None):
             return None
-        f = torch.stack([fl for fl, _ in self.match_flags]).cpu().long()
-        rows = sum(r for _, r in self.match_flags)
-        return {"refined_pairs_per_src_row": round(float(f[:, 3].sum()) / rows, 3),
-                "escaped_rows": int(f[:, 2].sum()), "escaped_row_fraction": round(float(f[:, 2].sum()) / rows, 5),
-                "whole_call_escapes": int(f[:, 0].sum()), "calls": len(self.match_flags)}
+        f = torch.stack([fl for fl, _, _ in self.match_flags]).cpu().long()
+        rows = sum(r for _, r, _ in self.match_flags)
+        out = {"refined_pairs_per_src_row": round(float(f[:, 3].sum()) / rows, 3),
+               "escaped_rows": int(f[:, 2].sum()), "escaped_row_fraction": round(float(f[:, 2].sum()) / rows, 5),
+               "whole_call_escapes": int(f[:, 0].sum()), "calls": len(self.match_flags)}
+        # partial-sum pruning of filter_kernel: flags[4] = 32 x 32 score blocks tested after KP of the KT 64-channel steps of
+        # their dst tile, flags[5] = blocks still alive after the test (the others skip their remaining MFMAs).  Calls whose
+        # rows are too short to prune (KT < 4) test nothing and execute everything.
+        tested, alive, mfma_all, mfma_done = 0, 0, 0.0, 0.0
+        for (fl, _, C), fr in zip(self.match_flags, f):
+            KT = (C + 63) // 64
+            KP = (2 * KT + 2) // 5 if KT >= 4 else 0
+            t, a = int(fr[4]), int(fr[5])
+            tested, alive = tested + t, alive + a
+            if t > 0 and 0 < KP < KT:
+                mfma_all += t * KT
+                mfma_done += t * KP + a * (KT - KP)
+        if tested > 0:
+            out["blocks_tested"] = tested
+            out["pruned_block_fraction"] = round(1.0 - alive / tested, 4)
+            out["executed_mfma_fraction"] = round(mfma_done / mfma_all, 4) if mfma_all else None
+            out["pruning_note"] = ("32 x 32 score blocks of the calls that prune (C >= 256): fraction whose remaining MFMAs were "
+                                   "skipped at the test depth, and the fraction of the nominal MFMA work executed")
+        return out
 
     def ms_by_kind(self):
         """{kind: total HIP-event ms} of every wrapped launch kind that ran."""
@@ -518,11 +577,16 @@ def cpu_baseline_torch(budget_s: float):
             "seconds_per_step": round(r["seconds_per_step"], 2), "detail": r["detail"]}
 
 
+PNP_SITES = ("up1.1", "up1.2", "up2.0", "up2.1", "up2.2", "up3.0", "up3.1", "up3.2")   # pnp_utils.py:98-105
+
+
 def main():
-    global FRAMES
+    global FRAMES, BATCH, LATENT, LOCAL_RATIO, GLOBAL_RATIO
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    wl = WORKLOADS[args.workload]
+    BATCH, LATENT, LOCAL_RATIO, GLOBAL_RATIO = wl["batch"], wl["latent"], wl["local"], wl["glob"]
     FRAMES = args.frames
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -550,52 +614,30 @@ def main():
     import vidtome_amd
     from vidtome_amd import _lib, sites
 
-    unet = sites.SiteUNet(sites.sd15_sites(), seed=0, full=args.full_block).to(device=dev, dtype=torch.float16)
+    site_list = sites.sd15_sites() if wl["sites"] == "sd15" else sites.sd21_sites()
+    unet = sites.SiteUNet(site_list, seed=0, full=args.full_block).to(device=dev, dtype=torch.float16)
     vidtome_amd.apply_patch(unet, local_merge_ratio=LOCAL_RATIO, merge_global=not args.local_only,
-                            global_merge_ratio=GLOBAL_RATIO, batch_size=BATCH, target_stride=4, global_rand=0.5)
+                            global_merge_ratio=GLOBAL_RATIO, batch_size=BATCH, target_stride=4, global_rand=0.5,
+                            align_batch=wl["align"])
     unet.set_size(LATENT)
-    total_passes = 1 + args.warmup + args.steps
+    if wl["pnp"]:      # what pnp.register_attention_control + register_time leave on the decoder blocks at an injection timestep
+        for blk, s_ in zip(unet.blocks, site_list):
+            if s_.name in PNP_SITES:
+                blk.attn1.injection_schedule, blk.attn1.t, blk.attn1.vtm_num_inputs = [981], 981, BATCH
+    merged_sites = sum(1 for s_ in site_list if s_.downsample <= 2)
     torch.manual_seed(123)           # the block generators fork this state (default.yaml seed)
-    ex = None
     mode = args.exchange or ("neighbour" if world > 1 else None)
-    if mode is not None and not args.local_only:
-        # every rank owns one chunk per pass; per merging block the global level takes its anchor tokens from the
-        # previous rank's chunk over RCCL / xGMI (chunk_parallel.py).  The whole run is ONE stream of chunks
-        # (chunk index = pass * world + rank), so the exchange knows which chunk is the last and leaves no send unmatched.
-        from vidtome_amd import chunk_parallel as cp
-        ex = cp.AnchorExchange(mode, transport=None if world > 1 else cp.LocalTransport.fabric(1)[0])
-        cp.enable(unet, ex)
-        ex.begin_step([FRAMES] * (total_passes * world))
-    # The run is one stream of chunks of ONE synthetic clip (sites.ClipStream): chunk c = pass * world + rank holds frame
-    # set c % K, so the anchor tokens a chunk merges against always come from a different chunk, at every N.
-    # N = 1 (no exchange): the reference's chained anchors, re-seeded every chunks_per_step - 1 passes with what the first
-    # chunk of a denoising step would have stored (generate.py:233-236 resets the anchors after every step).
-    # With an exchange the anchors are whatever the exchange mode defines (neighbour / all-gather: the previous chunk's
-    # local tokens, i.e. always a chain of length 1; ring: the exact chain, unbounded over the run).
-    site_list = sites.sd15_sites()
+    if args.local_only:
+        mode = None
     K = 1 if args.same_chunk else max(2, args.chunks)
-    stream = sites.ClipStream(unet, site_list, BATCH, FRAMES, LATENT, torch.float16, dev, n_sets=args.chunks,
-                              chunks_per_step=args.chunks_per_step, same_chunk=args.same_chunk, rank=rank,
-                              reseed=ex is None, regime=args.data,
-                              sets=None if ex is None else {(p_ * world + rank) % K for p_ in range(total_passes)},
-                              cond=(torch.randn(BATCH * FRAMES, 77, 768, generator=torch.Generator().manual_seed(77))
-                                    .to(device=dev, dtype=torch.float16) if args.full_block else None))
-    passes = [0]
+    cond = (torch.randn(BATCH * FRAMES, 77, 768, generator=torch.Generator().manual_seed(77))
+            .to(device=dev, dtype=torch.float16) if args.full_block else None)
+    every = max(1, args.event_every)
+    transport = [None]               # the N > 1 transport (per-edge communicators) is created once and shared by the modes
     dog = None
     if world > 1 and args.watchdog_seconds > 0:
-        dog = Watchdog(rank, args.watchdog_seconds, (lambda: ex.where) if ex is not None else (lambda: "no exchange"))
+        dog = Watchdog(rank, args.watchdog_seconds, lambda: "no exchange")
         dog.start()
-
-    def step():
-        c = passes[0] * world + rank
-        passes[0] += 1
-        if dog is not None:
-            dog.tick(f"pass {passes[0] - 1} started (chunk {c})")
-        if ex is None:
-            return stream.step(c)
-        ex.begin_chunk(c)
-        with torch.no_grad():
-            return stream._run(stream.sets[c % K])
 
     def fence():
         torch.cuda.synchronize()
@@ -603,54 +645,122 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if ex is None:
-        stream.populate()             # untimed: the first chunk(s) of a step fill the anchor tokens (steady state)
-    else:
-        step()                        # chunk 0 of the stream has no predecessor: it only publishes its tokens
-    for _ in range(args.warmup):
-        step()
-    every = max(1, args.event_every)
-    sampler = BoxSampler(local_rank) if rank == 0 else None
-    with KernelTimer(_lib) as mt:
-        fence()
-        if sampler is not None:
-            sampler.start()
-        t0 = time.perf_counter()
-        pass_events = []
-        for i in range(args.steps):
-            mt.enabled = i % every == 0           # HIP events on every k-th pass only
-            if mt.enabled:                        # ... bracketed as a whole too: what the itemised kernels leave is gaps
-                pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                pe0.record()
+    def run_region(regime, steps, warmup, xmode, with_box):
+        """One measured region: a fresh chunk stream of `regime`, anchors populated, `warmup` untimed and `steps` timed passes
+        between two fences (barrier + synchronize), HIP events on every `every`-th pass, one extra untimed pass for the
+        matcher's device-side counters.  Returns everything the line is built from."""
+        total_passes = 1 + warmup + steps
+        for b in unet.blocks:                       # a region starts like a denoising step: no anchors
+            b.global_tokens = None
+        ex = None
+        if xmode is not None:
+            # every rank owns one chunk per pass; per merging block the global level takes its anchor tokens from the
+            # previous rank's chunk over RCCL / xGMI (chunk_parallel.py).  The whole region is ONE stream of chunks
+            # (chunk index = pass * world + rank), so the exchange knows which chunk is the last and leaves no send unmatched.
+            from vidtome_amd import chunk_parallel as cp
+            if transport[0] is None:
+                transport[0] = cp.DistTransport() if world > 1 else cp.LocalTransport.fabric(1)[0]
+            ex = cp.AnchorExchange(xmode, transport=transport[0])
+            cp.enable(unet, ex)
+            ex.begin_step([FRAMES] * (total_passes * world))
+            if dog is not None:
+                dog.where = lambda: ex.where
+        # The region is one stream of chunks of ONE synthetic clip (sites.ClipStream): chunk c = pass * world + rank holds
+        # frame set c % K, so the anchor tokens a chunk merges against always come from a different chunk, at every N.
+        # N = 1 (no exchange): the reference's chained anchors, re-seeded every chunks_per_step - 1 passes with what the first
+        # chunk of a denoising step would have stored (generate.py:233-236 resets the anchors after every step).
+        # With an exchange the anchors are whatever the exchange mode defines (neighbour / all-gather: the previous chunk's
+        # local tokens, i.e. always a chain of length 1; ring: the exact chain, unbounded over the run).
+        stream = sites.ClipStream(unet, site_list, BATCH, FRAMES, LATENT, torch.float16, dev, n_sets=args.chunks,
+                                  chunks_per_step=args.chunks_per_step, same_chunk=args.same_chunk, rank=rank,
+                                  reseed=ex is None, regime=regime, gen_device=dev,
+                                  sets=None if ex is None else {(p_ * world + rank) % K for p_ in range(total_passes)},
+                                  cond=cond)
+        passes = [0]
+
+        def step():
+            c = passes[0] * world + rank
+            passes[0] += 1
+            if dog is not None:
+                dog.tick(f"{regime} / {xmode}: pass {passes[0] - 1} started (chunk {c})")
+            if ex is None:
+                return stream.step(c)
+            ex.begin_chunk(c)
+            with torch.no_grad():
+                return stream._run(stream.sets[c % K])
+
+        if ex is None:
+            stream.populate()             # untimed: the first chunk(s) of a step fill the anchor tokens (steady state)
+        else:
+            step()                        # chunk 0 of the stream has no predecessor: it only publishes its tokens
+        for _ in range(warmup):
             step()
-            if mt.enabled:
-                pe1.record()
-                pass_events.append((pe0, pe1))
-        mt.enabled = False
-        fence()
-        dt = time.perf_counter() - t0
-        event_pass_ms = sum(a.elapsed_time(b) for a, b in pass_events) / max(1, len(pass_events))
-        if ex is None:                            # one untimed pass for the matcher's counters (N = 1: the chunk stream
-            mt.count = True                       # of an exchange has no spare chunk)
-            step()
-            mt.count = False
-            torch.cuda.synchronize()
-    box = sampler.stop() if sampler is not None else None
-    if dog is not None:
-        dog.tick("timed region done")
-    if ex is not None:
-        ex.end_step()
-    # (gloo -- the test hook -- moves host tensors)
-    mine = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    per_rank = [mine.clone() for _ in range(world)]
-    if world > 1:
-        dist.all_gather(per_rank, mine)
-    per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in per_rank]
-    dt = max(float(t.item()) for t in per_rank)      # MAX over ranks
-    timed_passes = len(range(0, args.steps, every))
+        sampler = BoxSampler(local_rank) if (rank == 0 and with_box) else None
+        with KernelTimer(_lib) as mt:
+            fence()
+            if sampler is not None:
+                sampler.start()
+            t0 = time.perf_counter()
+            pass_events = []
+            for i in range(steps):
+                mt.enabled = i % every == 0           # HIP events on every k-th pass only
+                if mt.enabled:                        # ... bracketed as a whole too: what the itemised kernels leave is gaps
+                    pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    pe0.record()
+                step()
+                if mt.enabled:
+                    pe1.record()
+                    pass_events.append((pe0, pe1))
+            mt.enabled = False
+            fence()
+            dt = time.perf_counter() - t0
+            event_pass_ms = sum(a.elapsed_time(b) for a, b in pass_events) / max(1, len(pass_events))
+            if ex is None:                            # one untimed pass for the matcher's counters (N = 1: the chunk stream
+                mt.count = True                       # of an exchange has no spare chunk)
+                step()
+                mt.count = False
+                torch.cuda.synchronize()
+        box = sampler.stop() if sampler is not None else None
+        if dog is not None:
+            dog.tick(f"{regime} / {xmode}: timed region done")
+        if ex is not None:
+            ex.end_step()
+            from vidtome_amd import chunk_parallel as cp
+            cp.disable(unet)
+        # (gloo -- the test hook -- moves host tensors)
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        per_rank = [mine.clone() for _ in range(world)]
+        if world > 1:
+            dist.all_gather(per_rank, mine)
+        return {"dt": max(float(t.item()) for t in per_rank),        # MAX over ranks
+                "per_rank_ms": [round(float(t.item()) / steps * 1e3, 3) for t in per_rank],
+                "mt": mt, "event_pass_ms": event_pass_ms, "box": box, "steps": steps,
+                "timed_passes": len(range(0, steps, every)), "total_passes": total_passes,
+                "exchange": None if ex is None else
+                {"sent": int(ex.bytes_sent / max(1, total_passes)), "received": int(ex.bytes_received / max(1, total_passes)),
+                 "note": "this rank, averaged over all passes (N = 1: handed over in place, nothing crosses a link)"}}
+
+    def compact(r):
+        """The per-regime entry of `regimes`: step time, the two big components, what is left, and the matcher's counters."""
+        mt, tp = r["mt"], r["timed_passes"]
+        comp = mt.ms_by_kind()
+        att, mat = comp.get("attention", 0.0) / tp, comp.get("matching", 0.0) / tp
+        cnt = mt.match_counters() or {}
+        return {"ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "steps_per_s": round(world * r["steps"] / r["dt"], 3),
+                "steps": r["steps"], "attention_ms": round(att, 3), "matching_ms": round(mat, 3),
+                "other_launches_ms": round(sum(comp.values()) / tp - att - mat, 3),
+                "pairs_per_row": cnt.get("refined_pairs_per_src_row"), "escaped": cnt.get("escaped_rows"),
+                "escaped_row_fraction": cnt.get("escaped_row_fraction"), "whole_call_escapes": cnt.get("whole_call_escapes"),
+                "pruned_block_fraction": cnt.get("pruned_block_fraction"),
+                "executed_mfma_fraction": cnt.get("executed_mfma_fraction")}
+
+    head = run_region(args.data, args.steps, args.warmup, mode, True)
+    mt, dt, box = head["mt"], head["dt"], head["box"]
+    timed_passes, total_passes, event_pass_ms = head["timed_passes"], head["total_passes"], head["event_pass_ms"]
     aflops, ams, an = mt.summary("attention")
     top_flops, top_ms, top_n = mt.largest("attention")
     mflops, mms, mn = mt.summary("matching")
+    line = None
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -686,16 +796,19 @@ def main():
         # gaps and host time
         comp = {k: round(v / timed_passes, 3) for k, v in sorted(mt.ms_by_kind().items(), key=lambda kv: -kv[1])}
         comp_sum = sum(comp.values())
+        side = comp_sum - comp.get("attention", 0.0) - comp.get("matching", 0.0)
 
         par = f"chunk-parallel x{world}"
-        if ex is not None:
+        if mode is not None:
             par += {"neighbour": ", anchor tokens = the previous rank's local merged tokens, point-to-point over RCCL/xGMI "
                                  "per merging block",
-                    "allgather": ", RCCL all-gather of the anchor tokens per merging block",
+                    "allgather": ", RCCL all-gather of the composed merge maps per merging block, tokens point-to-point",
                     "ring": ", exact serial anchor chain (ring hand-off over RCCL/xGMI)"}[mode]
+        headline = args.workload == "cfg2" and FRAMES == 16 and not args.full_block and not args.local_only
         line = {
             "metric": "denoising steps/sec, 16-frame 512x512 SD-1.5 chunk, ratio=0.5" +
-                      (" -- FULL transformer blocks (secondary measurement, not the headline)" if args.full_block else ""),
+                      (" -- FULL transformer blocks (secondary measurement, not the headline)" if args.full_block else "") +
+                      ("" if args.workload == "cfg2" else f" -- SECONDARY workload {args.workload} (not the headline configuration)"),
             "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
@@ -703,7 +816,7 @@ def main():
             "ranks": dist.get_world_size() if world > 1 else 1,
             "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
             "launcher": os.environ.get("VIDTOME_BENCH_LAUNCHER", "torchrun/env" if "WORLD_SIZE" in os.environ else "single process"),
-            "per_rank_ms_per_step": per_rank_ms,
+            "per_rank_ms_per_step": head["per_rank_ms"],
             "box": box,
             # the arithmetic types of the path: tokens fp16; matching = fp16-MFMA candidate filter + fp32 exact
             # refinement (result bit-identical to an all-fp32 matcher); attention = fp16 MFMA, fp32 accumulate / softmax
@@ -711,34 +824,29 @@ def main():
                      "with f32 accumulate" if filtered else
                      "f16 tokens; matching f32 MFMA (exact); attention f16 MFMA with f32 accumulate",
             "data": "synthetic",
-            "config": {"workload": ("SD-1.5 16 frames 512x512 (cfg-2)" if FRAMES == 16 else
+            "config": {"workload": (wl["label"] if FRAMES == 16 else
                                     f"SD-1.5 {FRAMES}-frame chunk 512x512 (NOT the headline chunk size)") +
-                                   ": hot-path pass over the 16 transformer-block "
-                                   "sites, batch 2 (CFG), local merge 0.5" +
-                                   ("" if args.local_only else " + global merge 0.5 (steady state)"),
+                                   f": hot-path pass over the {len(site_list)} transformer-block "
+                                   f"sites, batch {BATCH}, local merge {LOCAL_RATIO}" +
+                                   ("" if args.local_only else f" + global merge {GLOBAL_RATIO} (steady state)"),
+                       "headline_configuration": headline,
                        "regime": ("same chunk fed to every pass (anchors = copies of its own rows; rounds 1-2)"
                                   if args.same_chunk else
                                   f"{K} distinct chunks of one synthetic clip rotate: every pass's anchor tokens come "
                                   f"from a different chunk (generate.py:215-219); " +
                                   (f"anchor chain of 1..{max(1, args.chunks_per_step - 1)} updates, re-seeded with the first "
                                    f"chunk's local tokens like a denoising step of {args.chunks_per_step} chunks "
-                                   f"(generate.py:233-236)" if ex is None else
+                                   f"(generate.py:233-236)" if mode is None else
                                    "anchors as the exchange mode defines them")),
-                       "data_regime": args.data + ": " + {
-                           "n01": "h ~ N(0,1), frames uncorrelated (SURVEY 8d)",
-                           "corr01": "h[f] = base + 0.1 N(0,1) (SURVEY 8d: realistic cross-frame cosine)",
-                           "corr05": "h[f] = base + 0.5 N(0,1) (rounds 1-3)",
-                           "flat25": "corr05 + a flat region over a quarter of every frame (candidate-list overflow -> exact escape)",
-                           "dup": "corr05 + a fifth of the positions exact copies of others"}[args.data],
+                       "data_regime": args.data + ": " + REGIME_NOTES[args.data] +
+                                      "; tokens drawn on the device (torch CUDA generator, fixed seeds)",
                        "full_block": bool(args.full_block),
-                       "sites": 16, "merged_sites": 10, "chunk_frames": FRAMES, "batch": BATCH,
+                       "sites": len(site_list), "merged_sites": merged_sites, "chunk_frames": FRAMES, "batch": BATCH,
                        "matcher": _merge.MATCH_MODE + (" (fp16-MFMA filter, fp32 refine; global-level index order inside "
                                                        "groups of EXACTLY equal similarity is the stable one, the "
                                                        "reference's is implementation-defined)" if filtered else ""),
-                       "parallelism": par, "exchange": mode if ex is not None else None,
-                       "exchange_bytes_per_step": None if ex is None else
-                       {"sent": int(ex.bytes_sent / max(1, total_passes)), "received": int(ex.bytes_received / max(1, total_passes)),
-                        "note": "this rank, averaged over all passes (N = 1: handed over in place, nothing crosses a link)"}},
+                       "parallelism": par, "exchange": mode,
+                       "exchange_bytes_per_step": head["exchange"]},
             # dominant single kernel of the step: the merged-token self-attention (MFMA-bound)
             # `achieved` counts EXECUTED flops (4 B Mq Mk C per launch): with a global level the block only computes the
             # attention rows unmerge() reads, so the reference-algorithmic 4 B M^2 C would overstate the kernel
@@ -764,21 +872,20 @@ def main():
                          "sustained_sclk_mhz": sclk,
                          "frac_at_sustained_clock": round(att_tf / roof_at_clock, 4) if roof_at_clock else None,
                          "note": box_note},
-            # the fused similarity + top-1 step (second largest).  The filtered matcher executes the reference's
-            # 2 B Ns Nd C flops ONCE on the fp16 MFMA (one-product filter) and re-evaluates the few surviving pairs in
-            # fp32: its roof is the fp16 MFMA peak.  The exact fallback kernel runs on the fp32 MFMA (157.3 TFLOP/s).
-            "matching": {"kernels": "filter_kernel + survivors + refine_kernel (vtm_match_filtered)" if filtered
+            # the fused similarity + top-1 step (second largest).  `nominal_tflops` = the reference's 2 B Ns Nd C flops per call /
+            # HIP-event time of the whole vtm_match_filtered call: the fp16-MFMA filter would execute exactly those once, but
+            # its partial-sum pruning skips the MFMAs of 32 x 32 blocks that can no longer matter -- `counters` carries the
+            # fraction of blocks pruned and of MFMA work really executed (device-side counters of one extra untimed pass).
+            # The exact fallback kernel runs on the fp32 MFMA (157.3 TFLOP/s).
+            "matching": {"kernels": "prep_operand + filter_kernel + refine_kernel + exact_rows_kernel (vtm_match_filtered)" if filtered
                                     else "match_kernel (vtm_match)",
-                         "executed_tflops": round(mat_tf, 1),
+                         "nominal_tflops": round(mat_tf, 1),
                          "peak": FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS,
-                         "frac": round(mat_tf / (FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS), 4),
+                         "nominal_frac": round(mat_tf / (FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS), 4),
                          "calls": mn, "matching_ms_per_step": round(mms / timed_passes, 3),
                          # device-side counters of one extra untimed pass: pairs the exact refine pass evaluated per src row,
-                         # rows whose candidate list overflowed (exact_rows_kernel), calls recomputed as a whole
+                         # rows whose candidate list overflowed (exact_rows_kernel), calls recomputed as a whole, blocks pruned
                          "counters": mt.match_counters() if filtered else None},
-            # the HBM-bound kernels of the path: algorithmic bytes (rows read + rows written) / HIP-event time.  The
-            # cfg-2 working sets (<= 212 MB) fit the 256 MB Infinity Cache, so `pmc` carries the counter-derived rates
-            # measured beyond it
             # q / k / v^T / out projections: GEMMs whose A rows are gathered through the composed merge map
             "projections": (lambda f, ms, n: {"kernel": "linear_rows_ws_kernel / linear_rows_kernel (vtm_linear_rows, fp16 MFMA)", "launches": n,
                                               "ms_per_step": round(ms / timed_passes, 3),
@@ -788,6 +895,8 @@ def main():
             # panel-GEMM projections of the C >= 640 / un-merged sites are `linear_panels` + their panel writers
             "components_ms_per_step": comp,
             "components_sum_ms": round(comp_sum, 3),
+            # everything that is neither attention nor the matcher (VERDICT r04 item 3's "side kernels")
+            "side_launches_ms_per_step": round(side, 3),
             # the event passes are bracketed as a whole as well: their own duration (they carry ~2 events per launch, so they
             # run a little longer than the mean pass) minus the itemised launches = dispatch gaps + host-side stalls
             "event_pass_ms": round(event_pass_ms, 3),
@@ -795,6 +904,9 @@ def main():
             "timing": f"value = {args.steps} passes / wall time between two fences (barrier + synchronize; perf_counter), "
                       f"i.e. the MEAN pass; kernel figures = HIP events on every {every}-th pass "
                       f"({timed_passes} event passes)",
+            # the HBM-bound kernels of the path: algorithmic bytes (rows read + rows written) / HIP-event time.  The
+            # cfg-2 working sets (<= 212 MB) fit the 256 MB Infinity Cache, so `pmc` carries the counter-derived rates
+            # measured beyond it
             "gather_path": {"hbm_peak_GBps": HBM_PEAK_GBPS, "layernorm": hbm("layernorm"),
                             "gather_rows": hbm("gather_rows"), "unmerge_add": hbm("unmerge_add"),
                             "pmc": pmc_gather_path()},
@@ -817,7 +929,54 @@ def main():
                 "ff_mode": __import__("vidtome_amd.patch", fromlist=["FF_MODE"]).FF_MODE,
                 "ff_geglu": gemm("ff_geglu"), "linear_panels": gemm("linear_panels"),
                 "layernorm_panels": hbm("layernorm_panels")}
-        if not args.no_cpu_baseline and world == 1 and not args.full_block:   # rank 0 at N = 1 only; the CPU leg times the segment
+
+    # ---- N = 1: the other token regimes, same harness, fewer passes (SURVEY 8d names n01 and corr01) ----
+    if world == 1 and mode is None and args.regimes != "none":
+        names = [n for n in ("n01", "corr01", "corr05", "corr002", "smooth", "dup", "flat25")] if args.regimes == "all" else \
+            [n.strip() for n in args.regimes.split(",") if n.strip()]
+        regs = {args.data: compact(head)}
+        for name in names:
+            if name in regs:
+                continue
+            if name not in REGIME_NOTES:
+                raise SystemExit(f"bench.py: unknown regime {name!r}")
+            regs[name] = compact(run_region(name, max(1, args.regime_steps), min(args.warmup, 2), None, False))
+        base = regs.get("corr05", {}).get("ms_per_step")
+        for name, r in regs.items():
+            r["vs_corr05"] = round(r["ms_per_step"] / base, 3) if base else None
+            r["what"] = REGIME_NOTES[name]
+        line["regimes"] = regs
+        line["regimes_note"] = (f"`value` is the {args.data} entry ({args.steps} passes); the others ran "
+                                f"{max(1, args.regime_steps)} timed passes each in the same process, same harness; vs_corr05 = "
+                                f"ms_per_step / corr05's (the regime rounds 1-4 quoted as the headline)")
+
+    # ---- N > 1: the other exchange modes (ring = the exact chain, neighbour / allgather = parallel anchors) ----
+    if world > 1 and mode is not None and args.exchange_modes != "none":
+        want = ["neighbour", "ring", "allgather"] if args.exchange_modes == "all" else \
+            [m.strip() for m in args.exchange_modes.split(",") if m.strip()]
+        modes = {mode: {"ms_per_step": round(dt / args.steps * 1e3, 3), "steps_per_s": round(world * args.steps / dt, 3),
+                        "per_rank_ms_per_step": head["per_rank_ms"], "exchange_bytes_per_step": head["exchange"]}}
+        if rank == 0:
+            line["exchange_modes"] = modes
+        if dog is not None:       # from here on a stuck rank must not take the headline with it
+            dog.fallback = (lambda: print(json.dumps(line), flush=True)) if rank == 0 else (lambda: None)
+        xsteps = max(2, min(args.steps, 10))
+        for m in want:
+            if m in modes:
+                continue
+            if dog is not None:
+                dog.phase = m
+            if rank == 0:
+                modes[m] = {"error": "did not finish (watchdog)"}        # overwritten when the region completes
+            r = run_region(args.data, xsteps, 1, m, False)
+            modes[m] = {"ms_per_step": round(r["dt"] / xsteps * 1e3, 3), "steps_per_s": round(world * xsteps / r["dt"], 3),
+                        "steps": xsteps, "per_rank_ms_per_step": r["per_rank_ms"], "exchange_bytes_per_step": r["exchange"]}
+        if dog is not None:
+            dog.fallback = None
+
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1 and not args.full_block and args.workload == "cfg2":
+            # rank 0 at N = 1 only; the CPU leg times the segment at the headline configuration
             line["cpu_baseline"] = (cpu_baseline_torch if args.cpu_baseline == "torch" else cpu_baseline_port)(
                 args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -48,6 +48,10 @@ typedef void *vtm_stream_t; /* hipStream_t */
 
 int vtm_version(void);
 const char *vtm_last_error(void);
+/* Bit mask of the ablation switches (vidtome_amd/csrc/ablate.h: experiment builds that drop loads / barriers / stores of
+ * the hand-scheduled kernels and produce WRONG results) the library was compiled with.  0 for every library that may be
+ * shipped; a host should refuse to run on anything else. */
+int vtm_build_ablations(void);
 
 /* Tile geometry the operand matrices of vtm_match must be padded to (rows to VTM_MATCH_ROW_PAD,
  * channels to VTM_MATCH_K_PAD). */

@@ -30,6 +30,23 @@ def test_library_exports_every_declared_symbol(built):
     assert _lib.lib().vtm_pad_rows(257) == 512 and _lib.lib().vtm_pad_k(320) == 320 and _lib.lib().vtm_pad_k(40) == 64
 
 
+def test_shipped_library_has_no_ablation_switch(built):
+    """The experiment switches of the hand-scheduled kernels (csrc/ablate.h: drop loads / barriers / stores, WRONG results)
+    live in one header; the kernel sources carry no #ifdef of theirs, the library the tests load was built with none of
+    them, and _lib refuses a library that was."""
+    import glob
+    from vidtome_amd import _lib
+    assert _lib.lib().vtm_build_ablations() == 0
+    assert ctypes.CDLL(built).vtm_build_ablations() == 0
+    csrc = os.path.join(ROOT, "vidtome_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*.hip")) + [os.path.join(csrc, "common.h")]:
+        src = open(path).read()
+        assert not re.search(r"#\s*if(n?def)?[^\n]*VTM_(EXP|LIN_NO)", src), path
+    hdr = open(os.path.join(csrc, "ablate.h")).read()
+    for name in re.findall(r"#ifdef (VTM_(?:EXP|LIN)_[A-Z]+)", hdr):       # every switch has a bit in the mask
+        assert re.search(r"VTM_ABL_BIT_" + name.replace("VTM_EXP_", "").replace("VTM_LIN_", "LIN_"), hdr), name
+
+
 def test_hot_kernels_keep_their_register_budget(built):
     """Code-object metadata of the built gfx950 kernels: the filter's hand-counted memory pipeline must not spill (a
     build whose SGPRs spilled faulted on the GPU) and must fit two waves per SIMD; the d = 40 attention kernel must keep

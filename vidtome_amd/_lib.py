@@ -31,6 +31,7 @@ _lib: Optional[ctypes.CDLL] = None
 _SIGNATURES = {
     "vtm_version": ([], _int),
     "vtm_last_error": ([], ctypes.c_char_p),
+    "vtm_build_ablations": ([], _int),
     "vtm_pad_rows": ([_i64], _i64),
     "vtm_pad_k": ([_i64], _i64),
     "vtm_normalize_gather": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp], _int),
@@ -102,6 +103,10 @@ def lib() -> ctypes.CDLL:
             fn.restype = restype
         if L.vtm_version() != 1:
             raise RuntimeError("libvidtome_hip.so ABI version mismatch")
+        if L.vtm_build_ablations() != 0 and os.environ.get("VIDTOME_ALLOW_ABLATED") != "1":
+            # an experiment build (csrc/ablate.h) computes wrong results by construction: only tools/ may load one, knowingly
+            raise RuntimeError(f"{LIB_PATH} was built with ablation switches (mask {L.vtm_build_ablations():#x}); "
+                               "set VIDTOME_ALLOW_ABLATED=1 to load it for a timing experiment")
         _lib = L
     return _lib
 

@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), tag: str = "")
     lib = os.path.join(libdir, "libvidtome_hip.so")
     os.makedirs(libdir, exist_ok=True)
     cc = hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "vidtome_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ablate.h"), os.path.join(HERE, "..", "include", "vidtome_hip.h")]
     objs, jobs = [], []
     flags = FLAGS + ["-D" + d for d in defines]
     for src in SOURCES:

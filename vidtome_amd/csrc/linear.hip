@@ -23,6 +23,7 @@
 // Workgroup tile: 128 tokens x 160 output channels (128 when N is not a multiple of 160), 5 (4) x 16 accumulator
 // registers per lane.
 #include "common.h"
+#include "ablate.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -97,11 +98,8 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
     auto issue_w = [&](int64_t k0) {
 #pragma unroll
         for (int i = 0; i < W_PER_T; ++i) {
-#ifdef VTM_LIN_NOW
-            rw[i] = u32x4{(unsigned)k0, 1u, 2u, 3u};
-#else
-            rw[i] = *reinterpret_cast<const u32x4 *>(wsrc[i] + k0);
-#endif
+            ABL_LIN_W(rw[i] = *reinterpret_cast<const u32x4 *>(wsrc[i] + k0);)
+            ABL_NO_LIN_W(rw[i] = u32x4{(unsigned)k0, 1u, 2u, 3u};)
         }
     };
     auto stage_w = [&](int buf) {
@@ -109,18 +107,13 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
         for (int i = 0; i < W_PER_T; ++i)
             if (wok[i]) *reinterpret_cast<u32x4 *>(&sW[buf][woff[i]]) = rw[i];
     };
-    // Ablation switches (never defined in the shipped build; they produce wrong results and only tell where the time
-    // goes): VTM_LIN_NOA no token loads, VTM_LIN_NOW no weight-tile loads, VTM_LIN_NOSTORE no output stores
+    // (ABL_* = the ablation switches of ablate.h: in the shipped build each expands to the code it wraps and nothing else)
     auto load_a = [&](vec (&a)[NA], int64_t k0) {
-#ifdef VTM_LIN_NOA
 #pragma unroll
-        for (int f = 0; f < NA; ++f)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[f][e] = (decltype(a[f][e] + a[f][e]))(k0 + f);
-#else
-#pragma unroll
-        for (int f = 0; f < NA; ++f) a[f] = *reinterpret_cast<const vec *>(xrow + k0 + f * 16);
-#endif
+        for (int f = 0; f < NA; ++f) {
+            ABL_LIN_A(a[f] = *reinterpret_cast<const vec *>(xrow + k0 + f * 16);)
+            ABL_NO_LIN_A(for (int e = 0; e < 8; ++e) a[f][e] = (decltype(a[f][e] + a[f][e]))(k0 + f);)
+        }
     };
 
     f32x16 acc[NJ];
@@ -189,9 +182,7 @@ __global__ __launch_bounds__(NT, 2) void linear_rows_kernel(
     // bytes per lane at a row stride, which costs more than the whole GEMM (measured: 107 -> 50 us at the cfg-2 top
     // block without the stores).  The tile therefore goes through LDS (the weight ring is free by now) and leaves as
     // 16-byte pieces of whole rows: 320 contiguous bytes per token (token-major), 256 per channel (channel-major).
-#ifdef VTM_LIN_NOSTORE
-    if (acc[0][0] != 12345.678f) return;
-#endif
+    ABL_NO_LIN_STORE(if (acc[0][0] != 12345.678f) return;)
     T *ob = out + b * out_batch_stride;
     const int64_t tok0 = m0 + 32 * wave;
     constexpr bool STAGED = sizeof(sW) >= (size_t)(TRANS ? TN * (TM + 8) : 4 * 32 * (TN + 8)) * sizeof(T);
@@ -392,11 +383,8 @@ __global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
     auto load_chunk = [&](const T *xr, int c) {           // chunk c of a block into buffer c & 1
 #pragma unroll
         for (int f = 0; f < WS_KCH; ++f) {
-#ifdef VTM_LIN_NOA
-            for (int e = 0; e < 8; ++e) a[c & 1][f][e] = (decltype(a[c & 1][f][e] + a[c & 1][f][e]))(f + c);
-#else
-            a[c & 1][f] = *reinterpret_cast<const vec *>(xr + (c * WS_KCH + f) * 16);
-#endif
+            ABL_LIN_A(a[c & 1][f] = *reinterpret_cast<const vec *>(xr + (c * WS_KCH + f) * 16);)
+            ABL_NO_LIN_A(for (int e = 0; e < 8; ++e) a[c & 1][f][e] = (decltype(a[c & 1][f][e] + a[c & 1][f][e]))(f + c);)
         }
     };
     const T *xr = row_ptr(blk0);
@@ -420,11 +408,10 @@ __global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
             for (int kk = 0; kk < WS_KCH; ++kk) {
                 vec fw[5];
 #pragma unroll
-#ifdef VTM_LIN_NOLDS
-                for (int j = 0; j < 5; ++j) fw[j] = a[c & 1][(kk + j) % WS_KCH];
-#else
-                for (int j = 0; j < 5; ++j) fw[j] = *reinterpret_cast<const vec *>(pw + j * 32 * WS_LDW + (c * WS_KCH + kk) * 16);
-#endif
+                for (int j = 0; j < 5; ++j) {
+                    ABL_LIN_LDS(fw[j] = *reinterpret_cast<const vec *>(pw + j * 32 * WS_LDW + (c * WS_KCH + kk) * 16);)
+                    ABL_NO_LIN_LDS(fw[j] = a[c & 1][(kk + j) % WS_KCH];)
+                }
                 const vec fx = a[c & 1][kk];
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
@@ -440,9 +427,7 @@ __global__ __launch_bounds__(WS_NT, 1) void linear_rows_ws_kernel(
         }
 
         const int64_t tok0 = blk * 32;
-#ifdef VTM_LIN_NOSTORE
-        if (acc[0][0] != 12345.678f) continue;
-#endif
+        ABL_NO_LIN_STORE(if (acc[0][0] != 12345.678f) continue;)
         if constexpr (!TRANS) {
             constexpr int SO = WS_TN + 8;
 #pragma unroll
@@ -589,3 +574,7 @@ VTM_EXPORT int vtm_linear_rows(const void *x0, int64_t P0, const void *x1, int64
     }
     return vtm::fail(VTM_EINVAL, "vtm_linear_rows: dtype must be VTM_F16 or VTM_BF16");
 }
+
+namespace vtm {
+int linear_ablations() { return VTM_ABLATIONS; }
+}  // namespace vtm

@@ -27,6 +27,7 @@
 // publishes +inf as the row's running maximum, which every other lane / split of the row picks up), so flat regions do not
 // flood the filter with candidate pushes either.
 #include "common.h"
+#include "ablate.h"
 
 #include <cstdlib>
 
@@ -35,12 +36,8 @@
 
 namespace {
 
-// Ablation switches (never defined in the shipped build; used for the measurements quoted in DESIGN.md section 9):
-//   VTM_EXP_NOWRAP     skip the candidate collection at the end of every dst tile
-//   VTM_EXP_NOBARRIER  drop the end-of-step wait + barrier      VTM_EXP_NOAWAIT  never wait for fragment loads
-//   VTM_EXP_NODMA      do not fetch dst tiles                   VTM_EXP_HOTMEM   fetch everything from one hot tile (phased loop)
-//   VTM_EXP_NOBLOAD    do not fetch src fragments               VTM_EXP_NOLDSREAD  do not read dst fragments from LDS
-// (all of them produce wrong results; they only tell where the time goes)
+// (The ABL_* macros in filter_kernel are the ablation switches of ablate.h: in the shipped build each expands to the code
+// it wraps and nothing else.)
 constexpr int FBD = 128;      // dst rows per tile (MFMA A operand, LDS)
 constexpr int FBS = 256;      // src rows per workgroup (B operand, registers), 64 per wave
 constexpr int FBK = 64;       // channels per pipeline step = 4 MFMA k-steps = 8 panels
@@ -393,11 +390,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const int64_t bgroup = 2 * Ns_pad;   // uint4 entries per k-step group (2 panels)
     u32x4 rb[4][2][2];
     [[maybe_unused]] auto load_b = [&](int kt, int ks, u32x4 (&dst)[2][2]) {
-#ifdef VTM_EXP_HOTMEM
-        const uint4 *ph = srch + ks * bgroup;
-#else
-        const uint4 *ph = srch + (int64_t)(kt * 4 + ks) * bgroup;   // uniform
-#endif
+        const uint4 *ph = srch + (int64_t)ABL_STREAMED(kt * 4 + ks, ks) * bgroup;   // uniform
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0][0]) : "v"(voff_b), "s"(ph));
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(dst[1][0]) : "v"(voff_b), "s"(ph));
         if constexpr (SRC_LO) {
@@ -427,11 +420,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     }
     const uint32_t voff_a = (uint32_t)lane * 16u;
     [[maybe_unused]] auto load_a_half = [&](int jt, int kt, int buf, int half_id) {
-#ifdef VTM_EXP_HOTMEM
-        const int64_t step_off = 0;
-#else
-        const int64_t step_off = (int64_t)kt * 8 * Nd_pad + (int64_t)jt * FBD;
-#endif
+        const int64_t step_off = ABL_STREAMED((int64_t)kt * 8 * Nd_pad + (int64_t)jt * FBD, (int64_t)0);
 #pragma unroll
         for (int t = 0; t < PG; ++t) {
             const uint4 *g = abase[half_id * PG + t] + step_off;
@@ -636,16 +625,10 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
             for (int s = 0; s < 4; ++s) {
                 if (s < 2) load_b(kt, s + 2, rb[s + 2]);
                 else load_b(ktp, s - 2, rb[s - 2]);
-#ifndef VTM_EXP_NODMA
-                if (s < 2) load_a_half(jtp, ktp, buf ^ 1, s);
-#endif
+                ABL_DMA(if (s < 2) load_a_half(jtp, ktp, buf ^ 1, s);)
                 // operations issued after B(s): see the table above
-#ifdef VTM_EXP_NOAWAIT
-                await_b(std::integral_constant<int, 63>{}, rb[s]);
-#else
-                if (s == 0 || s == 3) await_b(std::integral_constant<int, 2 * NB + PG>{}, rb[s]);
-                else await_b(std::integral_constant<int, 2 * NB + 2 * PG>{}, rb[s]);
-#endif
+                if (s == 0 || s == 3) await_b(std::integral_constant<int, ABL_AWAIT_COUNT(2 * NB + PG)>{}, rb[s]);
+                else await_b(std::integral_constant<int, ABL_AWAIT_COUNT(2 * NB + 2 * PG)>{}, rb[s]);
                 if constexpr (DST_LO) read_a(1, s, fl);
                 else if (s < 3) read_a(0, s + 1, fa[(s + 1) & 1]);   // one group ahead, alternating register sets
                 __builtin_amdgcn_sched_barrier(0);
@@ -684,17 +667,10 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                     }
                 }
             }
-#ifdef VTM_EXP_NOWRAP
-            if (wrap && jt < 0) collect_tile(jt, std::false_type{});
-#else
-            if (wrap) collect_tile(jt, std::false_type{});
-#endif
+            if (ABL_WRAP_COND(wrap)) collect_tile(jt, std::false_type{});
             // every wave's DMA pieces of the next tile must have landed before anybody reads them; they are older
             // than the 2 NB loads of groups 2 and 3
-#ifndef VTM_EXP_NOBARRIER
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
-            __syncthreads();
-#endif
+            ABL_BARRIER(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory"); __syncthreads();)
             kt = ktn;
             jt = jtn;
         }
@@ -773,13 +749,8 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
             constexpr int s = decltype(s_tag)::value;
             constexpr bool FIRST = decltype(first_tag)::value;
             constexpr int COUNT = s == 1 ? NB + 2 * PG : s == 2 ? NB + PG + 2 : NB + 2;
-            if constexpr (s != 0) {   // group 0's wait precedes the branch on kt (below)
-#ifdef VTM_EXP_NOAWAIT
-                await_b(std::integral_constant<int, 63>{}, rb[s]);
-#else
-                await_b(std::integral_constant<int, COUNT>{}, rb[s]);
-#endif
-            }
+            if constexpr (s != 0)   // group 0's wait precedes the branch on kt (below)
+                await_b(std::integral_constant<int, ABL_AWAIT_COUNT(COUNT)>{}, rb[s]);
             // the maxima fetched one step ago (X) are older than the fragments just awaited: only NOW have they certainly
             // landed.  Keeping their registers "in use" up to this point stops the compiler from handing them out while the
             // load is still in flight on the paths that never read them (every step that does not end a tile)
@@ -801,22 +772,15 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 4) {
-#ifndef VTM_EXP_NOLDSREAD
-                    if constexpr (s < 3) fn[j] = __builtin_bit_cast(h16x8, sA[buf][0][((s + 1) * 2 + kh) * FBD + j * 32 + l31]);
-                    else fn[j] = __builtin_bit_cast(h16x8, sA[buf ^ 1][0][kh * FBD + j * 32 + l31]);
-#else
-                    fn[j] = fh[j];
-#endif
+                    ABL_LDSREAD(if constexpr (s < 3) fn[j] = __builtin_bit_cast(h16x8, sA[buf][0][((s + 1) * 2 + kh) * FBD + j * 32 + l31]);
+                                else fn[j] = __builtin_bit_cast(h16x8, sA[buf ^ 1][0][kh * FBD + j * 32 + l31]);)
+                    ABL_NO_LDSREAD(fn[j] = fh[j];)
                 } else if (j < 6) {
-#ifndef VTM_EXP_NOBLOAD
-                    if constexpr (s < 2) load_b1(pb, s + 2, j - 4, rb[s + 2][j - 4][0]);
-                    else load_b1(pbn, s - 2, j - 4, rb[s - 2][j - 4][0]);
-#endif
+                    ABL_BLOAD(if constexpr (s < 2) load_b1(pb, s + 2, j - 4, rb[s + 2][j - 4][0]);
+                              else load_b1(pbn, s - 2, j - 4, rb[s - 2][j - 4][0]);)
                 } else {
-#ifndef VTM_EXP_NODMA
-                    if constexpr (s == 0) load_a_piece(pa1, buf ^ 1, j - 4);   // pieces 2, 3 of the next tile
-                    if constexpr (s == 3) load_a_piece(pa2, buf, j - 6);       // pieces 0, 1 of the one after
-#endif
+                    ABL_DMA(if constexpr (s == 0) load_a_piece(pa1, buf ^ 1, j - 4);   /* pieces 2, 3 of the next tile */
+                            if constexpr (s == 3) load_a_piece(pa2, buf, j - 6);)      /* pieces 0, 1 of the one after */
                     if constexpr (s == 1)   // agent scope: from L2, where the other workgroups' atomics land
                         asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(am[j - 6]) : "v"(voff_m[j - 6]), "s"(amax_rows));
                 }
@@ -825,26 +789,15 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         };
         // ONE wait statement for both variants of group 0: the fragments are usable only through the registers this
         // statement returns, and a second copy of it behind the branch would make the compiler copy them BEFORE it
-#ifdef VTM_EXP_NOAWAIT
-        await_b(std::integral_constant<int, 63>{}, rb[0]);
-#else
-        await_b(std::integral_constant<int, NB + PG>{}, rb[0]);
-#endif
+        await_b(std::integral_constant<int, ABL_AWAIT_COUNT(NB + PG)>{}, rb[0]);
         if (kt == 0) group(std::integral_constant<int, 0>{}, std::true_type{});
         else group(std::integral_constant<int, 0>{}, std::false_type{});
         group(std::integral_constant<int, 1>{}, std::false_type{});
         group(std::integral_constant<int, 2>{}, std::false_type{});
-#ifndef VTM_EXP_NOBARRIER
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NB + 2) : "memory");
-        __syncthreads();
-#endif
+        ABL_BARRIER(asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NB + 2) : "memory"); __syncthreads();)
         group(std::integral_constant<int, 3>{}, std::false_type{});
         if (kt + 1 == KP) live = prune_check(jt);      // (KP >= KT: pruning is off)
-#ifdef VTM_EXP_NOWRAP
-        if (wrap && jt < 0) collect_tile(jt, std::true_type{});
-#else
-        if (wrap && live) collect_tile(jt, std::true_type{});
-#endif
+        if (ABL_WRAP_COND(wrap && live)) collect_tile(jt, std::true_type{});
         if (wrap) {
             ++jt;
             live = 0xffu;
@@ -1556,3 +1509,7 @@ VTM_EXPORT int vtm_match_filtered_seeded(const void *x0, int64_t P0, const void 
     return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, b_rows, Nd, align, ws, ws_bytes, best, flags_out, seed_L,
                                seed_N, seed_pos1, seed_table, stream);
 }
+
+namespace vtm {
+int filter_ablations() { return VTM_ABLATIONS; }
+}  // namespace vtm

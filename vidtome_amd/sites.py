@@ -143,40 +143,80 @@ class SiteUNet(ModelMixin):
 
 DATA_REGIMES = {
     # name: (frame_noise, flat fraction, duplicate fraction) -- SURVEY.md 8d names the first two; `corr05` is what rounds
-    # 1-3 measured; `flat25` / `dup` load the matcher's candidate logic
+    # 1-3 measured; `flat25` / `dup` load the matcher's candidate logic; `corr002` / `smooth` are what SURVEY.md
+    # section 7 says LayerNorm'd video tokens look like (cross-frame cosine near 1, spatially smooth content)
     "n01": (None, 0.0, 0.0),        # h ~ N(0, 1), no cross-frame correlation: one candidate per row, low cosines
     "corr01": (0.1, 0.0, 0.0),      # h[f] = base + 0.1 N(0, 1): realistic high cross-frame cosine (~0.99)
+    "corr002": (0.02, 0.0, 0.0),    # h[f] = base + 0.02 N(0, 1): a static shot (cosine ~0.9996 between the frames of a position:
+                                    # every same-position dst token sits inside the filter's window)
     "corr05": (0.5, 0.0, 0.0),      # h[f] = base + 0.5 N(0, 1) (cosine ~0.8 between the frames of a position)
     "flat25": (0.5, 0.25, 0.0),     # corr05 + a flat region: a quarter of the positions (every frame) hold ONE content vector
                                     # + 2 % noise (a sky, a wall): ~N/4 dst rows per frame inside every such row's window
     "dup": (0.5, 0.0, 0.2),         # corr05 + exact copies: a fifth of the positions repeat another position's tokens bit for
                                     # bit in every frame (what anchor updates do to the global level, patch.py:80)
+    "smooth": ("smooth", 0.0, 0.0),  # a spatially low-passed field (Gaussian, sigma = SMOOTH_SIGMA tokens, unit variance per
+                                    # channel) that drifts by SMOOTH_SHIFT tokens per frame (sub-pixel, bilinear) + 0.05 N(0, 1):
+                                    # neighbouring positions AND neighbouring frames are near-maximal matches of a token
 }
+SMOOTH_SIGMA, SMOOTH_SHIFT, SMOOTH_NOISE = 2.0, 0.1, 0.05
+
+
+def _smooth_tokens(batch: int, frames: int, N: int, C: int, g: torch.Generator, gb: torch.Generator,
+                   frame0: int = 0) -> torch.Tensor:
+    """(batch, frames, N, C): one low-passed random field per sample, frame f = the field shifted by (frame0 + f) *
+    SMOOTH_SHIFT tokens along both axes (periodic, bilinear) + SMOOTH_NOISE * N(0, 1).  N must be a square grid (the
+    bench's latents are)."""
+    h = int(round(N ** 0.5))
+    if h * h != N:
+        raise ValueError(f"the smooth regime needs a square token grid, got N = {N}")
+    dev = g.device
+    base = torch.randn(batch, C, h, h, generator=gb, device=dev)
+    # separable periodic Gaussian blur via the FFT (exact circular convolution: the field tiles seamlessly)
+    fy = torch.fft.fftfreq(h, device=dev).view(h, 1)
+    fx = torch.fft.rfftfreq(h, device=dev).view(1, h // 2 + 1)
+    kern = torch.exp(-2.0 * (torch.pi * SMOOTH_SIGMA) ** 2 * (fy * fy + fx * fx))
+    field = torch.fft.irfft2(torch.fft.rfft2(base) * kern, s=(h, h))
+    field = field / field.std(dim=(2, 3), keepdim=True)
+    out = torch.empty(batch, frames, N, C, device=dev)
+    for f in range(frames):
+        s = (frame0 + f) * SMOOTH_SHIFT
+        k, a = int(s // 1), float(s - s // 1)
+        sh = lambda t, dy, dx: torch.roll(t, shifts=(dy, dx), dims=(2, 3))
+        fr = ((1 - a) * (1 - a) * sh(field, k, k) + a * (1 - a) * sh(field, k + 1, k)
+              + (1 - a) * a * sh(field, k, k + 1) + a * a * sh(field, k + 1, k + 1))
+        out[:, f] = fr.reshape(batch, C, N).transpose(1, 2)
+    return out + SMOOTH_NOISE * torch.randn(batch, frames, N, C, generator=g, device=dev)
 
 
 def regime_tokens(regime: str, batch: int, frames: int, N: int, C: int, g: torch.Generator,
-                  gb: torch.Generator = None) -> torch.Tensor:
+                  gb: torch.Generator = None, frame0: int = 0) -> torch.Tensor:
     """(batch, frames, N, C) fp32 tokens of one data regime (DATA_REGIMES); `gb` draws the clip content (base, flat
-    vector, duplicate pattern), `g` the per-frame noise."""
+    vector, duplicate pattern), `g` the per-frame noise.  `frame0` = index of the chunk's first frame in the clip (only
+    the drifting `smooth` regime looks at it).  The tensors are drawn on the generators' device (CPU generators: the
+    streams the tests and rounds 1-4 used; a CUDA generator draws on the GPU -- bench.py, seconds faster per regime)."""
     noise, flat, dup = DATA_REGIMES[regime]
     gb = g if gb is None else gb
+    dev = g.device
     if noise is None:
-        return torch.randn(batch, frames, N, C, generator=g)
-    base = torch.randn(batch, 1, N, C, generator=gb)
-    x = base + noise * torch.randn(batch, frames, N, C, generator=g)
+        return torch.randn(batch, frames, N, C, generator=g, device=dev)
+    if noise == "smooth":
+        return _smooth_tokens(batch, frames, N, C, g, gb, frame0)
+    base = torch.randn(batch, 1, N, C, generator=gb, device=dev)
+    x = base + noise * torch.randn(batch, frames, N, C, generator=g, device=dev)
     if flat > 0:
         nf = int(N * flat)
-        content = torch.randn(batch, 1, 1, C, generator=gb)
-        x[:, :, :nf] = content + 0.02 * torch.randn(batch, frames, nf, C, generator=g)
+        content = torch.randn(batch, 1, 1, C, generator=gb, device=dev)
+        x[:, :, :nf] = content + 0.02 * torch.randn(batch, frames, nf, C, generator=g, device=dev)
     if dup > 0:
         nd = int(N * dup)
-        src = torch.randint(nd, N, (nd,), generator=gb)
+        src = torch.randint(nd, N, (nd,), generator=gb, device=dev)
         x[:, :, :nd] = x[:, :, src]
     return x
 
 
 def synthetic_hidden(site: Site, batch: int, frames: int, latent_hw: Tuple[int, int], dtype, device,
-                     seed: int, frame_noise: float = 0.5, clip_seed: int = None, regime: str = None) -> torch.Tensor:
+                     seed: int, frame_noise: float = 0.5, clip_seed: int = None, regime: str = None,
+                     frame0: int = 0, gen_device=None) -> torch.Tensor:
     """(B*F, N, C) hidden states: per-sample base + frame_noise * N(0,1) per frame (frames of a clip are
     correlated).  Batch layout [uncond frames | cond frames] like generate.py:245.  With ``clip_seed`` the base comes
     from that seed and only the frame noise from ``seed``: different ``seed``s are then different CHUNKS OF ONE CLIP
@@ -184,13 +224,14 @@ def synthetic_hidden(site: Site, batch: int, frames: int, latent_hw: Tuple[int, 
     ``regime`` selects one of DATA_REGIMES instead (``corr05`` = the default arithmetic, same random stream)."""
     h, w = latent_hw[0] // site.downsample, latent_hw[1] // site.downsample
     N = h * w
-    g = torch.Generator().manual_seed(seed)
-    gb = g if clip_seed is None else torch.Generator().manual_seed(clip_seed)
+    gdev = torch.device("cpu") if gen_device is None else torch.device(gen_device)
+    g = torch.Generator(device=gdev).manual_seed(seed)
+    gb = g if clip_seed is None else torch.Generator(device=gdev).manual_seed(clip_seed)
     if regime is not None and regime != "corr05":
-        x = regime_tokens(regime, batch, frames, N, site.channels, g, gb)
+        x = regime_tokens(regime, batch, frames, N, site.channels, g, gb, frame0)
     else:
-        base = torch.randn(batch, 1, N, site.channels, generator=gb)
-        x = base + frame_noise * torch.randn(batch, frames, N, site.channels, generator=g)
+        base = torch.randn(batch, 1, N, site.channels, generator=gb, device=gdev)
+        x = base + frame_noise * torch.randn(batch, frames, N, site.channels, generator=g, device=gdev)
     return x.reshape(batch * frames, N, site.channels).to(device=device, dtype=dtype)
 
 
@@ -227,7 +268,7 @@ class ClipStream:
 
     def __init__(self, unet: "SiteUNet", site_list: List[Site], batch: int, frames: int, latent_hw: Tuple[int, int], dtype,
                  device, n_sets: int = 3, chunks_per_step: int = 8, same_chunk: bool = False, rank: int = 0,
-                 reseed: bool = True, sets=None, cond: torch.Tensor = None, regime: str = None):
+                 reseed: bool = True, sets=None, cond: torch.Tensor = None, regime: str = None, gen_device=None):
         self.unet, self.site_list = unet, site_list
         self.cond = cond                      # not None: full-block passes (run_block_pass)
         self.K = 1 if same_chunk else max(2, n_sets)
@@ -239,10 +280,11 @@ class ClipStream:
 
         def make(j):
             if same_chunk:
-                return [synthetic_hidden(s, batch, frames, latent_hw, dtype, device, seed=1234 + 97 * rank + i, regime=regime)
-                        for i, s in enumerate(site_list)]
+                return [synthetic_hidden(s, batch, frames, latent_hw, dtype, device, seed=1234 + 97 * rank + i, regime=regime,
+                                         gen_device=gen_device) for i, s in enumerate(site_list)]
             return [synthetic_hidden(s, batch, frames, latent_hw, dtype, device, seed=1234 + 97 * j + i,
-                                     clip_seed=4321 + i, regime=regime) for i, s in enumerate(site_list)]
+                                     clip_seed=4321 + i, regime=regime, frame0=j * frames, gen_device=gen_device)
+                    for i, s in enumerate(site_list)]
         self.sets = {j: make(j) for j in want}
 
     def _first_chunk(self, j: int) -> None:
