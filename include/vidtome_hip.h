@@ -104,11 +104,13 @@ int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd,
  * makes that kernel recompute every row of the call (device flag, no host round trip).  Four launches per call (operand
  * preparation, filter, refine, escape).  C > 1280 is rejected (the error budget is derived for C <= 1280; use vtm_match).
  * Inputs are the token pool (x0 | x1, as vtm_normalize_gather) and the gathered pool ids a_rows (B, Ns),
- * b_rows (B, Nd); B * Nd < 2^31.  ws: >= vtm_match_filtered_ws_bytes(...) bytes.  flags_out (optional, 4 int32,
+ * b_rows (B, Nd); B * Nd < 2^31.  ws: >= vtm_match_filtered_ws_bytes(...) bytes.  flags_out (optional, 8 int32,
  * device): [0] = 1 if every row was recomputed exactly (a dst row without a usable norm), [1] = 1 if any row without a
  * usable norm was seen, [2] = number of rows recomputed by the escape because their candidate list overflowed or their own
- * norm was unusable, [3] = number of (row, dst) pairs the refine pass evaluated.  Derivation of the window:
- * vidtome_amd/csrc/match_filter.hip.
+ * norm was unusable, [3] = number of (row, dst) pairs the refine pass evaluated, [4] = 32 x 32 score blocks the filter's
+ * partial-sum pruning tested, [5] = blocks still alive after the test (the others skipped their remaining MFMAs; both 0
+ * when the rows are too short to prune), [6], [7] = 0 (reserved).  The block counters are only collected when flags_out
+ * is given.  Derivation of the window: vidtome_amd/csrc/match_filter.hip.
  *
  * vtm_match_filtered_seeded -- the same result, usually faster on video tokens: before the filter starts every src row gets
  * a starting maximum from ONE guessed pair, the dst row at the same token position (one more small launch).  seed_N =

@@ -157,7 +157,8 @@ def time_step(batch: int, frames: int, latent_hw: Tuple[int, int], site_list, ar
     """Time the segment on ONE site of every kind (same shape => same cost) in steady state (anchors populated by a
     preceding chunk, as in bench.py) and add the kinds up to a whole step.  A merged site whose full batch would
     blow the time budget is timed on ONE batch sample (the reference loops nothing over the batch, but every operation
-    of the path is independent per sample) and doubled; `sampled` says which."""
+    of the path is independent per sample) and doubled; `sampled` says which.  Every kind gets one untimed warm-up pass
+    and the median of two timed ones (a single cold pass spread 108-123 s across boxes)."""
     torch.set_grad_enabled(False)
     kinds: Dict[Tuple[int, int, int], int] = {}
     for s in site_list:
@@ -174,7 +175,8 @@ def time_step(batch: int, frames: int, latent_hw: Tuple[int, int], site_list, ar
         if merges:
             L = frames * N
             flops = batch * (2.0 * 1.2 * L * L * C * 0.6 + 4.0 * (0.8 * L) ** 2 * C)        # rough: matching + attention
-            if per_flop is not None and per_flop * flops > 0.6 * max(budget_s - spent, 1.0) and batch > 1:
+            # (three passes per kind: warm-up + two timed)
+            if per_flop is not None and 3.0 * per_flop * flops > 0.6 * max(budget_s - spent, 1.0) and batch > 1:
                 b_run = 1
                 sampled.append(f"ds{ds}")
         else:
@@ -187,14 +189,27 @@ def time_step(batch: int, frames: int, latent_hw: Tuple[int, int], site_list, ar
         state: Dict = {}
         if merges:
             compute_merge(F.layer_norm(make(), (C,)), b_run, args, state, gen)               # preceding chunk: anchors
-        x = make()
+        # one untimed warm-up pass (first-touch page faults, oneDNN / OpenMP start-up, the allocator's high-water mark), then
+        # `reps` timed passes over fresh chunks of the same clip; the site's time is their median (reps = 2: the mean of the
+        # two, both listed).  A site kind whose warm-up alone shows that three passes would blow the budget keeps ONE timed
+        # pass (`reps` says so).
         t0 = time.perf_counter()
-        segment(x, b_run, args, state, gen, w, heads, merges)
-        dt = time.perf_counter() - t0
-        spent += dt
+        segment(make(), b_run, args, state, gen, w, heads, merges)
+        warm = time.perf_counter() - t0
+        spent += warm
+        reps = 2 if spent + 2.0 * warm <= budget_s else 1
+        times = []
+        for _ in range(reps):
+            x = make()
+            t0 = time.perf_counter()
+            segment(x, b_run, args, state, gen, w, heads, merges)
+            times.append(time.perf_counter() - t0)
+        spent += sum(times)
+        dt = sorted(times)[len(times) // 2] if len(times) % 2 else sum(sorted(times)[len(times) // 2 - 1:len(times) // 2 + 1]) / 2.0
         dt_full = dt * (batch / b_run)
         if merges and b_run == batch:
             per_flop = dt / flops if per_flop is None else min(per_flop, dt / flops)
-        detail[f"ds{ds}_C{C}"] = {"seconds_per_site": round(dt_full, 3), "sites": n_sites, "timed_batch": b_run}
+        detail[f"ds{ds}_C{C}"] = {"seconds_per_site": round(dt_full, 3), "sites": n_sites, "timed_batch": b_run,
+                                  "warmup_s": round(warm, 3), "timed_s": [round(t, 3) for t in times]}
         total += dt_full * n_sites
     return {"seconds_per_step": total, "detail": detail, "sampled": sampled, "spent": spent}

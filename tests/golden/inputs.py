@@ -26,6 +26,24 @@ def planted_inputs(Ns, Nd, C, seed, B=1):
     return np.stack(out_a), np.stack(out_b)
 
 
+def portable_weight(name, shape):
+    """A weight matrix as a pure function of its parameter NAME and shape, in integer arithmetic only (splitmix64 over the
+    element index, top 12 bits -> k / 2048 in [-1, 1), times a power of two near sqrt(3 / fan_in)): the same bits on any
+    machine and library version, exactly representable in fp16, variance ~1 / fan_in.  The full-block fixtures
+    (make_golden_fullblock.py) draw every 2-D block weight from here instead of storing 20+ MB of them."""
+    import zlib
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64) + np.uint64(zlib.crc32(name.encode())) * np.uint64(0x9E3779B97F4A7C15)
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    k = (z >> np.uint64(52)).astype(np.int64) - 2048                        # 12 bits -> [-2048, 2047]
+    scale = 2.0 ** np.round(np.log2(np.sqrt(3.0 / shape[-1])))
+    return (k.astype(np.float32) / 2048.0 * np.float32(scale)).reshape(shape)
+
+
 def fuzz_inputs(cfg):
     """Chunk inputs of a fuzz_compute_merge.npz configuration: (B*F, N, C) fp32 per chunk, nothing but torch.randn on a
     seeded CPU generator (shared by make_golden_fuzz.py and the tests)."""

@@ -37,7 +37,7 @@ ref_pnp = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(ref_pnp)
 
 sys.path.insert(0, HERE)
-from inputs import planted_inputs  # noqa: E402  (shared, reference-free input builders)
+from inputs import planted_inputs, portable_weight  # noqa: E402  (shared, reference-free input builders)
 
 torch.set_grad_enabled(False)
 
@@ -291,30 +291,82 @@ class Zero(torch.nn.Module):
         return torch.zeros_like(x)
 
 
+class CrossAttention(Attention):
+    """attn2 of an SD block (make_golden_fullblock.py): queries from the tokens, keys / values from the conditioning."""
+
+    def __init__(self, C, heads, cond_dim):
+        super().__init__(C, heads)
+        self.to_k = torch.nn.Linear(cond_dim, C, bias=False)
+        self.to_v = torch.nn.Linear(cond_dim, C, bias=False)
+
+
+class GEGLU(torch.nn.Module):
+    """Diffusers' GEGLU (third-party, SURVEY.md 8c: restated from its published form): one Linear to 2 D, value * gelu(gate),
+    exact (erf) gelu."""
+
+    def __init__(self, C, D):
+        super().__init__()
+        self.proj = torch.nn.Linear(C, 2 * D)
+
+    def forward(self, x):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * torch.nn.functional.gelu(gate)
+
+
+class FeedForward(torch.nn.Module):
+    """Diffusers' FeedForward of an SD block: [GEGLU(C -> 4C), Dropout(0), Linear(4C -> C)]."""
+
+    def __init__(self, C):
+        super().__init__()
+        self.net = torch.nn.ModuleList([GEGLU(C, 4 * C), torch.nn.Dropout(0.0), torch.nn.Linear(4 * C, C)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
 class BasicTransformerBlock(torch.nn.Module):   # class NAME is what apply_patch looks for (patch.py:319)
-    def __init__(self, C, heads):
+    def __init__(self, C, heads, full=False, cond_dim=0):
         super().__init__()
         self.norm1 = torch.nn.LayerNorm(C)
         self.attn1 = Attention(C, heads)
-        self.attn2 = None
-        self.norm2 = None
-        self.norm3 = torch.nn.Identity()
-        self.ff = Zero()
         self.only_cross_attention = False
+        if full:        # make_golden_fullblock.py: the whole SD block (patch.py:171-199)
+            self.norm2 = torch.nn.LayerNorm(C)
+            self.attn2 = CrossAttention(C, heads, cond_dim)
+            self.norm3 = torch.nn.LayerNorm(C)
+            self.ff = FeedForward(C)
+        else:
+            self.attn2 = None
+            self.norm2 = None
+            self.norm3 = torch.nn.Identity()
+            self.ff = Zero()
 
 
 class _Attn2D(torch.nn.Module):
-    def __init__(self, C, heads):
+    """Stand-in for Diffusers' Transformer2DModel: it calls its block with the FULL keyword set the patched forward
+    declares (patch.py:128-137; caller side per SURVEY.md 8b)."""
+
+    def __init__(self, C, heads, full=False, cond_dim=0):
         super().__init__()
-        self.transformer_blocks = torch.nn.ModuleList([BasicTransformerBlock(C, heads)])
+        self.transformer_blocks = torch.nn.ModuleList([BasicTransformerBlock(C, heads, full, cond_dim)])
+
+    def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, class_labels=None,
+                cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None):
+        for block in self.transformer_blocks:
+            hidden_states = block(hidden_states, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
+                                  encoder_attention_mask=encoder_attention_mask, timestep=timestep,
+                                  cross_attention_kwargs=cross_attention_kwargs, class_labels=class_labels)
+        return hidden_states
 
 
 class _UpBlock(torch.nn.Module):
-    def __init__(self, C, heads, n, ds):
+    def __init__(self, C, heads, n, ds, full=False, cond_dim=0):
         super().__init__()
         self.ds = ds
         if n:
-            self.attentions = torch.nn.ModuleList([_Attn2D(C, heads) for _ in range(n)])
+            self.attentions = torch.nn.ModuleList([_Attn2D(C, heads, full, cond_dim) for _ in range(n)])
 
 
 class ModelMixin(torch.nn.Module):              # class NAME checked by isinstance_str (patch.py:279-280)
@@ -324,11 +376,12 @@ class ModelMixin(torch.nn.Module):              # class NAME checked by isinstan
 class StandInUNet(ModelMixin):
     """up_blocks[1..3] x 3 transformer blocks at downsample 4 / 2 / 1, like SD's decoder."""
 
-    def __init__(self, C, heads):
+    def __init__(self, C, heads, full=False, cond_dim=0):
         super().__init__()
         self.C = C
-        self.up_blocks = torch.nn.ModuleList([_UpBlock(C, heads, 0, 8), _UpBlock(C, heads, 3, 4),
-                                              _UpBlock(C, heads, 3, 2), _UpBlock(C, heads, 3, 1)])
+        self.full = full
+        self.up_blocks = torch.nn.ModuleList([_UpBlock(C, heads, 0, 8), _UpBlock(C, heads, 3, 4, full, cond_dim),
+                                              _UpBlock(C, heads, 3, 2, full, cond_dim), _UpBlock(C, heads, 3, 1, full, cond_dim)])
         self.embed = torch.nn.Linear(4, C)
         self.mix = torch.nn.Linear(C, C)
         self.gen = torch.Generator().manual_seed(0)
@@ -340,8 +393,15 @@ class StandInUNet(ModelMixin):
                 for a in ub.attentions:
                     yield ub.ds, a.transformer_blocks[0]
 
+    def transformers(self):
+        for ub in self.up_blocks:
+            if hasattr(ub, "attentions"):
+                for a in ub.attentions:
+                    yield a
+
     def forward(self, latent, t=None, encoder_hidden_states=None):
         outs = []
+        t2d = list(self.transformers())
         for bi, (ds, blk) in enumerate(self.blocks()):
             z = torch.nn.functional.avg_pool2d(latent, ds) if ds > 1 else latent
             tok = z.flatten(2).transpose(1, 2)                    # (B*F, N, 4)
@@ -351,7 +411,10 @@ class StandInUNet(ModelMixin):
                 getattr(self, "hidden_noise", 1.0) * torch.randn(tok.shape[0], tok.shape[1], self.C, generator=self.gen).to(tok.dtype)
             if getattr(self, "fp16_grid", False):     # make_golden_chain16.py: hidden states an fp16 model can hold exactly
                 hidden = hidden.half().to(tok.dtype)
-            out = blk(hidden, encoder_hidden_states=encoder_hidden_states)
+            if self.full:   # through the stand-in Transformer2DModel: the block is called with the full keyword set
+                out = t2d[bi](hidden, encoder_hidden_states=encoder_hidden_states, timestep=t)
+            else:
+                out = blk(hidden, encoder_hidden_states=encoder_hidden_states)
             self.records.append({"block": bi, "ds": ds, "hidden": hidden.clone(), "out": out.clone()})
             outs.append(out)
         return outs
@@ -367,9 +430,19 @@ class Pipe:
 def run_chain(dtype, cfg, weights_seed):
     C, heads, H, W = cfg["C"], cfg["heads"], cfg["H"], cfg["W"]
     torch.manual_seed(weights_seed)
-    unet = StandInUNet(C, heads)
+    full = bool(cfg.get("full"))
+    unet = StandInUNet(C, heads, full, cfg.get("cond_dim", 0)) if full else StandInUNet(C, heads)
     for p in unet.parameters():     # drawn in fp32 so the fp64 screening run sees the same weights
         p.copy_(torch.randn_like(p) * (0.5 if p.ndim == 1 else p.shape[-1] ** -0.5))
+    if full:                        # LayerNorm gains near 1 (a gain drawn like a bias would be a different model)
+        for _, blk in unet.blocks():
+            for nrm in (blk.norm2, blk.norm3):
+                nrm.weight.copy_(1.0 + 0.1 * torch.randn_like(nrm.weight))
+        # the blocks' matrices come from a portable integer generator keyed by the parameter name (inputs.portable_weight):
+        # the fixture stores the 1-D parameters only, the test rebuilds the matrices
+        for n, p in unet.named_parameters():
+            if p.ndim == 2 and "transformer_blocks" in n:
+                p.copy_(torch.from_numpy(portable_weight(n, tuple(p.shape))))
     if cfg.get("fp16_grid"):
         # make_golden_chain16.py: weights and hidden states on the fp16 grid (an fp16 model holds them exactly; the
         # reference still computes in `dtype`), positions of one clip correlated across frames
@@ -407,6 +480,30 @@ def run_chain(dtype, cfg, weights_seed):
             blk.attn1.injection_schedule = None
             blk.attn1.forward = _plain_sa(blk.attn1)
         blk.attn1.t = cfg["t"]
+    if full:
+        # attn2 = the reference's own attention arithmetic too: register_attention_control is pointed at a holder whose
+        # "attn1" slots are the blocks' attn2 modules, so sa_forward's closure (its is_cross branch, pnp_utils.py:51-53,
+        # 71-75) becomes attn2.forward; the one block it skips (pnp_utils.py:100) gets the same arithmetic restated
+        class _Holder(torch.nn.Module):
+            pass
+        fake = _Holder()
+        fake.unet = _Holder()
+        fake.unet.up_blocks = []
+        for ub in unet.up_blocks:
+            h_ub = _Holder()
+            h_ub.attentions = []
+            for a in (ub.attentions if hasattr(ub, "attentions") else []):
+                h_a, h_b = _Holder(), _Holder()
+                h_b.attn1 = a.transformer_blocks[0].attn2
+                h_a.transformer_blocks = [h_b]
+                h_ub.attentions.append(h_a)
+            fake.unet.up_blocks.append(h_ub)
+        ref_pnp.register_attention_control(fake, None, cfg["B"])
+        for _, blk in unet.blocks():
+            if not hasattr(blk.attn2, "injection_schedule"):
+                blk.attn2.injection_schedule = None
+                blk.attn2.forward = _plain_sa(blk.attn2)
+            blk.attn2.t = cfg["t"]
     # record what attn1 receives = compute_merge's merged tokens
     for bi, (_, blk) in enumerate(unet.blocks()):
         inner = blk.attn1.forward
@@ -457,10 +554,14 @@ def run_chain(dtype, cfg, weights_seed):
             for _, blk in unet.blocks():
                 blk.attn1.seen.clear()
             n0 = len(trace)
-            unet(lat, 0, None)
+            cond = None
+            if full:    # the text conditioning: one embedding per batch group, repeated over the chunk's frames (generate.py:245)
+                cond = torch.randn(cfg["B"], 1, cfg["cond_tokens"], cfg["cond_dim"], generator=g).half().float()
+                cond = cond.expand(-1, F, -1, -1).reshape(cfg["B"] * F, cfg["cond_tokens"], cfg["cond_dim"]).to(dtype)
+            unet(lat, cfg["t"] if full else 0, cond)
             gts = vidtome.collect_from_patch(unet, attr="global_tokens")
             chunks.append({
-                "latent": lat.clone(), "records": [dict(r) for r in unet.records],
+                "latent": lat.clone(), "cond": None if cond is None else cond.clone(), "records": [dict(r) for r in unet.records],
                 "merged": [blk.attn1.seen[0].clone() for _, blk in unet.blocks()],
                 "global_tokens": {k: (None if v is None else v.clone()) for k, v in gts.items()},
                 "trace": trace[n0:],
@@ -476,9 +577,10 @@ def run_chain(dtype, cfg, weights_seed):
 
 def _plain_sa(attn):
     def forward(x, encoder_hidden_states=None, attention_mask=None, **kw):
+        ctx = x if encoder_hidden_states is None else encoder_hidden_states      # pnp_utils.py:51-53
         q = attn.head_to_batch_dim(attn.to_q(x))
-        k = attn.head_to_batch_dim(attn.to_k(x))
-        v = attn.head_to_batch_dim(attn.to_v(x))
+        k = attn.head_to_batch_dim(attn.to_k(ctx))
+        v = attn.head_to_batch_dim(attn.to_v(ctx))
         sim = torch.einsum("b i d, b j d -> b i j", q, k) * attn.scale
         out = torch.einsum("b i j, b j d -> b i d", sim.softmax(dim=-1), v)
         return attn.to_out[0](attn.batch_to_head_dim(out))

@@ -26,30 +26,76 @@ class Zero(torch.nn.Module):
         return torch.zeros_like(x)
 
 
+class CrossAttention(Attention):
+    """attn2 of an SD block: queries from the tokens, keys / values from the conditioning (fullblock16_*.npz)."""
+
+    def __init__(self, C, heads, cond_dim):
+        super().__init__(C, heads)
+        self.to_k = torch.nn.Linear(cond_dim, C, bias=False)
+        self.to_v = torch.nn.Linear(cond_dim, C, bias=False)
+
+
+class GEGLU(torch.nn.Module):
+    def __init__(self, C, D):
+        super().__init__()
+        self.proj = torch.nn.Linear(C, 2 * D)
+
+    def forward(self, x):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * torch.nn.functional.gelu(gate)
+
+
+class FeedForward(torch.nn.Module):
+    def __init__(self, C):
+        super().__init__()
+        self.net = torch.nn.ModuleList([GEGLU(C, 4 * C), torch.nn.Dropout(0.0), torch.nn.Linear(4 * C, C)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
 class BasicTransformerBlock(torch.nn.Module):
-    def __init__(self, C, heads):
+    def __init__(self, C, heads, full=False, cond_dim=0):
         super().__init__()
         self.norm1 = torch.nn.LayerNorm(C)
         self.attn1 = Attention(C, heads)
-        self.attn2 = None
-        self.norm2 = None
-        self.norm3 = torch.nn.Identity()
-        self.ff = Zero()
         self.only_cross_attention = False
+        if full:        # the whole SD block (vidtome/patch.py:171-199), as in tests/golden/make_golden_fullblock.py
+            self.norm2 = torch.nn.LayerNorm(C)
+            self.attn2 = CrossAttention(C, heads, cond_dim)
+            self.norm3 = torch.nn.LayerNorm(C)
+            self.ff = FeedForward(C)
+        else:
+            self.attn2 = None
+            self.norm2 = None
+            self.norm3 = torch.nn.Identity()
+            self.ff = Zero()
 
 
 class _Attn2D(torch.nn.Module):
-    def __init__(self, C, heads):
+    """Stand-in Transformer2DModel: calls its block with the FULL keyword set of the patched forward (patch.py:128-137)."""
+
+    def __init__(self, C, heads, full=False, cond_dim=0):
         super().__init__()
-        self.transformer_blocks = torch.nn.ModuleList([BasicTransformerBlock(C, heads)])
+        self.transformer_blocks = torch.nn.ModuleList([BasicTransformerBlock(C, heads, full, cond_dim)])
+
+    def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, class_labels=None,
+                cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None):
+        for block in self.transformer_blocks:
+            hidden_states = block(hidden_states, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
+                                  encoder_attention_mask=encoder_attention_mask, timestep=timestep,
+                                  cross_attention_kwargs=cross_attention_kwargs, class_labels=class_labels)
+        return hidden_states
 
 
 class _UpBlock(torch.nn.Module):
-    def __init__(self, C, heads, n, ds):
+    def __init__(self, C, heads, n, ds, full=False, cond_dim=0):
         super().__init__()
         self.ds = ds
         if n:
-            self.attentions = torch.nn.ModuleList([_Attn2D(C, heads) for _ in range(n)])
+            self.attentions = torch.nn.ModuleList([_Attn2D(C, heads, full, cond_dim) for _ in range(n)])
 
 
 class ModelMixin(torch.nn.Module):
@@ -59,10 +105,11 @@ class ModelMixin(torch.nn.Module):
 class StandInUNet(ModelMixin):
     """forward(latent, hiddens): feeds hiddens[i] to block i; the latent only provides (H, W) to the size hook."""
 
-    def __init__(self, C, heads):
+    def __init__(self, C, heads, full=False, cond_dim=0):
         super().__init__()
-        self.up_blocks = torch.nn.ModuleList([_UpBlock(C, heads, 0, 8), _UpBlock(C, heads, 3, 4),
-                                              _UpBlock(C, heads, 3, 2), _UpBlock(C, heads, 3, 1)])
+        self.full = full
+        self.up_blocks = torch.nn.ModuleList([_UpBlock(C, heads, 0, 8), _UpBlock(C, heads, 3, 4, full, cond_dim),
+                                              _UpBlock(C, heads, 3, 2, full, cond_dim), _UpBlock(C, heads, 3, 1, full, cond_dim)])
 
     def blocks(self):
         for ub in self.up_blocks:
@@ -70,7 +117,18 @@ class StandInUNet(ModelMixin):
                 for a in ub.attentions:
                     yield a.transformer_blocks[0]
 
-    def forward(self, latent, hiddens):
+    def transformers(self):
+        for ub in self.up_blocks:
+            if hasattr(ub, "attentions"):
+                for a in ub.attentions:
+                    yield a
+
+    def forward(self, latent, hiddens, encoder_hidden_states=None, timestep=None):
+        """hiddens[i] feeds block i (None = skip that block).  The full stand-in goes through its Transformer2DModel
+        stand-ins, i.e. the blocks are called with every keyword of patch.py:128-137."""
+        if self.full:
+            return [None if h is None else t2d(h, encoder_hidden_states=encoder_hidden_states, timestep=timestep)
+                    for t2d, h in zip(self.transformers(), hiddens)]
         return [blk(h) for blk, h in zip(self.blocks(), hiddens)]
 
 
@@ -79,14 +137,23 @@ class Pipe:
         self.unet = unet
 
 
-def load_block_weights(unet, z, device, dtype):
-    """Copy the fixture's weights (saved from the reference run's stand-in) into the blocks."""
+def load_block_weights(unet, z, device, dtype, portable=None):
+    """Copy the fixture's weights (saved from the reference run's stand-in) into the blocks.  ``portable`` (the full-block
+    fixtures): a function (name, shape) -> matrix for the 2-D parameters the fixture does not store
+    (tests/golden/inputs.portable_weight), and blocks the fixture keeps no parameters of stay as constructed."""
     sd = {}
     for k in z.files:
         if k.startswith("w/up_blocks"):
             sd[k[2:]] = torch.from_numpy(z[k])
     own = unet.state_dict()
     for k in own:
-        own[k] = sd[k]
+        if k in sd:
+            own[k] = sd[k]
+        elif portable is not None:
+            prefix = k.rsplit(".transformer_blocks.0.", 1)[0] + ".transformer_blocks.0."
+            if own[k].ndim == 2 and any(n.startswith(prefix) for n in sd):
+                own[k] = torch.from_numpy(portable(k, tuple(own[k].shape)))
+        else:
+            own[k] = sd[k]               # KeyError: the fixture must hold every parameter
     unet.load_state_dict(own)
     return unet.to(device=device, dtype=dtype)

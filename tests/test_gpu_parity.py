@@ -14,6 +14,9 @@ from inputs import planted_inputs
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 IDX = ("a_idx", "b_idx", "unm_idx", "src_idx", "dst_idx")
+# whole-block outputs of an fp16 model against the reference's fp32 run, relative to the output scale (the self-attention
+# segment alone: north_star's 1e-3); see test_full_block_vs_reference_chain
+FULL_BLOCK_TOL = 2e-3
 
 
 @pytest.fixture(scope="module")
@@ -767,6 +770,83 @@ def test_default_fp16_path_vs_reference_chain(L, name, proj, monkeypatch):
         for n in calls:
             setattr(L, n, orig[n])
     assert calls["linear_rows" if proj == "auto" else "linear_panels"] > 0, calls
+    vidtome_amd.remove_patch(unet)
+
+
+@pytest.mark.parametrize("name,mode", [("fullblock16_cfg_f4_d40", "panels"), ("fullblock16_cfg_f4_d40", "blas"),
+                                       ("fullblock16_pnp_f4_d64", "panels"), ("fullblock16_pnp_f4_d64", "blas")])
+def test_full_block_vs_reference_chain(L, name, mode, monkeypatch):
+    """The WHOLE patched block against the reference's recorded `ToMeBlock.forward` (tests/golden/make_golden_fullblock.py):
+    a full SD block -- norm1 / attn1 on merged tokens, norm2 / attn2 over 77 conditioning tokens (the reference's own
+    `sa_forward` cross branch), norm3 / GEGLU feed-forward -- called by a stand-in Transformer2DModel with every keyword of
+    patch.py:128-137, CPU fp32 reference on an fp16-grid model, multi-chunk chains with global merging (both coins, a
+    single-frame chunk; PnP batch 3 with aligned matching and shared probabilities).  The fp16 model's patched forward runs
+    the panel-GEMM path (default: vtm_layernorm_panels / vtm_linear_panels / vtm_ff_geglu / vtm_attention_kv) and, forced, the
+    library-GEMM path.  Tolerance FULL_BLOCK_TOL of the output scale: the segment alone is held to north_star's 1e-3
+    (test_default_fp16_path_vs_reference_chain); the full block adds two more fp16 residual roundings, a rounded
+    LayerNorm -> GEMM chain twice over and the gated activation's three roundings on top of it."""
+    import vidtome_amd
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import pnp
+    from inputs import portable_weight
+    from standin import Pipe, StandInUNet, load_block_weights
+
+    monkeypatch.setattr(vpatch, "FF_MODE", mode)
+    monkeypatch.setattr(vpatch, "PROJ_MODE", "auto" if mode == "panels" else "blas")
+    monkeypatch.setattr(vpatch, "FUSED_PROJ", mode == "panels")
+    cfg, z = load_chain(name)
+    keep = cfg["keep_blocks"]
+    unet = load_block_weights(StandInUNet(cfg["C"], cfg["heads"], True, cfg["cond_dim"]), z, DEV, torch.float16,
+                              portable=portable_weight)
+    pipe = Pipe(unet)
+    if cfg["injection"] is not None:
+        pnp.register_attention_control(pipe, cfg["injection"], cfg["B"])
+        pnp.register_time(pipe, cfg["t"])
+    vidtome_amd.apply_patch(unet, local_merge_ratio=cfg["local_ratio"], merge_global=cfg["merge_global"],
+                            global_merge_ratio=cfg["global_ratio"], batch_size=cfg["B"], align_batch=cfg["align"],
+                            target_stride=4, global_rand=0.5)
+    torch.set_rng_state(torch.from_numpy(z["rng_state"]))
+    calls = {"linear_panels": 0, "ff_geglu": 0, "layernorm_panels": 0, "attention_kv": 0}
+    orig = {n: getattr(L, n) for n in calls}
+
+    def counted(n):
+        def f(*a, **k):
+            calls[n] += 1
+            return orig[n](*a, **k)
+        return f
+    for n in calls:
+        setattr(L, n, counted(n))
+    try:
+        names = [str(s) for s in z["block_names"]]
+        worst = 0.0
+        for ck, F in enumerate(cfg["chunk_frames"]):
+            if ck in cfg.get("reset_before", []):
+                vidtome_amd.update_patch(unet, global_tokens=None)
+            hiddens = [(_t(z[f"c{ck}/b{bi}/hidden"]) if bi in keep else None) for bi in range(9)]
+            cond = _t(z[f"c{ck}/cond"])                                   # (B, 77, cond_dim) fp16, repeated over the frames
+            cond = cond[:, None].expand(-1, F, -1, -1).reshape(cfg["B"] * F, cond.shape[1], cond.shape[2]).contiguous()
+            latent = torch.zeros(tuple(int(v) for v in z[f"c{ck}/latent_shape"]), device=DEV, dtype=torch.float16)
+            with torch.no_grad():
+                outs = unet(latent, hiddens, encoder_hidden_states=cond, timestep=cfg["t"])
+            for bi in keep:
+                ref_out = z[f"c{ck}/b{bi}/out"]
+                err = np.abs(outs[bi].float().cpu().numpy() - ref_out).max() / max(1.0, np.abs(ref_out).max())
+                worst = max(worst, err)
+                assert err < FULL_BLOCK_TOL, (name, mode, ck, bi, err)
+            gts = vidtome_amd.collect_from_patch(unet, attr="global_tokens")
+            for bi in keep:
+                key = f"c{ck}/gt/{names[bi]}"
+                if key in z.files:
+                    ref = z[key].astype(np.float32)
+                    err = np.abs(gts[names[bi]].float().cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+                    assert err < 1e-3, (name, ck, bi, err)
+        print(name, mode, "worst full-block output error / scale:", worst, calls)
+    finally:
+        for n in calls:
+            setattr(L, n, orig[n])
+    if mode == "panels":        # the path under test really is the in-house one
+        assert calls["ff_geglu"] > 0 and calls["layernorm_panels"] > 0 and calls["linear_panels"] > 0, calls
+    assert calls["attention_kv"] > 0, calls
     vidtome_amd.remove_patch(unet)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks on the cfg-2 shapes (used while optimising; run under rocprofv3 for counters).
 
-    python tools/kbench.py match  [--shape top_l1|top_l2|top_g|mid_l1] [--iters 5] [--data n01|corr01|corr05|flat25|dup|zero|all]
+    python tools/kbench.py match  [--shape top_l1|top_l2|top_g|mid_l1] [--iters 5] [--data n01|corr01|corr002|corr05|smooth|flat25|dup|zero|all]
                                   (data regimes: vidtome_amd/sites.DATA_REGIMES; `zero` = corr05 with ONE zero token among the
                                    dst rows, which sends the whole call to the exact escape; `all` prints the table of regimes)
     python tools/kbench.py attn   [--M 52224 --d 40 --heads 8 --B 2] [--iters 3]
@@ -80,10 +80,10 @@ def main():
                 x[0, Ns + 5] = 0
             return x.to(dev)
 
-        regimes = ["n01", "corr01", "corr05", "flat25", "dup", "zero"] if a.data == "all" else [a.data]
+        regimes = ["n01", "corr01", "corr002", "corr05", "smooth", "flat25", "dup", "zero"] if a.data == "all" else [a.data]
         fl = 2.0 * B * Ns * Nd * C
         print(f"match {a.shape} B={B} Ns={Ns} Nd={Nd} C={C} align={a.align} seeded={bool(seed)}")
-        print(f"{'data':8s} {'filtered ms':>12s} {'alg TFLOP/s':>12s} {'exact ms':>9s} {'pairs/row':>10s} {'escape rows':>12s} {'whole-call':>10s} equal")
+        print(f"{'data':8s} {'filtered ms':>12s} {'nom TFLOP/s':>12s} {'exact ms':>9s} {'pairs/row':>10s} {'escape rows':>12s} {'whole-call':>10s} {'blocks alive':>12s} equal")
         for regime in regimes:
             x = tokens(regime)
             aop, _ = _lib.normalize_gather(x, None, ra)
@@ -92,9 +92,9 @@ def main():
             medf, bestf = timeit(lambda: _lib.match_filtered(x, None, ra, rb, a.align, seed=seed), a.iters)
             out, fl_ = _lib.match_filtered(x, None, ra, rb, a.align, want_flag=True, seed=seed)
             same = bool(torch.equal(out, _lib.match(aop, bop, Ns, Nd, a.align)))
-            f = fl_.tolist()                # [whole-call exact, non-finite, escape rows, refined pairs]
+            f = fl_.tolist()                # [whole-call exact, non-finite, escape rows, refined pairs, blocks tested, alive, 0, 0]
             rows = Ns if a.align else B * Ns
-            print(f"{regime:8s} {medf:12.3f} {fl / medf / 1e9:12.1f} {med:9.3f} {f[3] / rows:10.2f} {f[2]:12d} {f[0]:10d} {same}")
+            print(f"{regime:8s} {medf:12.3f} {fl / medf / 1e9:12.1f} {med:9.3f} {f[3] / rows:10.2f} {f[2]:12d} {f[0]:10d} {(f[5] / f[4] if f[4] else 1.0):12.3f} {same}")
             del aop, bop
     elif a.what == "attn":
         B, M, h, d = a.B, a.M, a.heads, a.d

@@ -143,6 +143,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 _WS: dict = {}
+_WS_LOCK = threading.Lock()
 
 
 def _workspace(tag: str, nbytes: int, device: torch.device) -> torch.Tensor:
@@ -152,20 +153,24 @@ def _workspace(tag: str, nbytes: int, device: torch.device) -> torch.Tensor:
     The host thread is part of the key: two threads launching on the same stream never share a buffer (their launches
     are not ordered against each other by anything the caller can rely on).  `remove_patch` drops the cache."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag, threading.get_ident())
-    buf = _WS.get(key)
+    buf = _WS.get(key)                     # (a thread only ever reads / replaces its OWN keys outside the lock)
     if buf is None or buf.numel() < nbytes:
-        if buf is None:
-            # a new (thread, stream, purpose): the moment to let go of the buffers of threads that no longer exist
-            alive = {t.ident for t in threading.enumerate()}
-            for k in [k for k in _WS if k[3] not in alive]:
-                del _WS[k]
-        buf = _WS[key] = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
+        new = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
+        with _WS_LOCK:                     # insertion + clean-up mutate the dict other threads iterate
+            if buf is None:
+                # a new (thread, stream, purpose): the moment to let go of the buffers of threads that no longer exist
+                alive = {t.ident for t in threading.enumerate()}
+                for k in [k for k in list(_WS) if k[3] not in alive]:
+                    _WS.pop(k, None)
+            _WS[key] = new
+        buf = new
     return buf
 
 
 def release_workspaces() -> None:
     """Drop the cached scratch buffers (they are re-created on demand)."""
-    _WS.clear()
+    with _WS_LOCK:
+        _WS.clear()
 
 
 def _req(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -233,7 +238,8 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
     nbytes = lib().vtm_match_filtered_ws_bytes(B, C, Ns, Nd, int(align))
     ws = _workspace("match", nbytes, x0.device)
     best = torch.empty((1 if align else B, Ns), dtype=torch.int64, device=x0.device)
-    flag = torch.zeros((4,), dtype=torch.int32, device=x0.device) if want_flag else None   # any, special, fifo, cap
+    # whole-call escape, unusable norm seen, escaped rows, refined pairs, blocks tested, blocks alive, 0, 0
+    flag = torch.zeros((8,), dtype=torch.int32, device=x0.device) if want_flag else None
     if seed is not None and SEED_MATCHER:
         sN, sL, pos1, table = seed
         if pos1 is not None and (pos1.dtype != torch.int32 or tuple(pos1.shape) != (B, P1) or not pos1.is_contiguous()):

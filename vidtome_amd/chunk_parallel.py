@@ -459,7 +459,8 @@ class AnchorExchange:
             ids, st.recv_ids = st.recv_ids.wait(), None
             self.bytes_received += got.numel() * got.element_size() + ids.numel() * 4
             if got.is_cuda:
-                got._vtm_cid = (ids, got._version)
+                from .patch import tag_content_ids
+                tag_content_ids(got, ids)
             return got
         if self.mode == "neighbour" and self.world > 1:
             B, C = like.shape[0], like.shape[2]
@@ -504,7 +505,8 @@ class AnchorExchange:
         st_lens = dict(st.lens)
         # lengths of the later chunks of this round: simulate on a COPY of the generator (their draws are consumed
         # for real when this rank replays them before its next chunk)
-        gen = torch.Generator(device="cpu").set_state(st.module.generator.get_state())
+        g0 = st.module.generator
+        gen = torch.Generator(device=g0.device).set_state(g0.get_state())
         self._skip_own_draws(gen, st, i)
         for c in range(i + 1, min(first + self.world, n)):
             st_lens[c] = simulate_block_draws(gen, self._frames[c], st.tsize, st.args, has_anchors=c > 0)["M_local"]
@@ -546,10 +548,9 @@ class AnchorExchange:
             st.carry = anchors
             return
         self._send(anchors.contiguous(), dst, st)
-        cid = getattr(anchors, "_vtm_cid", None)
-        if cid is not None and (cid[1] != anchors._version or tuple(cid[0].shape) != tuple(anchors.shape[:2])):
-            cid = None
-        ids = cid[0].contiguous() if cid is not None else \
+        from .patch import content_ids
+        cid = content_ids(anchors, anchors.device, anchors.dtype)
+        ids = cid.contiguous() if cid is not None else \
             torch.full(tuple(anchors.shape[:2]), -1, dtype=torch.int32, device=anchors.device)
         self._send(ids, dst, st)
 
@@ -617,6 +618,17 @@ def enable(model: torch.nn.Module, exchange: AnchorExchange) -> None:
     exchange.reset()
     for name, m in root.named_modules():
         if m.__class__.__name__ == "ToMeBlock":
+            # The exchange forks / replays the block generators on the HOST (begin_step, simulate_block_draws): with the
+            # opt-in device stream (apply_patch(generator_device="device") / VIDTOME_GENERATOR=device) the patched pre-hook
+            # would re-fork from torch.cuda.get_rng_state() at each rank's own first forward -- a rank-dependent fork point --
+            # and every replayed draw would cost a device sync.  Chunk-parallel runs therefore pin the CPU stream (the
+            # sequential run they are compared with uses the same one).
+            args = getattr(m, "_tome_info", {}).get("args", {})
+            from . import utils as _utils
+            if (args.get("generator_device") or _utils.GENERATOR_MODE) == "device":
+                raise RuntimeError("chunk_parallel.enable: the device generator stream (generator_device='device' / "
+                                   "VIDTOME_GENERATOR=device) cannot be combined with an AnchorExchange; patch the model with "
+                                   "generator_device='cpu'")
             m._vtm_exchange = exchange
             m._vtm_key = name
             exchange.register(name, m)

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const uint4 *__restrict__ bl, int64_t Ns, int64_t Nd, int64_t Ns_pad, int64_t Nd_pad, int64_t C_pad, int align,
     int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split, int total_src_tiles, int patch_tiles,
     unsigned int *__restrict__ amax, int *__restrict__ cnt, uint2 *__restrict__ cand, int cand_rows, int *__restrict__ flags,
-    const float *__restrict__ rest_a, const float *__restrict__ rest_bt, int KP) {
+    const float *__restrict__ rest_a, const float *__restrict__ rest_bt, int KP, int count_blocks) {
     // dst tile of one step: 8 panels x 128 rows x 16 B, hi and lo, double-buffered: 2 x 2 x 16 KiB
     __shared__ __attribute__((aligned(16))) uint4 sA[2][DST_LO ? 2 : 1][8 * FBD];
 
@@ -706,6 +706,17 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         if (sb == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_b), "s"(ph));
         else asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(dst) : "v"(voff_b), "s"(ph));
     };
+#ifdef VTM_TRY_BSKIP
+    // src fragments nobody will multiply: all 4 accumulator blocks of src block `sb` are dead (partial-sum pruning) and the
+    // load is for the SAME dst tile -> issue it with EXEC = 0: it still takes its slot in the in-order vmcnt sequence
+    // (the counted waits stay valid) but moves no data through the vector L1
+    auto load_b1m = [&](const char *pb_, int ks, int sb, u32x4 &dst, bool need) {
+        const char *ph = pb_ + ks * kstep_b;   // uniform
+        const int m = __builtin_amdgcn_readfirstlane(need ? -1 : 0);
+        if (sb == 0) asm volatile("s_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, %3\n\tglobal_load_dwordx4 %0, %1, %2\n\ts_mov_b64 exec, -1" : "=v"(dst) : "v"(voff_b), "s"(ph), "s"(m));
+        else asm volatile("s_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, %3\n\tglobal_load_dwordx4 %0, %1, %2 offset:512\n\ts_mov_b64 exec, -1" : "=v"(dst) : "v"(voff_b), "s"(ph), "s"(m));
+    };
+#endif
     auto load_a_piece = [&](const char *pa_, int buf_, int t) {
         const char *g = pa_ + (t >> 1) * panel_b + (t & 1) * 1024;
         const uint32_t lds_off = lds_a + (uint32_t)buf_ * (uint32_t)sizeof(sA[0]) + (uint32_t)t * 1024u;
@@ -776,8 +787,14 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                                 else fn[j] = __builtin_bit_cast(h16x8, sA[buf ^ 1][0][kh * FBD + j * 32 + l31]);)
                     ABL_NO_LDSREAD(fn[j] = fh[j];)
                 } else if (j < 6) {
+#ifdef VTM_TRY_BSKIP
+                    const bool need = ((live >> (4 * (j - 4))) & 0xfu) != 0u || (s >= 2 && wrap);
+                    if constexpr (s < 2) load_b1m(pb, s + 2, j - 4, rb[s + 2][j - 4][0], need);
+                    else load_b1m(pbn, s - 2, j - 4, rb[s - 2][j - 4][0], need);
+#else
                     ABL_BLOAD(if constexpr (s < 2) load_b1(pb, s + 2, j - 4, rb[s + 2][j - 4][0]);
                               else load_b1(pbn, s - 2, j - 4, rb[s - 2][j - 4][0]);)
+#endif
                 } else {
                     ABL_DMA(if constexpr (s == 0) load_a_piece(pa1, buf ^ 1, j - 4);   /* pieces 2, 3 of the next tile */
                             if constexpr (s == 3) load_a_piece(pa2, buf, j - 6);)      /* pieces 0, 1 of the one after */
@@ -796,7 +813,14 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         group(std::integral_constant<int, 2>{}, std::false_type{});
         ABL_BARRIER(asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NB + 2) : "memory"); __syncthreads();)
         group(std::integral_constant<int, 3>{}, std::false_type{});
-        if (kt + 1 == KP) live = prune_check(jt);      // (KP >= KT: pruning is off)
+        if (kt + 1 == KP) {                            // (KP >= KT: pruning is off)
+            live = prune_check(jt);
+            // counters for flags_out (only when the caller asked for them): 32 x 32 blocks tested / still alive
+            if (count_blocks && lane == 0) {
+                atomicAdd(&flags[4], 8);
+                atomicAdd(&flags[5], __popc(live));
+            }
+        }
         if (ABL_WRAP_COND(wrap && live)) collect_tile(jt, std::true_type{});
         if (wrap) {
             ++jt;
@@ -872,7 +896,11 @@ __global__ __launch_bounds__(256) void seed_kernel(const T *__restrict__ x0, int
 #pragma unroll
     for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (sub == 0) {
-        const float s = acc / (na[b * Ns + i] * nb[b * Nd + j]);
+        // two divisions, not one by the product of the norms: the product of two norms near 2^100 overflows (s = 0 -- or a
+        // denormal with a large relative error -- would pass the range check and could sit ABOVE every real score of the
+        // row).  The published value is lowered by a margin far above the fp32 error of this dot product (~1e-5 at
+        // C = 1280) so that it is provably <= the pair's filter score + EPS.
+        const float s = (acc / na[b * Ns + i]) / nb[b * Nd + j] - 1e-4f;
         if (s == s && __builtin_fabsf(s) <= 1.5f && !dry)    // (a row without a usable norm publishes nothing)
             atomicMax(&amax[align ? i : b * Ns + i], orderable(s));
     }
@@ -891,6 +919,17 @@ __global__ __launch_bounds__(256) void seed_kernel(const T *__restrict__ x0, int
 //      and, behind a barrier, works them off itself, a pair per thread and round: the canonical fp32 chain (x / norm with
 //      the operations and roundings of the IEEE expansion, the reciprocal refinement hoisted out of the channel loop),
 //      combined with the packed atomicMax of vtm_match.
+//   3a. (round 5) SCREEN.  With highly correlated frames a row has 4-17 candidates inside the fp16 filter's window
+//      (corr01: 5.6 per row over a step, 16 at the global levels) and the one-thread-per-pair chain -- 11 dependent
+//      instructions per channel -- was 5 ms of the 56 ms step.  When the workgroup's slice holds noticeably more pairs than
+//      rows, every pair first gets a FAST fp32 score: 8 lanes per pair, coalesced 16-byte pieces, plain fma partial sums,
+//      (sum / |a|) / |b| -- the arithmetic of seed_kernel.  It differs from the canonical chain value by at most
+//      EPS2 = (4 C + 32) 2^-24 (first-order bound: both are fp32 evaluations of the same cosine; the canonical one carries
+//      <= (2 C + 8) u -- rounded quotients, a C-term chain --, the fast one <= (1.2 C + 10) u, u = 2^-24), i.e. 7.8e-5 at
+//      C = 320 against the filter's 1.2e-3.  The argument that makes the filter exact applies verbatim with the smaller
+//      EPS: the true argmax columns of a row lie within W2 = 2 EPS2 of the row's largest fast score, so only those pairs
+//      run the canonical chain.  A fast score that is not a finite number in [-1.5, 1.5] (norm products near the fp32
+//      range) keeps its pair unconditionally and is not published.
 template <typename T>
 __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1,
                                                      int64_t P1, int64_t B, int64_t C,
@@ -902,9 +941,11 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
                                                      const uint2 *__restrict__ cand, int *__restrict__ ovf_cnt,
                                                      int *__restrict__ ovf_rows, uint2 *__restrict__ pairs,
                                                      const float *__restrict__ tile_rest, int64_t n_tile_rest,
-                                                     unsigned long long *__restrict__ best) {
+                                                     unsigned long long *__restrict__ best, float *__restrict__ pscore,
+                                                     float W2) {
     __shared__ int wave_tot[4];
     __shared__ int s_base;
+    __shared__ unsigned int s_rowmax[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- 1. a dst row without a usable norm anywhere?
     {
@@ -988,12 +1029,48 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
             if (__uint_as_float(cd.x) >= thr) pairs[at++] = make_uint2((uint32_t)row, cd.y);
         }
     }
+    // ---- 3a. screen (workgroup-uniform decision: worth it only when rows have several candidates)
+    const int rows_with_pairs = __syncthreads_count(ns > 0);
+    const bool screen = W2 > 0.0f && 2 * total >= 3 * rows_with_pairs && total > rows_with_pairs;
+    s_rowmax[tid] = 0u;                                   // (orderable: below every score)
     __threadfence_block();
     __syncthreads();
+    if (screen) {
+        const int sub = tid & 7;
+        for (int p = base + (tid >> 3); p < base + total; p += 32) {
+            const uint2 pr = pairs[p];
+            const int64_t prow = pr.x;
+            const uint32_t col = pr.y;
+            const int64_t i = align ? prow : prow % Ns;
+            const int64_t bi = align ? (int64_t)(col / (uint32_t)Nd) : prow / Ns;
+            const int64_t j = align ? (int64_t)(col % (uint32_t)Nd) : (int64_t)col;
+            const T *pa = pool_row(x0, P0, x1, P1, bi, a_rows[bi * Ns + i], C);
+            const T *pb = pool_row(x0, P0, x1, P1, bi, b_rows[bi * Nd + j], C);
+            float acc = 0.0f;
+            for (int64_t k = sub * 8; k < C; k += 64) {
+                float fa[8], fb[8];
+                load8(pa + k, fa);
+                load8(pb + k, fb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(fa[e], fb[e], acc);
+            }
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (sub == 0) {
+                float sc = (acc / na[bi * Ns + i]) / nb[bi * Nd + j];
+                if (sc == sc && __builtin_fabsf(sc) <= 1.5f) atomicMax(&s_rowmax[prow - (int64_t)blockIdx.x * 256], orderable(sc));
+                else sc = INFINITY;                        // unknown: the pair is kept whatever the row's maximum
+                pscore[p] = sc;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     for (int p = base + tid; p < base + total; p += 256) {
         const uint2 pr = pairs[p];
         const int64_t prow = pr.x;
         const uint32_t col = pr.y;
+        if (screen && !(pscore[p] >= from_orderable(s_rowmax[prow - (int64_t)blockIdx.x * 256]) - W2)) continue;
         const int64_t i = align ? prow : prow % Ns;
         const int64_t bi = align ? (int64_t)(col / (uint32_t)Nd) : prow / Ns;
         const int64_t j = align ? (int64_t)(col % (uint32_t)Nd) : (int64_t)col;
@@ -1279,7 +1356,7 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf_cnt, ovf, pairs, rest_a, rest_bt, total;
+    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf_cnt, ovf, pairs, pscore, rest_a, rest_bt, total;
     int64_t Ns_pad, Nd_pad, C64;
 };
 
@@ -1304,6 +1381,7 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     L.cand = take((size_t)rows_out * CAP * 8);
     L.ovf = take((size_t)rows_out * 4);
     L.pairs = take((size_t)rows_out * CAP * 8);
+    L.pscore = take((size_t)rows_out * CAP * 4);     // fast fp32 scores of the pairs (refine_kernel's screen)
     L.rest_a = take((size_t)B * L.Ns_pad * 4);
     L.rest_bt = take((size_t)B * (L.Nd_pad / FBD) * 4);
     L.total = o;
@@ -1443,17 +1521,25 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
         const int tiles_per_split = (int)vtm::cdiv(nd_tiles, nsplit);
         nsplit = (int)vtm::cdiv(nd_tiles, tiles_per_split);
         const int64_t grid = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit;
+        int64_t c_run = L.C64;
+        if (const char *dbg = getenv("VTM_DEBUG_KSTEPS")) {   // timing hook (WRONG results): only the first v 64-channel steps
+            const int v = atoi(dbg);
+            if (v >= 1 && (int64_t)v * FBK < L.C64) c_run = (int64_t)v * FBK;
+        }
         hipLaunchKernelGGL(filter_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
-                           L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles, amax,
+                           L.Nd_pad, c_run, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles, amax,
                            cnt, cand, (int)rows_out, flags, prune ? (const float *)rest_a : nullptr,
-                           prune ? (const float *)rest_bt : nullptr, prune ? KP : 0x7fffffff);
+                           prune ? (const float *)rest_bt : nullptr, prune ? KP : 0x7fffffff, flags_out != nullptr ? 1 : 0);
     }
     {
         const dim3 grid((unsigned)vtm::cdiv(rows_out, 256)), block(256);
         unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
         const int64_t n_tile_rest = B * (L.Nd_pad / FBD);
+        // window of the refine pass's screen: 2 x the bound on |fast fp32 score - canonical chain value| (refine_kernel, 3a)
+        float W2 = 2.0f * (4.0f * (float)C + 32.0f) * 0x1p-24f;
+        if (getenv("VTM_DEBUG_NOSCREEN")) W2 = 0.0f;          // A/B hook
 #define VTM_REFINE_ARGS a_rows, Ns, b_rows, Nd, na, nb, align, flags, rows_out, amax, cnt, cand, ovf_cnt, ovf_rows, pairs, \
-                        (const float *)rest_bt, n_tile_rest, bp
+                        (const float *)rest_bt, n_tile_rest, bp, (float *)(w + L.pscore), W2
         // the escape: a fixed grid strides over the (device-side) lists of overflowed rows -- normally empty, then the
         // workgroups leave at once; dst splits of >= 8 tiles so that a short list still spreads over the chip
         const int xd_tiles = (int)vtm::cdiv(Nd, XD);
@@ -1486,7 +1572,7 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
     if (int rc = vtm::launch_status("vtm_match_filtered")) return rc;
 
     if (flags_out) {
-        const hipError_t e = hipMemcpyAsync(flags_out, flags, 4 * sizeof(int), hipMemcpyDeviceToDevice, s);
+        const hipError_t e = hipMemcpyAsync(flags_out, flags, 8 * sizeof(int), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: copy: %s", hipGetErrorString(e));
     }
     return VTM_OK;

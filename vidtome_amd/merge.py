@@ -99,7 +99,11 @@ def global_level(x0: torch.Tensor, anchors: torch.Tensor, cur_local: Optional[to
     if cur_local is None:
         cur_local = torch.arange(Ml, dtype=torch.int32, device=x0.device).expand(B, Ml).contiguous()
     seed = table = None
-    if tokens and _lib.SEED_MATCHER and (anchor_positions is not None or not local_is_src):
+    # a seed pairs a src row with the dst row at the same token position: one side of the level is the anchors, so their
+    # positions must be known whichever side it is (local-is-src: the position -> dst row table is built from them;
+    # local-is-dst: they are the src rows).  Anchors that arrived without positions (an exchange's single-message form, a
+    # user-supplied tensor): no table, no seed launch
+    if tokens and _lib.SEED_MATCHER and anchor_positions is not None:
         table = torch.empty((B, tokens), dtype=torch.int32, device=x0.device)
         seed = (tokens, L, anchor_positions, table)
     parts = _lib.partition_global(cur_local, L, anchors.shape[1], local_is_src, table, tokens or 0, anchor_positions)

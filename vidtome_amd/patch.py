@@ -110,6 +110,47 @@ class MergePlan:
         return self._merged
 
 
+CHECK_CONTENT_IDS = os.environ.get("VIDTOME_CHECK_CID", "0") == "1"
+
+
+def tag_content_ids(tokens: torch.Tensor, ids: torch.Tensor) -> None:
+    """Attach content ids (B, M) int32 -- equal id = byte-identical rows; -1 = none -- to an anchor tensor.  RESULTS depend
+    on them (the attention folds rows with equal ids into one key), so the tag also records what the tensor looked like
+    when the ids were computed: torch's version counter, the storage address and the shape.  `content_ids` drops the ids
+    when any of them changed.  What no tag can see is a write that bypasses torch (`.data`, a raw pointer, another library's
+    kernel): `module.global_tokens` must not be edited that way; VIDTOME_CHECK_CID=1 verifies the claim on every use (one
+    device sync per block: a debugging aid)."""
+    tokens._vtm_cid = (ids, tokens._version, tokens.data_ptr(), tuple(tokens.shape))
+
+
+def content_ids(tokens: torch.Tensor, device, dtype) -> Optional[torch.Tensor]:
+    """The ids `tag_content_ids` attached, or None when the tag is missing or stale."""
+    tag = getattr(tokens, "_vtm_cid", None)
+    if tag is None or len(tag) != 4:
+        return None
+    ids, version, ptr, shape = tag
+    if (version != tokens._version or ptr != tokens.data_ptr() or shape != tuple(tokens.shape)
+            or tuple(ids.shape) != tuple(tokens.shape[:2]) or ids.device != torch.device(device) or tokens.dtype != dtype):
+        return None
+    if CHECK_CONTENT_IDS:
+        # rows with equal ids must be equal: compare every row with the first row of its id
+        B, M = ids.shape
+        for b in range(B):
+            idb = ids[b].long()
+            valid = idb >= 0
+            if not bool(valid.any()):
+                continue
+            first = torch.full((int(idb.max()) + 1,), M, dtype=torch.long, device=ids.device)
+            first.scatter_reduce_(0, idb[valid], torch.arange(M, device=ids.device)[valid], reduce="amin")
+            ref = tokens[b][first[idb.clamp(min=0)].clamp(max=M - 1)]
+            same = (tokens[b].view(torch.int16 if tokens.element_size() == 2 else torch.int32)
+                    == ref.view(torch.int16 if tokens.element_size() == 2 else torch.int32)).all(dim=1)
+            if not bool((same | ~valid).all()):
+                raise RuntimeError("vidtome_amd: anchor rows with equal content ids differ -- module.global_tokens was "
+                                   "modified behind torch's back (VIDTOME_CHECK_CID=1)")
+    return ids
+
+
 def _draw_coin(generator: torch.Generator) -> float:
     """patch.py:62: ``torch.rand(1, generator=generator, device=generator.device)``."""
     return float(torch.rand(1, generator=generator, device=generator.device))
@@ -184,11 +225,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 gt_pos = None
             # content ids (equal id = identical rows), same lifetime rule -- and, because RESULTS depend on them, only while
             # nobody has written to the tensor since (in-place edits bump torch's version counter)
-            gt_cid = getattr(gt, "_vtm_cid", None) if gt is not None else None
-            if gt_cid is not None and (tuple(gt_cid[0].shape) != tuple(gt.shape[:2]) or gt_cid[0].device != xj.device
-                                       or gt_cid[1] != gt._version or gt.dtype != xj.dtype):
-                gt_cid = None
-            gt_cid = gt_cid[0] if gt_cid is not None else None
+            gt_cid = content_ids(gt, xj.device, xj.dtype) if gt is not None else None
             if gt is not None:
                 gt = gt.to(xj).contiguous()                                        # patch.py:65,70
                 coin = _draw_coin(generator)
@@ -233,7 +270,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 if anchors_pos is not None:
                     anchors_out._vtm_pos = anchors_pos
                 if anchors_cid is not None:
-                    anchors_out._vtm_cid = (anchors_cid, anchors_out._version)
+                    tag_content_ids(anchors_out, anchors_cid)
             elif plan.global_level is None:
                 # patch.py:82: first chunk of a step stores its local tokens (device-resident, shared
                 # with `merged`, which nothing mutates)
