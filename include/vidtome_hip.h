@@ -109,7 +109,8 @@ int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd,
  * usable norm was seen, [2] = number of rows recomputed by the escape because their candidate list overflowed or their own
  * norm was unusable, [3] = number of (row, dst) pairs the refine pass evaluated, [4] = 32 x 32 score blocks the filter's
  * partial-sum pruning tested, [5] = blocks still alive after the test (the others skipped their remaining MFMAs; both 0
- * when the rows are too short to prune), [6], [7] = 0 (reserved).  The block counters are only collected when flags_out
+ * when the rows are too short to prune), [6] = work items the escape launch handed out dynamically (internal), [7] = 0
+ * (reserved).  The block counters are only collected when flags_out
  * is given.  Derivation of the window: vidtome_amd/csrc/match_filter.hip.
  *
  * vtm_match_filtered_seeded -- the same result, usually faster on video tokens: before the filter starts every src row gets

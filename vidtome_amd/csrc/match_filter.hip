@@ -365,6 +365,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const int KT = (int)(C_pad / FBK);
     const int64_t G = C_pad / 8;
     const int steps = (jt1 - jt0) * KT;
+    int n_tested = 0, n_alive = 0;            // (wave-uniform) pruning statistics, published once per wave
     const uint4 *srch = ah + (int64_t)bi * G * Ns_pad, *srcl = al + (int64_t)bi * G * Ns_pad;
     const uint4 *dsth = bh + (int64_t)bi * G * Nd_pad, *dstl = bl + (int64_t)bi * G * Nd_pad;
     const int64_t srow0 = (int64_t)st_ * FBS + wave * 64;
@@ -706,17 +707,6 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         if (sb == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_b), "s"(ph));
         else asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(dst) : "v"(voff_b), "s"(ph));
     };
-#ifdef VTM_TRY_BSKIP
-    // src fragments nobody will multiply: all 4 accumulator blocks of src block `sb` are dead (partial-sum pruning) and the
-    // load is for the SAME dst tile -> issue it with EXEC = 0: it still takes its slot in the in-order vmcnt sequence
-    // (the counted waits stay valid) but moves no data through the vector L1
-    auto load_b1m = [&](const char *pb_, int ks, int sb, u32x4 &dst, bool need) {
-        const char *ph = pb_ + ks * kstep_b;   // uniform
-        const int m = __builtin_amdgcn_readfirstlane(need ? -1 : 0);
-        if (sb == 0) asm volatile("s_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, %3\n\tglobal_load_dwordx4 %0, %1, %2\n\ts_mov_b64 exec, -1" : "=v"(dst) : "v"(voff_b), "s"(ph), "s"(m));
-        else asm volatile("s_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, %3\n\tglobal_load_dwordx4 %0, %1, %2 offset:512\n\ts_mov_b64 exec, -1" : "=v"(dst) : "v"(voff_b), "s"(ph), "s"(m));
-    };
-#endif
     auto load_a_piece = [&](const char *pa_, int buf_, int t) {
         const char *g = pa_ + (t >> 1) * panel_b + (t & 1) * 1024;
         const uint32_t lds_off = lds_a + (uint32_t)buf_ * (uint32_t)sizeof(sA[0]) + (uint32_t)t * 1024u;
@@ -787,14 +777,8 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
                                 else fn[j] = __builtin_bit_cast(h16x8, sA[buf ^ 1][0][kh * FBD + j * 32 + l31]);)
                     ABL_NO_LDSREAD(fn[j] = fh[j];)
                 } else if (j < 6) {
-#ifdef VTM_TRY_BSKIP
-                    const bool need = ((live >> (4 * (j - 4))) & 0xfu) != 0u || (s >= 2 && wrap);
-                    if constexpr (s < 2) load_b1m(pb, s + 2, j - 4, rb[s + 2][j - 4][0], need);
-                    else load_b1m(pbn, s - 2, j - 4, rb[s - 2][j - 4][0], need);
-#else
                     ABL_BLOAD(if constexpr (s < 2) load_b1(pb, s + 2, j - 4, rb[s + 2][j - 4][0]);
                               else load_b1(pbn, s - 2, j - 4, rb[s - 2][j - 4][0]);)
-#endif
                 } else {
                     ABL_DMA(if constexpr (s == 0) load_a_piece(pa1, buf ^ 1, j - 4);   /* pieces 2, 3 of the next tile */
                             if constexpr (s == 3) load_a_piece(pa2, buf, j - 6);)      /* pieces 0, 1 of the one after */
@@ -815,11 +799,8 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
         group(std::integral_constant<int, 3>{}, std::false_type{});
         if (kt + 1 == KP) {                            // (KP >= KT: pruning is off)
             live = prune_check(jt);
-            // counters for flags_out (only when the caller asked for them): 32 x 32 blocks tested / still alive
-            if (count_blocks && lane == 0) {
-                atomicAdd(&flags[4], 8);
-                atomicAdd(&flags[5], __popc(live));
-            }
+            n_tested += 8;                             // 32 x 32 blocks tested / still alive (flags_out[4], [5])
+            n_alive += __popc(live);
         }
         if (ABL_WRAP_COND(wrap && live)) collect_tile(jt, std::true_type{});
         if (wrap) {
@@ -832,6 +813,11 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused prefetches of the last step
+    // one pair of atomics per WAVE: per tile they serialise on two words (a counting call took 4.5 instead of 0.75 ms)
+    if (count_blocks && lane == 0 && n_tested) {
+        atomicAdd(&flags[4], n_tested);
+        atomicAdd(&flags[5], n_alive);
+    }
 
     // flush: the entries still inside the window of this lane's final maximum
 #pragma unroll
@@ -870,7 +856,8 @@ __global__ __launch_bounds__(256) void seed_kernel(const T *__restrict__ x0, int
                                                    const int32_t *__restrict__ b_rows, int64_t Nd,
                                                    const float *__restrict__ na, const float *__restrict__ nb, int align,
                                                    int64_t seed_L, int64_t N, const int32_t *__restrict__ pos1,
-                                                   const int32_t *__restrict__ table, unsigned int *__restrict__ amax, int dry) {
+                                                   const int32_t *__restrict__ table, unsigned int *__restrict__ amax, int dry,
+                                                   unsigned int *__restrict__ seed_lb, float lb_margin) {
     constexpr int LPR = 8;                                   // lanes per row
     const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;     // (sample, src row)
     const int sub = threadIdx.x & (LPR - 1);
@@ -900,14 +887,21 @@ __global__ __launch_bounds__(256) void seed_kernel(const T *__restrict__ x0, int
         // denormal with a large relative error -- would pass the range check and could sit ABOVE every real score of the
         // row).  The published value is lowered by a margin far above the fp32 error of this dot product (~1e-5 at
         // C = 1280) so that it is provably <= the pair's filter score + EPS.
-        const float s = (acc / na[b * Ns + i]) / nb[b * Nd + j] - 1e-4f;
-        if (s == s && __builtin_fabsf(s) <= 1.5f && !dry)    // (a row without a usable norm publishes nothing)
+        const float s0 = (acc / na[b * Ns + i]) / nb[b * Nd + j];
+        const float s = s0 - 1e-4f;
+        if (s == s && __builtin_fabsf(s) <= 1.5f && !dry) {  // (a row without a usable norm publishes nothing)
             atomicMax(&amax[align ? i : b * Ns + i], orderable(s));
+            // ... and, kept apart from the filter's running maximum (which an overflowing row overwrites with +inf), a
+            // CERTIFIED lower bound of the row's exact maximum for exact_rows_kernel's tile pruning: this pair's canonical
+            // chain value is >= s0 - lb_margin (|fast fp32 dot - canonical chain| <= (4 C + 32) 2^-24, both evaluate the
+            // same cosine with the same two norms)
+            atomicMax(&seed_lb[align ? i : b * Ns + i], orderable(s0 - lb_margin));
+        }
     }
 }
 
 // ---- refine: the candidates inside the window of each row's final approximate maximum, re-evaluated exactly ----
-// One launch (rounds 1-3: a compaction kernel + a pair kernel).  A workgroup owns 256 rows:
+// One launch (rounds 1-3: a compaction kernel + a pair kernel).  A workgroup owns RROWS rows:
 //   1. it decides what kind of call this is -- every workgroup scans the same few hundred per-tile values prep_operand left
 //      (tile_rest: +inf marks a dst tile holding a row without a finite positive norm in [2^-100, 2^100]; zero token -> NaN
 //      xhat, merge.py:84 has no eps) and reaches the same answer without a grid-wide exchange: such a call is recomputed as a
@@ -919,17 +913,18 @@ __global__ __launch_bounds__(256) void seed_kernel(const T *__restrict__ x0, int
 //      and, behind a barrier, works them off itself, a pair per thread and round: the canonical fp32 chain (x / norm with
 //      the operations and roundings of the IEEE expansion, the reciprocal refinement hoisted out of the channel loop),
 //      combined with the packed atomicMax of vtm_match.
-//   3a. (round 5) SCREEN.  With highly correlated frames a row has 4-17 candidates inside the fp16 filter's window
-//      (corr01: 5.6 per row over a step, 16 at the global levels) and the one-thread-per-pair chain -- 11 dependent
-//      instructions per channel -- was 5 ms of the 56 ms step.  When the workgroup's slice holds noticeably more pairs than
-//      rows, every pair first gets a FAST fp32 score: 8 lanes per pair, coalesced 16-byte pieces, plain fma partial sums,
-//      (sum / |a|) / |b| -- the arithmetic of seed_kernel.  It differs from the canonical chain value by at most
-//      EPS2 = (4 C + 32) 2^-24 (first-order bound: both are fp32 evaluations of the same cosine; the canonical one carries
-//      <= (2 C + 8) u -- rounded quotients, a C-term chain --, the fast one <= (1.2 C + 10) u, u = 2^-24), i.e. 7.8e-5 at
-//      C = 320 against the filter's 1.2e-3.  The argument that makes the filter exact applies verbatim with the smaller
-//      EPS: the true argmax columns of a row lie within W2 = 2 EPS2 of the row's largest fast score, so only those pairs
-//      run the canonical chain.  A fast score that is not a finite number in [-1.5, 1.5] (norm products near the fp32
-//      range) keeps its pair unconditionally and is not published.
+//   (round 5) A workgroup owns RROWS = 64 rows, not 256: with 4-17 candidates per row (frames of one clip at low noise:
+//      5.6 pairs per row over a step, 16 at the global levels) a 256-row workgroup walks 16 rounds of pairs while the
+//      launch has one wave per SIMD; four times as many workgroups put four waves on every SIMD.
+//   (A screen that scored every pair with a fast, coalesced fp32 dot product first -- 8 lanes per pair, window 2 EPS2 =
+//   2 (4 C + 32) 2^-24 -- and ran the canonical chain only on the pairs within that window of the row's best was written
+//   twice, exact both times, and SLOWER both times: top global level, 16 pairs per row, 1.51 vs 1.35 ms per call; it adds a
+//   pass over the same rows, and the chain pass is not limited by its instruction count.  profiles/r05_d_refine_ab.txt.)
+#ifndef VTM_RROWS
+#define VTM_RROWS 64        // (A/B build switch: 256 = rounds 1-4)
+#endif
+constexpr int RROWS = VTM_RROWS;   // rows per refine workgroup (256 threads)
+static_assert(RROWS == 32 || RROWS == 64 || RROWS == 128 || RROWS == 256, "refine rows per workgroup");
 template <typename T>
 __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1,
                                                      int64_t P1, int64_t B, int64_t C,
@@ -941,11 +936,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
                                                      const uint2 *__restrict__ cand, int *__restrict__ ovf_cnt,
                                                      int *__restrict__ ovf_rows, uint2 *__restrict__ pairs,
                                                      const float *__restrict__ tile_rest, int64_t n_tile_rest,
-                                                     unsigned long long *__restrict__ best, float *__restrict__ pscore,
-                                                     float W2) {
+                                                     unsigned long long *__restrict__ best) {
     __shared__ int wave_tot[4];
     __shared__ int s_base;
-    __shared__ unsigned int s_rowmax[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- 1. a dst row without a usable norm anywhere?
     {
@@ -960,8 +953,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
         }
     }
     // ---- 2. per row
-    const int64_t row = (int64_t)blockIdx.x * 256 + tid;
-    const bool live = row < rows_out;
+    const int64_t row = (int64_t)blockIdx.x * RROWS + tid;
+    const bool live = tid < RROWS && row < rows_out;      // (the rows sit in wave 0; all four waves work the pairs off)
     const int n = live ? cnt[row] : 0;
     const float thr = live ? from_orderable(amax[row]) - WINDOW : 0.0f;
     bool bad_src = false;
@@ -1029,48 +1022,12 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
             if (__uint_as_float(cd.x) >= thr) pairs[at++] = make_uint2((uint32_t)row, cd.y);
         }
     }
-    // ---- 3a. screen (workgroup-uniform decision: worth it only when rows have several candidates)
-    const int rows_with_pairs = __syncthreads_count(ns > 0);
-    const bool screen = W2 > 0.0f && 2 * total >= 3 * rows_with_pairs && total > rows_with_pairs;
-    s_rowmax[tid] = 0u;                                   // (orderable: below every score)
     __threadfence_block();
     __syncthreads();
-    if (screen) {
-        const int sub = tid & 7;
-        for (int p = base + (tid >> 3); p < base + total; p += 32) {
-            const uint2 pr = pairs[p];
-            const int64_t prow = pr.x;
-            const uint32_t col = pr.y;
-            const int64_t i = align ? prow : prow % Ns;
-            const int64_t bi = align ? (int64_t)(col / (uint32_t)Nd) : prow / Ns;
-            const int64_t j = align ? (int64_t)(col % (uint32_t)Nd) : (int64_t)col;
-            const T *pa = pool_row(x0, P0, x1, P1, bi, a_rows[bi * Ns + i], C);
-            const T *pb = pool_row(x0, P0, x1, P1, bi, b_rows[bi * Nd + j], C);
-            float acc = 0.0f;
-            for (int64_t k = sub * 8; k < C; k += 64) {
-                float fa[8], fb[8];
-                load8(pa + k, fa);
-                load8(pb + k, fb);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(fa[e], fb[e], acc);
-            }
-#pragma unroll
-            for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-            if (sub == 0) {
-                float sc = (acc / na[bi * Ns + i]) / nb[bi * Nd + j];
-                if (sc == sc && __builtin_fabsf(sc) <= 1.5f) atomicMax(&s_rowmax[prow - (int64_t)blockIdx.x * 256], orderable(sc));
-                else sc = INFINITY;                        // unknown: the pair is kept whatever the row's maximum
-                pscore[p] = sc;
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
     for (int p = base + tid; p < base + total; p += 256) {
         const uint2 pr = pairs[p];
         const int64_t prow = pr.x;
         const uint32_t col = pr.y;
-        if (screen && !(pscore[p] >= from_orderable(s_rowmax[prow - (int64_t)blockIdx.x * 256]) - W2)) continue;
         const int64_t i = align ? prow : prow % Ns;
         const int64_t bi = align ? (int64_t)(col / (uint32_t)Nd) : prow / Ns;
         const int64_t j = align ? (int64_t)(col % (uint32_t)Nd) : (int64_t)col;
@@ -1149,7 +1106,8 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
     const int32_t *__restrict__ a_rows, int64_t Ns, const int32_t *__restrict__ b_rows, int64_t Nd,
     const float *__restrict__ na, const float *__restrict__ nb, int align, const int *__restrict__ flags,
     const int *__restrict__ ovf_cnt, const int *__restrict__ ovf_rows, unsigned long long *__restrict__ best, int nsplit,
-    int tiles_per_split) {
+    int tiles_per_split, const float *__restrict__ rest_a, const float *__restrict__ rest_bt, int KX, int64_t Ns_pad,
+    int64_t rest_tiles, const unsigned int *__restrict__ seed_lb, int *__restrict__ work) {
     __shared__ __attribute__((aligned(16))) float sD[8 * XPD * 4];
     __shared__ __attribute__((aligned(16))) float sS[8 * XPS * 4];
     constexpr int RAW = sizeof(T) == 4 ? 2 : 1;      // 16-byte loads per 8-channel piece
@@ -1163,7 +1121,12 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
     const int nd_tiles = (int)xcdiv(Nd, XD);
     const int prow = tid >> 2, pg = tid & 3;          // staging role: rows prow, prow + 64; 8-channel group pg of the step
 
-    for (int64_t item = blockIdx.x;; item += gridDim.x) {
+    // Work distribution: the first item of a workgroup is its block index (the normal case -- empty lists -- costs nothing),
+    // every further one comes off a device-side counter.  (A static stride hands a workgroup the SAME dst split every
+    // time when the split count divides the grid size; with tile pruning the splits inside a flat region cost 2.5x the
+    // others and a quarter of the workgroups did all the work: profiles/r05_e_xprune_ab.txt.)
+    __shared__ int64_t s_item;
+    for (int64_t item = blockIdx.x;;) {
         // ---- which (list, tile, sample, split) ----
         int64_t rem = item, l = 0, cnt_l = 0;
         for (; l < nlists; ++l) {
@@ -1178,7 +1141,16 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
         const int64_t bi = align ? rem % nsel : l;
         const int64_t tile = rem / nsel;
         const int jt0 = split * tiles_per_split, jt1 = min(jt0 + tiles_per_split, nd_tiles);
-        if (jt0 >= jt1) continue;
+        auto next_item = [&]() {                      // (all threads; two barriers: s_item is re-used)
+            __syncthreads();
+            if (tid == 0) s_item = (int64_t)gridDim.x + atomicAdd(work, 1);
+            __syncthreads();
+            return s_item;
+        };
+        if (jt0 >= jt1) {
+            item = next_item();
+            continue;
+        }
         auto listed = [&](int r) -> int64_t {         // row (within its sample) of tile entry r, -1 = past the list
             const int64_t at = tile * XS + r;
             if (at >= cnt_l) return -1;
@@ -1265,16 +1237,29 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
         f32x16 acc[4][XSB];
         float bestv[XSB];
         uint32_t besti[XSB];
+        // Tile pruning (round 5): after the KX 32-channel steps in front of the filter's pruning cut a pair's exact score is
+        // at most  partial + |xhat_a rest| |xhat_b rest|  (Cauchy-Schwarz; prep_operand's rest norms of the fp16 operands,
+        // 1024 xhat rounded, cover the exact ones with a factor 1 + 2^-9; + 1e-4 for the fp32 chain's own rounding).  If
+        // that is below a CERTIFIED lower bound of the row's maximum -- the lane's running exact maximum, or the seed pair's
+        // score -- for every row of the tile, no score of the tile can be (or tie) a row maximum and the remaining steps are
+        // skipped.  Flat regions are what fills this kernel's lists: a flat src row scores ~1 against the flat dst rows and
+        // ~0 against everything else, so the tiles outside the flat region die at 40 % depth.  NaN scores (a row without
+        // a usable norm) only occur in whole-call mode or for rows whose rest norm is +inf: no pruning there.
+        float floor_[XSB], rest_l[XSB];
+        const bool can_prune = !all && rest_a != nullptr && KX > 0 && KX < KT;
 #pragma unroll
         for (int sb = 0; sb < XSB; ++sb) {
             bestv[sb] = -INFINITY;
             besti[sb] = 0xffffffffu;
+            const int64_t i = listed(wave * (32 * XSB) + sb * 32 + l31);
+            floor_[sb] = (can_prune && i >= 0) ? from_orderable(seed_lb[align ? i : l * Ns + i]) : -INFINITY;
+            rest_l[sb] = (can_prune && i >= 0) ? rest_a[bi * Ns_pad + i] : 0.0f;
+            if (i < 0) floor_[sb] = INFINITY;            // rows past the list never keep a tile alive
         }
-        const int steps = (jt1 - jt0) * KT;
         dst_rows(jt0);
         fetch(0);
         int kt = 0, jt = jt0;
-        for (int st = 0; st < steps; ++st) {
+        while (jt < jt1) {
             __syncthreads();                           // everybody has read the previous step's panels
 #pragma unroll
             for (int u = 0; u < 2; ++u) stage(raw[u], dd[u], vd[u], sD, XPD, prow + 64 * u);
@@ -1282,7 +1267,7 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
             for (int u = 0; u < XSU; ++u) stage(raw[2 + u], ds[u], vs[u], sS, XPS, prow + 64 * u);
             __syncthreads();
             const bool wrap = kt + 1 == KT;
-            if (st + 1 < steps) {                      // next step's pieces fly behind this step's MFMAs
+            if (!wrap || jt + 1 < jt1) {               // next step's pieces fly behind this step's MFMAs
                 if (wrap) dst_rows(jt + 1);
                 fetch(wrap ? 0 : kt + 1);
             }
@@ -1338,6 +1323,29 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
                 }
                 ++jt;
                 kt = 0;
+            } else if (can_prune && kt + 1 == KX) {
+                // can any pair of this tile still reach a row maximum?
+                const float rb = rest_bt[bi * rest_tiles + jt] * (1.0f + 0x1p-9f) * INV_S2;
+                bool dead = true;
+#pragma unroll
+                for (int sb = 0; sb < XSB; ++sb) {
+                    float pm = -INFINITY;
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) pm = fmaxf(pm, acc[ib][sb][r]);
+                    dead = dead && (pm + rest_l[sb] * rb + 1e-4f < fmaxf(bestv[sb], floor_[sb]));
+                }
+                if (__syncthreads_and(dead)) {         // (workgroup-uniform) -> next tile; the fetch in flight is replaced
+                    ++jt;
+                    kt = 0;
+                    if (jt < jt1) {
+                        dst_rows(jt);
+                        fetch(0);
+                    }
+                } else {
+                    ++kt;
+                }
             } else {
                 ++kt;
             }
@@ -1350,13 +1358,14 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
                 atomicMax(&best[align ? i : l * Ns + i], ((unsigned long long)orderable(bestv[sb]) << 32) | (uint32_t)(~col));
             }
         }
+        item = next_item();
     }
 }
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t na, nb, ah, al, bh, bl, amax, cnt, cand, flags, ovf_cnt, ovf, pairs, pscore, rest_a, rest_bt, total;
+    size_t na, nb, ah, al, bh, bl, amax, cnt, seedlb, cand, flags, ovf_cnt, ovf, pairs, rest_a, rest_bt, total;
     int64_t Ns_pad, Nd_pad, C64;
 };
 
@@ -1376,12 +1385,12 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     L.bl = take(DST_LO ? (size_t)B * L.C64 * L.Nd_pad * 2 : 0);
     L.amax = take((size_t)rows_out * 4);      // amax, cnt and flags are contiguous: cleared together
     L.cnt = take((size_t)rows_out * 4);
+    L.seedlb = take((size_t)rows_out * 4);    // certified lower bounds of the rows' exact maxima (seed_kernel -> exact_rows_kernel)
     L.flags = take(256);
     L.ovf_cnt = take((size_t)B * 4);          // per-sample overflow-list lengths (inside the cleared range)
     L.cand = take((size_t)rows_out * CAP * 8);
     L.ovf = take((size_t)rows_out * 4);
     L.pairs = take((size_t)rows_out * CAP * 8);
-    L.pscore = take((size_t)rows_out * CAP * 4);     // fast fp32 scores of the pairs (refine_kernel's screen)
     L.rest_a = take((size_t)B * L.Ns_pad * 4);
     L.rest_bt = take((size_t)B * (L.Nd_pad / FBD) * 4);
     L.total = o;
@@ -1465,19 +1474,21 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
 
     if (seed_N > 0) {   // starting maxima from same-position guesses (a kernel boundary behind prep_operand: norms, cleared amax)
         const int dry = getenv("VTM_DEBUG_SEED_DRY") != nullptr;   // A/B hook: the seeds are computed and thrown away
+        unsigned int *seedlb = (unsigned int *)(w + L.seedlb);
+        const float lb_margin = (4.0f * (float)C + 32.0f) * 0x1p-24f + 1e-6f;   // see seed_kernel
         const dim3 grid((unsigned)vtm::cdiv(B * Ns * 8, 256)), block(256);
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(seed_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1, B, C, a_rows,
-                                   Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax, dry);
+                                   Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax, dry, seedlb, lb_margin);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(seed_kernel<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1, P1, B, C,
-                                   a_rows, Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax, dry);
+                                   a_rows, Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax, dry, seedlb, lb_margin);
                 break;
             default:
                 hipLaunchKernelGGL(seed_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0, (const vtm_bf16 *)x1, P1, B,
-                                   C, a_rows, Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax, dry);
+                                   C, a_rows, Ns, b_rows, Nd, (const float *)na, (const float *)nb, align, seed_L, seed_N, seed_pos1, seed_table, amax, dry, seedlb, lb_margin);
         }
     }
     {
@@ -1532,14 +1543,11 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
                            prune ? (const float *)rest_bt : nullptr, prune ? KP : 0x7fffffff, flags_out != nullptr ? 1 : 0);
     }
     {
-        const dim3 grid((unsigned)vtm::cdiv(rows_out, 256)), block(256);
+        const dim3 grid((unsigned)vtm::cdiv(rows_out, RROWS)), block(256);
         unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
         const int64_t n_tile_rest = B * (L.Nd_pad / FBD);
-        // window of the refine pass's screen: 2 x the bound on |fast fp32 score - canonical chain value| (refine_kernel, 3a)
-        float W2 = 2.0f * (4.0f * (float)C + 32.0f) * 0x1p-24f;
-        if (getenv("VTM_DEBUG_NOSCREEN")) W2 = 0.0f;          // A/B hook
 #define VTM_REFINE_ARGS a_rows, Ns, b_rows, Nd, na, nb, align, flags, rows_out, amax, cnt, cand, ovf_cnt, ovf_rows, pairs, \
-                        (const float *)rest_bt, n_tile_rest, bp, (float *)(w + L.pscore), W2
+                        (const float *)rest_bt, n_tile_rest, bp
         // the escape: a fixed grid strides over the (device-side) lists of overflowed rows -- normally empty, then the
         // workgroups leave at once; dst splits of >= 8 tiles so that a short list still spreads over the chip
         const int xd_tiles = (int)vtm::cdiv(Nd, XD);
@@ -1548,25 +1556,29 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
         const int xtps = (int)vtm::cdiv(xd_tiles, xsplit);
         xsplit = (int)vtm::cdiv(xd_tiles, xtps);
         const dim3 xgrid((unsigned)((XS == 128 ? 2 : 1) * vtm::device_cus()));
+        // exact_rows_kernel's tile pruning: the rest norms prep_operand wrote for the filter's cut, in 32-channel steps
+        const int KX = getenv("VTM_DEBUG_NOXPRUNE") ? 0 : (int)(cut / XK);
+#define VTM_XPRUNE_ARGS (const float *)rest_a, (const float *)rest_bt, KX, L.Ns_pad, L.Nd_pad / FBD, (const unsigned int *)(w + L.seedlb), \
+                        flags + 6
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(refine_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
                                    B, C, VTM_REFINE_ARGS);
                 hipLaunchKernelGGL(exact_rows_kernel<float>, xgrid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt, ovf_rows, bp, xsplit, xtps);
+                                   B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt, ovf_rows, bp, xsplit, xtps, VTM_XPRUNE_ARGS);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(refine_kernel<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
                                    P1, B, C, VTM_REFINE_ARGS);
                 hipLaunchKernelGGL(exact_rows_kernel<__half>, xgrid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt, ovf_rows, bp, xsplit, xtps);
+                                   P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt, ovf_rows, bp, xsplit, xtps, VTM_XPRUNE_ARGS);
                 break;
             default:
                 hipLaunchKernelGGL(refine_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
                                    (const vtm_bf16 *)x1, P1, B, C, VTM_REFINE_ARGS);
                 hipLaunchKernelGGL(exact_rows_kernel<vtm_bf16>, xgrid, block, 0, s, (const vtm_bf16 *)x0, P0,
                                    (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt,
-                                   ovf_rows, bp, xsplit, xtps);
+                                   ovf_rows, bp, xsplit, xtps, VTM_XPRUNE_ARGS);
         }
     }
     if (int rc = vtm::launch_status("vtm_match_filtered")) return rc;
