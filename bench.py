@@ -435,7 +435,7 @@ def pmc_traffic():
     x 52 224 keys).  NOT measured in this run: read from the committed rocprofv3 PMC passes under profiles/
     (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, separate --pmc runs of tools/kbench.py on the same shape).
     Returns (bytes or None, source string)."""
-    for fname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         d, src = _profile_json(fname)
         if not d:
             continue
@@ -449,7 +449,7 @@ def pmc_gather_path():
     """Counter-derived HBM rates of the gather-path kernels at working sets beyond the 256 MB Infinity Cache
     (profiles/r02_pmc_traffic.json, section "gather_path"); None when the profile is absent."""
     d = src = None
-    for fname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for fname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         d, src = _profile_json(fname)
         if d and "gather_path" in d:
             break

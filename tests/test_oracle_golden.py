@@ -412,3 +412,96 @@ def test_merge_modes_golden(oracle):
             gotb = m(xb.float().numpy(), mode=mode, round_to=rounders["bf16"])
             assert np.array_equal(torch.from_numpy(np.ascontiguousarray(gotb, dtype=np.float32)).bfloat16().view(torch.int16).numpy(),
                                   c[f"bf16/{mode}"]), ("bf16", mode)
+
+
+@pytest.mark.parametrize("name", ["fullblock16_cfg_f4_d40", "fullblock16_pnp_f4_d64"])
+def test_fullblock_fixture_oracle_chain(oracle, name):
+    """The full-block fixtures (tests/golden/make_golden_fullblock.py: the reference's ToMeBlock.forward on a full SD block --
+    attn2 over 77 conditioning tokens, GEGLU feed-forward -- called through a stand-in Transformer2DModel with the whole
+    keyword set) against the CPU oracle + a plain fp32 restatement of the rest of the block: segment from the oracle
+    (norm1 rounded to fp16 like the recorded run, compute_merge, attention, unmerge, residual), then norm2 / attn2 / norm3 /
+    feed-forward in torch fp32 with the fixture's own weights (1-D parameters stored, matrices rebuilt from
+    inputs.portable_weight).  Every kept block of every chunk: 2e-5 of the output scale; anchors exact.  Pins the oracle to
+    the reference through the multi-chunk chain of these cases AND pins the fixture's weight plumbing the GPU test uses."""
+    import torch
+    import torch.nn.functional as F
+    from inputs import portable_weight
+    from standin import StandInUNet, load_block_weights
+    cfg, z = load_chain(name)
+    unet = load_block_weights(StandInUNet(cfg["C"], cfg["heads"], True, cfg["cond_dim"]), z, "cpu", torch.float32,
+                              portable=portable_weight)
+    blocks = list(unet.blocks())
+    names = [str(s) for s in z["block_names"]]
+    gen = forked_generator_from_state(z["rng_state"])
+    args = {"max_downsample": 2, "target_stride": 4, "local_merge_ratio": cfg["local_ratio"], "merge_global": cfg["merge_global"],
+            "global_merge_ratio": cfg["global_ratio"], "global_rand": 0.5, "batch_size": cfg["B"], "align_batch": cfg["align"]}
+    f32 = lambda t: t.detach().float().numpy()
+
+    def att(a, x, ctx, share=1):
+        """sa_forward (pnp_utils.py:47-95) in torch fp32; `share` groups reuse the first group's probabilities."""
+        h = a.heads
+        sp = lambda t: t.reshape(t.shape[0], t.shape[1], h, -1).transpose(1, 2)
+        q, k, v = sp(a.to_q(x)), sp(a.to_k(ctx)), sp(a.to_v(ctx))
+        if share > 1:
+            n = q.shape[0] // share
+            p = torch.softmax(q[:n] @ k[:n].transpose(-1, -2) * a.scale, -1).repeat(share, 1, 1, 1)
+        else:
+            p = torch.softmax(q @ k.transpose(-1, -2) * a.scale, -1)
+        return a.to_out[0]((p @ v).transpose(1, 2).reshape(x.shape))
+
+    for bi in cfg["keep_blocks"]:
+        blk = blocks[bi]
+        draws = oracle.RandomDraws.from_torch_generator(forked_generator_from_state(z["rng_state"]))
+        state = {"global_tokens": None}
+        injected = cfg["injection"] is not None and bi != 0          # pnp_utils.py:100 skips the first decoder block
+        for ck, Fr in enumerate(cfg["chunk_frames"]):
+            if ck in cfg.get("reset_before", []):
+                state["global_tokens"] = None
+            hid = torch.from_numpy(z[f"c{ck}/b{bi}/hidden"].astype(np.float32))
+            lat = tuple(int(v) for v in z[f"c{ck}/latent_shape"][2:])
+            cond = torch.from_numpy(z[f"c{ck}/cond"].astype(np.float32))
+            cond = cond[:, None].expand(-1, Fr, -1, -1).reshape(cfg["B"] * Fr, cond.shape[1], cond.shape[2])
+            with torch.no_grad():
+                nh = blk.norm1(hid).half().float()                               # the recorded run's rounded norm1
+                m, u, merged, _ = oracle.compute_merge(f32(nh), lat, args, draws, state)
+                a1 = blk.attn1
+                w = {k_: f32(getattr(a1, k_).weight) for k_ in ("to_q", "to_k", "to_v")}
+                o = oracle.self_attention(merged, w["to_q"], w["to_k"], w["to_v"], f32(a1.to_out[0].weight), f32(a1.to_out[0].bias),
+                                          cfg["heads"], share_groups=cfg["B"] if injected else 1)
+                x = torch.from_numpy(u(o)) + hid
+                x = att(blk.attn2, blk.norm2(x), cond) + x
+                x = blk.ff(blk.norm3(x)) + x
+            ref = z[f"c{ck}/b{bi}/out"]
+            err = np.abs(f32(x) - ref).max() / max(1.0, np.abs(ref).max())
+            assert err < 2e-5, (name, bi, ck, err)
+            key = f"c{ck}/gt/{names[bi]}"
+            if key in z.files:
+                assert np.array_equal(state["global_tokens"], z[key].astype(np.float32)), (name, bi, ck)
+
+
+def test_token_regimes_have_the_statistics_they_claim():
+    """sites.DATA_REGIMES (bench.py's synthetic tokens): cross-frame cosine of a position ~ 1 / (1 + noise^2) for the corr*
+    regimes, a flat quarter in flat25, exact copies in dup, spatially AND temporally smooth content in `smooth`; a CUDA
+    generator is not needed for any of it."""
+    import torch
+    from vidtome_amd import sites
+    B, Fr, N, C = 1, 6, 256, 64
+    cosf = lambda x, f, g: torch.nn.functional.cosine_similarity(x[0, f], x[0, g], dim=-1)
+    for name, noise in (("corr002", 0.02), ("corr01", 0.1), ("corr05", 0.5)):
+        x = sites.regime_tokens(name, B, Fr, N, C, torch.Generator().manual_seed(1))
+        assert abs(float(cosf(x, 0, 3).mean()) - 1.0 / (1.0 + noise * noise)) < 0.02, name
+    x = sites.regime_tokens("n01", B, Fr, N, C, torch.Generator().manual_seed(1))
+    assert abs(float(cosf(x, 0, 3).mean())) < 0.05
+    x = sites.regime_tokens("flat25", B, Fr, N, C, torch.Generator().manual_seed(1))
+    assert float(torch.nn.functional.cosine_similarity(x[0, 0, 3], x[0, 4, 50], dim=-1)) > 0.99      # two flat positions, two frames
+    x = sites.regime_tokens("dup", B, Fr, N, C, torch.Generator().manual_seed(1))
+    nd = int(N * 0.2)
+    rows = {r.numpy().tobytes() for r in x[0, 2, nd:]}
+    assert all(r.numpy().tobytes() in rows for r in x[0, 2, :nd])                                      # every copy has an original
+    x = sites.regime_tokens("smooth", B, Fr, N, C, torch.Generator().manual_seed(1))
+    g = x[0, 0].reshape(16, 16, C)
+    near = float(torch.nn.functional.cosine_similarity(g[:, :-1], g[:, 1:], dim=-1).mean())
+    far = float(torch.nn.functional.cosine_similarity(g[:, :-8], g[:, 8:], dim=-1).mean())
+    assert near > 0.8 > far and float(cosf(x, 0, 1).mean()) > float(cosf(x, 0, 5).mean()) > 0.9     # drifts 0.1 token per frame
+    with pytest.raises(ValueError):
+        sites.regime_tokens("smooth", B, Fr, 200, C, torch.Generator().manual_seed(1))
