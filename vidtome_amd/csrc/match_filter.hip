@@ -1503,27 +1503,52 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
         const int patches_per_xcd = (int)vtm::cdiv(tiles_per_xcd, max_patch);
         const int patch_tiles = (int)vtm::cdiv(tiles_per_xcd, patches_per_xcd);
         const int ngroups = (int)vtm::cdiv(total_src_tiles, patch_tiles);
-        // dst splits: enough workgroups to fill the chip, >= 4 dst tiles each, at most 8 (every split
-        // contributes >= 1 candidate per row), and 8 whenever the dst axis is long enough (L2 patching)
-        int64_t want = vtm::cdiv(1536, (int64_t)ns_tiles * B);
-        int nsplit = (int)(want < 1 ? 1 : want);
-        if (nd_tiles >= 32) nsplit = 8;
-        if (nsplit > nd_tiles / 4) nsplit = nd_tiles / 4 > 0 ? nd_tiles / 4 : 1;
-        if (nsplit > 8) nsplit = 8;
         // workgroups one XCD has to run (2 per CU at a time) for a split count
         auto wgs_per_xcd = [&](int ns) {
             const int tps = (int)vtm::cdiv(nd_tiles, ns);
             return patches_per_xcd * patch_tiles * (int)vtm::cdiv(nd_tiles, tps);
         };
-        // a bit more than one round of workgroups takes almost two: 7 or 6 splits instead of 8 when that
-        // brings an XCD's share down to a single round (cfg-2 mid global level: 80 -> 60 workgroups, -15 %)
-        if (nsplit == 8) {
+        int nsplit;
+        if (getenv("VTM_DEBUG_NSPLIT_R4")) {
+            // rounds 1-4: enough workgroups to fill the chip, >= 4 dst tiles each, at most 8 (every split contributes >= 1
+            // candidate per row), 8 whenever the dst axis is long enough, 7 or 6 when that saves a round (A/B hook)
+            int64_t want = vtm::cdiv(1536, (int64_t)ns_tiles * B);
+            nsplit = (int)(want < 1 ? 1 : want);
+            if (nd_tiles >= 32) nsplit = 8;
+            if (nsplit > nd_tiles / 4) nsplit = nd_tiles / 4 > 0 ? nd_tiles / 4 : 1;
+            if (nsplit > 8) nsplit = 8;
+            if (nsplit == 8) {
+                const int slots = vtm::device_cus() / 8 * 2;
+                for (int ns = 7; ns >= 6; --ns)
+                    if (wgs_per_xcd(8) > slots && wgs_per_xcd(ns) <= slots) {
+                        nsplit = ns;
+                        break;
+                    }
+            }
+        } else {
+            // Round 5: the split count that minimises  rounds x (tiles per split + 1.5) + 0.25 splits  -- an XCD runs its
+            // workgroups in rounds of its CUs x 2, a
+            // workgroup costs its dst tiles plus ~1.5 tiles of prologue / flush, and every split adds candidates to the rows'
+            // lists.  Reproduces the best of tools/sweep_nsplit.py's 2..14 sweep on all six cfg-2 shapes
+            // (profiles/r05_h_sweeps.txt): level 2 takes 5 splits instead of 8 (768 workgroups = 1.5 rounds -> 480 = one round:
+            // -6 %), the mid levels 5 / 14 instead of 8 (-7 % / -10 %), the top global level 7.
             const int slots = vtm::device_cus() / 8 * 2;
-            for (int ns = 7; ns >= 6; --ns)
-                if (wgs_per_xcd(8) > slots && wgs_per_xcd(ns) <= slots) {
+            double best_cost = 1e30;
+            nsplit = 1;
+            for (int ns = 1; ns <= 16 && ns <= nd_tiles; ++ns) {
+                const int tps = (int)vtm::cdiv(nd_tiles, ns);
+                if ((int)vtm::cdiv(nd_tiles, tps) != ns) continue;          // same workgroups as a smaller count
+                if (tps < 4 && ns > 1) continue;                            // >= 4 dst tiles per split (rounds 1-4's rule: every split
+                                                                            // starts its rows' running maxima and lists anew)
+                const int wgs = wgs_per_xcd(ns);
+                // (a single round must leave a few slots free: 63 workgroups on 64 slots measured as two rounds)
+                const double rounds = (wgs <= slots && wgs > slots - slots / 16) ? 2.0 : (double)vtm::cdiv(wgs, slots);
+                const double cost = rounds * (tps + 1.5) + 0.25 * ns;
+                if (cost < best_cost - 1e-9) {
+                    best_cost = cost;
                     nsplit = ns;
-                    break;
                 }
+            }
         }
         if (const char *dbg = getenv("VTM_DEBUG_NSPLIT")) {   // tuning hook (tools/sweep_nsplit.py)
             const int v = atoi(dbg);
