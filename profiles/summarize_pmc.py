@@ -71,7 +71,8 @@ for what, kern, alg_mb in (("layernorm", "layernorm", 755.0), ("gather", "gather
                 "hbm_GBps": round((rd + wr) / us * 1e3), "frac_of_8TBps": round((rd + wr) / us * 1e3 / 8000, 3)}
 traffic["gather_path"] = gp
 rnd = tag.split("_")[0]
-json.dump(sq, open(f"profiles/{rnd}_pmc_counters.json", "w"), indent=1)
-json.dump(traffic, open(f"profiles/{rnd}_pmc_traffic.json", "w"), indent=1)
+here = os.path.dirname(os.path.abspath(__file__))       # (the session script runs this from /tmp)
+json.dump(sq, open(os.path.join(here, f"{rnd}_pmc_counters.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(here, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in sq.items() if k != "_how"}, indent=1)[:1500])
 print(json.dumps(gp, indent=1))

@@ -13,6 +13,11 @@ python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 for rep in 2 3; do python bench.py --no-cpu-baseline --regimes none > $O/bench_run$rep.json 2>> $O/bench.err; done
 python bench.py --no-cpu-baseline --regimes none --full-block > $O/bench_full_block.json 2>> $O/bench.err; echo "bench full rc=$?"
 for wlk in cfg3 cfg5; do python bench.py --no-cpu-baseline --regimes none --workload $wlk > $O/bench_$wlk.json 2>> $O/bench.err; done
+# the secondary options still run (N = 1 exchange modes in place, cfg-4's 8-frame chunk, local-only, rounds 1-2's regime)
+for opt in "--exchange neighbour" "--exchange ring" "--exchange allgather" "--frames 8" "--local-only" "--same-chunk" "--data corr05"; do
+  python bench.py --no-cpu-baseline --regimes none --steps 8 $opt 2>> $O/bench.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('option $opt:', d['ms_per_step'], 'ms per step,', d['value'], 'steps/s')" ; done > $O/bench_options.txt 2>&1; cat $O/bench_options.txt
 python - <<PY
 import json
 for n in ("bench","bench_run2","bench_run3","bench_full_block","bench_cfg3","bench_cfg5"):
