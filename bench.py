@@ -320,17 +320,22 @@ class KernelTimer:
         self._wrap("attention_kv", "attention", kv_flops)
         # match_filtered(x0, x1, a_rows, b_rows, align): 2 * B * Ns * Nd * C algorithmic flops
         self._wrap("match_filtered", "matching",
-                   lambda x0, x1, ar, br, align, want_flag=False, seed=None: 2.0 * x0.shape[0] * ar.shape[1] * br.shape[1] * x0.shape[2])
+                   lambda x0, x1, ar, br, align, want_flag=False, seed=None, **kw: 2.0 * x0.shape[0] * ar.shape[1] * br.shape[1] * x0.shape[2])
         # the matcher's device-side counters (refined pairs, escaped rows) come from ONE extra, untimed pass after the timed
         # region (`count`): the read-back is a small device copy per call that must not sit inside the event brackets
         timed_match = self.lib_mod.match_filtered
         self.match_flags = []
 
         self.count = False             # set for ONE untimed pass after the timed region
+        self.plan_modes = []           # the launch plan merge.MatchPlanner chose for each call of that pass
 
-        def match_with_counters(x0, x1, ar, br, align, want_flag=False, seed=None):
+        def match_with_counters(x0, x1, ar, br, align, want_flag=False, seed=None, **kw):
             if not self.count or want_flag:
-                return timed_match(x0, x1, ar, br, align, want_flag, seed=seed)
+                return timed_match(x0, x1, ar, br, align, want_flag, seed=seed, **kw)
+            # the counter pass reads the ONE-LAUNCH plan's counters (blocks tested / alive at the 40 % test of every tile) as
+            # a device tensor; which plan the timed passes took is reported separately (matching.plan)
+            kw.pop("stats_host", None)
+            self.plan_modes.append(kw.pop("mode", 0))
             best, flag = timed_match(x0, x1, ar, br, align, True, seed=seed)
             self.match_flags.append((flag, ar.shape[1] if align else x0.shape[0] * ar.shape[1], x0.shape[2]))
             return best
@@ -381,7 +386,8 @@ class KernelTimer:
             return None
         f = torch.stack([fl for fl, _, _ in self.match_flags]).cpu().long()
         rows = sum(r for _, r, _ in self.match_flags)
-        out = {"refined_pairs_per_src_row": round(float(f[:, 3].sum()) / rows, 3),
+        out = {"scout_range_calls": int(sum(1 for m_ in self.plan_modes if m_ == 1)),
+               "refined_pairs_per_src_row": round(float(f[:, 3].sum()) / rows, 3),
                "escaped_rows": int(f[:, 2].sum()), "escaped_row_fraction": round(float(f[:, 2].sum()) / rows, 5),
                "whole_call_escapes": int(f[:, 0].sum()), "calls": len(self.match_flags)}
         # partial-sum pruning of filter_kernel: flags[4] = 32 x 32 score blocks tested after KP of the KT 64-channel steps of
@@ -656,6 +662,10 @@ def main():
         total_passes = 1 + warmup + steps
         for b in unet.blocks:                       # a region starts like a denoising step: no anchors
             b.global_tokens = None
+            # ... and like a new clip: the matcher's launch planners (merge.MatchPlanner) start over -- a planner that the
+            # PREVIOUS regime sent to the one-launch plan would sit out its cool-down in this one (regimes do not alternate in
+            # a real run; the populate / warm-up passes below absorb the planner's first, exploring call)
+            b.__dict__.pop("_vtm_match_plans", None)
         ex = None
         if xmode is not None:
             # every rank owns one chunk per pass; per merging block the global level takes its anchor tokens from the
@@ -755,6 +765,7 @@ def main():
                 "other_launches_ms": round(sum(comp.values()) / tp - att - mat, 3),
                 "pairs_per_row": cnt.get("refined_pairs_per_src_row"), "escaped": cnt.get("escaped_rows"),
                 "escaped_row_fraction": cnt.get("escaped_row_fraction"), "whole_call_escapes": cnt.get("whole_call_escapes"),
+                "scout_range_calls": cnt.get("scout_range_calls"),
                 "pruned_block_fraction": cnt.get("pruned_block_fraction"),
                 "executed_mfma_fraction": cnt.get("executed_mfma_fraction")}
 

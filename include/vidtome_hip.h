@@ -110,7 +110,7 @@ int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd,
  * norm was unusable, [3] = number of (row, dst) pairs the refine pass evaluated, [4] = 32 x 32 score blocks the filter's
  * partial-sum pruning tested, [5] = blocks still alive after the test (the others skipped their remaining MFMAs; both 0
  * when the rows are too short to prune), [6] = work items the escape launch handed out dynamically (internal), [7] = 0
- * (reserved).  The block counters are only collected when flags_out
+ * (vtm_match_filtered_plan: blocks inside the spans of the second launch).  The block counters are only collected when flags_out
  * is given.  Derivation of the window: vidtome_amd/csrc/match_filter.hip.
  *
  * vtm_match_filtered_seeded -- the same result, usually faster on video tokens: before the filter starts every src row gets
@@ -131,6 +131,25 @@ int vtm_match_filtered_seeded(const void *x0, int64_t P0, const void *x1, int64_
                               int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
                               int64_t seed_L, int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table,
                               vtm_stream_t stream);
+/* vtm_match_filtered_plan -- vtm_match_filtered_seeded with the launch plan chosen by the caller; the RESULT is the same bits
+ * for every plan.  VTM_MATCH_ONE_LAUNCH = as above.  VTM_MATCH_SCOUT_RANGE (round 5) is for levels whose src AND dst rows are in
+ * (frame, position) order (the first local level): a "scout" launch runs the filter loop over the channels in front of the
+ * pruning test only and marks the 256 x 128 (src tile, dst tile) pairs in which a block stays alive; the filter launch proper then
+ * shrinks every workgroup's dst range -- one dst frame of seed_N tokens per split -- to the span of the marked tiles.  On
+ * frames of one clip 94 % of the tile pairs of such a level are dead and a top level-1 call drops from 0.75 to about 0.5 ms;
+ * when most tiles stay alive (uncorrelated tokens, noisy clips at this test depth, rows in similarity-rank order) the scout is
+ * pure overhead (+ 40 %).  The host steers by the counters of the previous call of the same level: flags_out may be PINNED HOST
+ * memory (the 32-byte copy is asynchronous either way); with this plan flags_out[4] / [5] = blocks tested / alive in the scout
+ * and flags_out[7] = blocks inside the spans the second launch processed ([7] / [4] = the fraction of the level it had to stream:
+ * the plan pays below about 0.45).  Falls back to one launch when there are no seeds, the rows are
+ * shorter than 256 channels or seed_N is not a multiple of 128 >= 256. */
+#define VTM_MATCH_ONE_LAUNCH 0
+#define VTM_MATCH_SCOUT_RANGE 1
+int vtm_match_filtered_plan(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                            int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
+                            int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
+                            int64_t seed_L, int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table,
+                            int mode, vtm_stream_t stream);
 
 /* node_max (fp32, -0 canonicalised to +0) and node_idx (int32) out of packed keys; either output may
  * be NULL. */

@@ -314,6 +314,82 @@ def test_match_filtered_seeds_never_change_the_result(L):
     assert torch.equal(L.match_filtered(x0, x1, ra1, rb0, False, seed=(N, Ns, pos1, t2)), e2)
 
 
+@pytest.mark.parametrize("align", [False, True])
+def test_match_scout_range_plan_equals_exact(L, align):
+    """The scout + range launch plan (round 5: a scout launch marks the 256 x 128 tile pairs whose partial sums can still
+    reach a row's window, the filter launch proper shrinks every workgroup's dst range -- one dst frame per split -- to the span
+    of the marked tiles; vtm_match_filtered_plan, VTM_MATCH_SCOUT_RANGE) must give the bits of the exact fp32 matcher in every
+    data regime -- it is a launch plan, never a different result: frames of one clip at three noise levels, a drifting smooth
+    field, exact duplicates, a flat region (lists overflow -> exact escape), UNCORRELATED tokens (every tile stays marked),
+    garbage seeds, no seeds (one launch), ragged sizes (rows past Ns / Nd inside the tiles, a last partial dst frame), batch 3,
+    C = 256 / 320 / 640, frames that are not whole tiles (one launch); a zero dst token sends the whole call to the escape."""
+    from vidtome_amd import sites
+    g = torch.Generator().manual_seed(77)
+    cases = [("corr01", 2, 8, 256, 320, 6), ("corr002", 2, 8, 256, 320, 6), ("corr05", 2, 8, 256, 320, 6),
+             ("smooth", 2, 8, 256, 320, 6), ("dup", 2, 8, 256, 320, 6), ("flat25", 2, 8, 256, 320, 6),
+             ("n01", 2, 8, 256, 320, 6), ("corr01", 3, 5, 384, 256, 3), ("corr05", 2, 6, 512, 640, 4),
+             ("corr01", 1, 7, 441, 320, 5), ("corr01", 2, 12, 1024, 320, 9)]
+    for (regime, B, F, N, C, fs) in cases:
+        x = sites.regime_tokens(regime, B, F, N, C, g)
+        x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, F * N, C).half().to(DEV)
+        Ns, Nd = fs * N, (F - fs) * N
+        ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+        rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+        a_op, _ = L.normalize_gather(x, None, ra)
+        b_op, _ = L.normalize_gather(x, None, rb)
+        exact = L.match(a_op, b_op, Ns, Nd, align)
+        seed = (N, F * N, None, None)
+        got, flag = L.match_filtered(x, None, ra, rb, align, want_flag=True, seed=seed, mode=L.MATCH_SCOUT_RANGE)
+        assert torch.equal(got, exact), (regime, B, F, N, C)
+        f = flag.tolist()
+        if N % 128 == 0:
+            assert f[4] > 0 and 0 < f[7] <= f[4] and f[5] <= f[4], (regime, f)           # the scout ran, the spans are not empty
+            if regime in ("corr01", "corr002") and N >= 1024:
+                assert f[7] < 0.3 * f[4], (regime, f)                                     # ... and short on a low-noise clip
+            if regime == "n01":
+                assert f[7] > 0.9 * f[4], (regime, f)                                     # ... the whole level on uncorrelated tokens
+        else:
+            assert f[7] == 0, (regime, f)                                                  # frames are not whole tiles: one launch
+        # garbage seeds, and no seeds at all (then the plan is the one-launch one): exact whatever the starting maxima are
+        table = torch.randint(-3, Nd + 50, (B, N), generator=g, dtype=torch.int32).to(DEV)
+        assert torch.equal(L.match_filtered(x, None, ra, rb, align, seed=(N, F * N, None, table), mode=L.MATCH_SCOUT_RANGE), exact)
+        assert torch.equal(L.match_filtered(x, None, ra, rb, align, mode=L.MATCH_SCOUT_RANGE), exact)
+        assert torch.equal(L.match_filtered(x, None, ra, rb, align, seed=seed), exact)
+        if regime == "corr05":
+            x[B - 1, Ns + 7] = 0
+            a_op, _ = L.normalize_gather(x, None, ra)
+            b_op, _ = L.normalize_gather(x, None, rb)
+            got, flag = L.match_filtered(x, None, ra, rb, align, want_flag=True, seed=seed, mode=L.MATCH_SCOUT_RANGE)
+            assert torch.equal(got, L.match(a_op, b_op, Ns, Nd, align)) and int(flag[0]) == 1
+
+
+def test_match_planner_steers_by_the_previous_calls_counters(L):
+    """merge.MatchPlanner: a scout + range call copies its counters into the planner's pinned buffer (no synchronisation in
+    the product path; the test synchronises to look); uncorrelated tokens (every wave tile alive) send the block's first level
+    back to the one-launch plan for COOL calls, frames of a low-noise clip keep the scout + range plan."""
+    from vidtome_amd import merge, sites
+    g = torch.Generator().manual_seed(5)
+    B, F, N, C, fs = 2, 8, 4096, 320, 6          # 4 096 tokens per frame: a src tile's matches sit in 2 of a frame's 32 dst tiles
+    Ns, Nd = fs * N, (F - fs) * N
+    ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+    rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+    seed = (N, F * N, None, None)
+    for regime, expect in (("corr01", L.MATCH_SCOUT_RANGE), ("corr05", L.MATCH_ONE_LAUNCH), ("n01", L.MATCH_ONE_LAUNCH)):
+        x = sites.regime_tokens(regime, B, F, N, C, g)
+        x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, F * N, C).half().to(DEV)
+        pl = merge.MatchPlanner()
+        mode, buf = pl.next()
+        assert mode == L.MATCH_SCOUT_RANGE and buf.is_pinned()
+        L.match_filtered(x, None, ra, rb, False, seed=seed, mode=mode, stats_host=buf)
+        torch.cuda.synchronize()
+        assert int(buf[4]) > 0, buf.tolist()
+        assert pl.next()[0] == expect, (regime, buf.tolist())
+        if expect == L.MATCH_ONE_LAUNCH:
+            for _ in range(merge.MatchPlanner.COOL - 1):
+                assert pl.next()[0] == L.MATCH_ONE_LAUNCH
+            assert pl.next()[0] == L.MATCH_SCOUT_RANGE          # ... and tries again
+
+
 def test_refine_many_candidates_per_row(L):
     """Rows with MANY candidates inside the fp16 filter's window (what frames of one clip at low noise produce: 4-17 per
     row): every src row has 6-12 dst rows whose scores differ by ~1e-7 ... 1e-3, exact duplicates among them, C up to 1280,

@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--no-seed", action="store_true", help="match: the filtered matcher WITHOUT its same-position seeds (default: "
                     "seeded like the product path -- the rows of a kbench call are frame-ordered: dst index = position in the "
                     "first dst frame)")
+    ap.add_argument("--plan", default="one", choices=["one", "range"], help="match: launch plan of the filtered matcher "
+                    "(one launch / scout + range; same bits)")
     ap.add_argument("--C", type=int, default=320)
     ap.add_argument("--data", default="random", help="attn: random | zeros | const (operand values); match: n01 | corr01 | "
                     "corr05 | flat25 | dup | zero | all (token regime; random = n01 in fp16 straight from the device generator)")
@@ -82,15 +84,16 @@ def main():
 
         regimes = ["n01", "corr01", "corr002", "corr05", "smooth", "flat25", "dup", "zero"] if a.data == "all" else [a.data]
         fl = 2.0 * B * Ns * Nd * C
-        print(f"match {a.shape} B={B} Ns={Ns} Nd={Nd} C={C} align={a.align} seeded={bool(seed)}")
+        print(f"match {a.shape} B={B} Ns={Ns} Nd={Nd} C={C} align={a.align} seeded={bool(seed)} plan={a.plan}")
         print(f"{'data':8s} {'filtered ms':>12s} {'nom TFLOP/s':>12s} {'exact ms':>9s} {'pairs/row':>10s} {'escape rows':>12s} {'whole-call':>10s} {'blocks alive':>12s} equal")
         for regime in regimes:
             x = tokens(regime)
             aop, _ = _lib.normalize_gather(x, None, ra)
             bop, _ = _lib.normalize_gather(x, None, rb)
             med, best = timeit(lambda: _lib.match(aop, bop, Ns, Nd, a.align), a.iters)
-            medf, bestf = timeit(lambda: _lib.match_filtered(x, None, ra, rb, a.align, seed=seed), a.iters)
-            out, fl_ = _lib.match_filtered(x, None, ra, rb, a.align, want_flag=True, seed=seed)
+            mode = _lib.MATCH_SCOUT_RANGE if a.plan == "range" else _lib.MATCH_ONE_LAUNCH
+            medf, bestf = timeit(lambda: _lib.match_filtered(x, None, ra, rb, a.align, seed=seed, mode=mode), a.iters)
+            out, fl_ = _lib.match_filtered(x, None, ra, rb, a.align, want_flag=True, seed=seed, mode=mode)
             same = bool(torch.equal(out, _lib.match(aop, bop, Ns, Nd, a.align)))
             f = fl_.tolist()                # [whole-call exact, non-finite, escape rows, refined pairs, blocks tested, alive, 0, 0]
             rows = Ns if a.align else B * Ns

@@ -39,6 +39,8 @@ _SIGNATURES = {
     "vtm_match_filtered_ws_bytes": ([_i64, _i64, _i64, _i64, _int], ctypes.c_size_t),
     "vtm_match_filtered": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
                             _vp, _vp, _vp], _int),
+    "vtm_match_filtered_plan": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
+                                 _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp], _int),
     "vtm_match_filtered_seeded": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
                                    _vp, _vp, _i64, _i64, _vp, _vp, _vp], _int),
     "vtm_anchor_pos": ([_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp], _int),
@@ -224,13 +226,21 @@ def match(a: torch.Tensor, b: torch.Tensor, Ns: int, Nd: int, align: bool) -> to
     return best
 
 
+MATCH_ONE_LAUNCH, MATCH_SCOUT_RANGE = 0, 1         # include/vidtome_hip.h: VTM_MATCH_*
+
+
 @_on_device
 def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.Tensor, b_rows: torch.Tensor,
-                   align: bool, want_flag: bool = False, seed=None):
+                   align: bool, want_flag: bool = False, seed=None, mode: int = MATCH_ONE_LAUNCH,
+                   stats_host: Optional[torch.Tensor] = None):
     """Same packed result as normalize_gather x2 + match, through the fp16-filter / fp32-refine path.  ``seed`` (optional,
     never changes the result): (tokens per frame N, L = pool rows that are chunk tokens, pos1 (B, P1) int32 positions of the
     x1 rows or None, table (B, N) int32 position -> dst index or None for identity) -- every src row then starts from the
-    score of the dst row at its own token position (vtm_match_filtered_seeded)."""
+    score of the dst row at its own token position.  ``mode`` = the launch plan (MATCH_ONE_LAUNCH / MATCH_SCOUT_RANGE: a scout
+    launch + the filter over the spans of live dst tiles, for levels with position-ordered rows; same bits;
+    include/vidtome_hip.h, vtm_match_filtered_plan).  ``stats_host``: a PINNED host tensor of 8 int32 that receives the
+    call's counters asynchronously (flags_out of the C ABI) -- what merge.MatchPlanner steers by; ``want_flag`` returns them
+    as a device tensor instead."""
     _req(x0, "x0"), _req(a_rows, "a_rows"), _req(b_rows, "b_rows")
     B, P0, C = x0.shape
     P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
@@ -238,22 +248,26 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
     nbytes = lib().vtm_match_filtered_ws_bytes(B, C, Ns, Nd, int(align))
     ws = _workspace("match", nbytes, x0.device)
     best = torch.empty((1 if align else B, Ns), dtype=torch.int64, device=x0.device)
-    # whole-call escape, unusable norm seen, escaped rows, refined pairs, blocks tested, blocks alive, 0, 0
+    # whole-call escape, unusable norm seen, escaped rows, refined pairs, blocks tested, blocks alive, (internal), scout's
+    # live wave tiles
     flag = torch.zeros((8,), dtype=torch.int32, device=x0.device) if want_flag else None
+    flags_out = _ptr(flag)
+    if flag is None and stats_host is not None:
+        if not (stats_host.is_pinned() and stats_host.dtype == torch.int32 and stats_host.numel() >= 8):
+            raise RuntimeError("match_filtered: stats_host must be a pinned int32 tensor of 8 elements")
+        flags_out = stats_host.data_ptr()
+    sN = sL = 0
+    pos1 = table = None
     if seed is not None and SEED_MATCHER:
         sN, sL, pos1, table = seed
         if pos1 is not None and (pos1.dtype != torch.int32 or tuple(pos1.shape) != (B, P1) or not pos1.is_contiguous()):
             raise RuntimeError("match_filtered: seed positions must be a contiguous (B, P1) int32 tensor")
         if table is not None and (table.dtype != torch.int32 or tuple(table.shape) != (B, sN) or not table.is_contiguous()):
             raise RuntimeError("match_filtered: the seed table must be a contiguous (B, N) int32 tensor")
-        _check(lib().vtm_match_filtered_seeded(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(a_rows), Ns,
-                                               _ptr(b_rows), Nd, int(align), _ptr(ws), nbytes, _ptr(best), _ptr(flag),
-                                               int(sL), int(sN), _ptr(pos1), _ptr(table), _stream()),
-               "vtm_match_filtered_seeded")
-        return (best, flag) if want_flag else best
-    _check(lib().vtm_match_filtered(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(a_rows), Ns, _ptr(b_rows),
-                                    Nd, int(align), _ptr(ws), nbytes, _ptr(best), _ptr(flag), _stream()),
-           "vtm_match_filtered")
+    _check(lib().vtm_match_filtered_plan(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(a_rows), Ns,
+                                         _ptr(b_rows), Nd, int(align), _ptr(ws), nbytes, _ptr(best), flags_out,
+                                         int(sL), int(sN), _ptr(pos1), _ptr(table), int(mode), _stream()),
+           "vtm_match_filtered_plan")
     return (best, flag) if want_flag else best
 
 

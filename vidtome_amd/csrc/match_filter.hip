@@ -330,12 +330,23 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
 }
 
 // ---- filter: approximate scores on the fp16 MFMA, candidate collection ----
+// Round 5, "scout + range" plan for levels whose rows are position-ordered on both sides (level 1): on frames of one clip
+// 94 % of the 256 x 128 WORKGROUP tiles of such a level are dead as a whole at the pruning test, yet the one-launch kernel
+// streams all five channel steps of every tile (the steps behind the test cost 0.22 of the 0.75 ms of a top level-1 call,
+// profiles/r05_b_scout_timing.txt).  SCOUT = the same loop over only the KP steps in front of the test: nothing is
+// collected, a wave whose test leaves a block alive sets the tile's bit in `tilemap`.  The second launch is THIS kernel,
+// unchanged, except that a workgroup shrinks its dst range [jt0, jt1) to the span of the set bits inside it (one dst frame
+// per split: the live tiles of a src tile sit together there).  Every tile outside the spans is certified dead (no pair of
+// it can come within the window of a valid running maximum, see "partial-sum pruning"), every tile inside is processed in
+// full: the result is what the one-launch plan computes.  Only the host knows whether the plan pays (merge.MatchPlanner).
+template <bool SCOUT>
 __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     const uint4 *__restrict__ ah, const uint4 *__restrict__ al, const uint4 *__restrict__ bh,
     const uint4 *__restrict__ bl, int64_t Ns, int64_t Nd, int64_t Ns_pad, int64_t Nd_pad, int64_t C_pad, int align,
     int ns_tiles, int nd_tiles, int nsplit, int tiles_per_split, int total_src_tiles, int patch_tiles,
     unsigned int *__restrict__ amax, int *__restrict__ cnt, uint2 *__restrict__ cand, int cand_rows, int *__restrict__ flags,
-    const float *__restrict__ rest_a, const float *__restrict__ rest_bt, int KP, int count_blocks) {
+    const float *__restrict__ rest_a, const float *__restrict__ rest_bt, int KP, int count_blocks,
+    unsigned int *__restrict__ tilemap, int map_words) {
     // dst tile of one step: 8 panels x 128 rows x 16 B, hi and lo, double-buffered: 2 x 2 x 16 KiB
     __shared__ __attribute__((aligned(16))) uint4 sA[2][DST_LO ? 2 : 1][8 * FBD];
 
@@ -358,11 +369,32 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     if (stg >= total_src_tiles) return;
     const int st_ = stg % ns_tiles;
     const int bi = stg / ns_tiles;
-    const int jt0 = split * tiles_per_split;
-    const int jt1 = min(jt0 + tiles_per_split, nd_tiles);
+    int jt0 = split * tiles_per_split;
+    int jt1 = min(jt0 + tiles_per_split, nd_tiles);
     if (jt0 >= jt1) return;
+    if constexpr (!SCOUT) {
+        if (tilemap != nullptr) {   // range plan: the span of the tiles the scout left alive inside this split (wave-uniform)
+            const unsigned int *row = tilemap + (int64_t)stg * map_words;
+            int lo = jt1, hi = jt0;
+            for (int w = jt0 >> 5; w <= (jt1 - 1) >> 5; ++w) {
+                unsigned int bits = row[w];
+                if (w == (jt0 >> 5)) bits &= 0xffffffffu << (jt0 & 31);
+                if (w == ((jt1 - 1) >> 5) && (jt1 & 31)) bits &= 0xffffffffu >> (32 - (jt1 & 31));
+                if (bits) {
+                    lo = min(lo, w * 32 + __ffs(bits) - 1);
+                    hi = max(hi, w * 32 + 32 - __clz(bits));
+                }
+            }
+            lo = __builtin_amdgcn_readfirstlane(lo);
+            hi = __builtin_amdgcn_readfirstlane(hi);
+            if (lo >= hi) return;
+            jt0 = lo;
+            jt1 = hi;
+        }
+    }
 
-    const int KT = (int)(C_pad / FBK);
+    // channel steps per dst tile: all of them, or (scout) only the KP in front of the pruning test
+    const int KT = SCOUT ? KP : (int)(C_pad / FBK);
     const int64_t G = C_pad / 8;
     const int steps = (jt1 - jt0) * KT;
     int n_tested = 0, n_alive = 0;            // (wave-uniform) pruning statistics, published once per wave
@@ -487,7 +519,7 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     // value is an approximate score of the row, hence a valid running maximum; starting every split from -inf instead
     // would multiply the record-breaking tiles (8 splits: 71 % of the blocks trigger the candidate path, shared: 25 %).
     uint32_t am[2] = {0u, 0u};
-    auto collect_tile = [&](int jt, auto share_tag) {
+    [[maybe_unused]] auto collect_tile = [&](int jt, auto share_tag) {
         constexpr bool SHARE = decltype(share_tag)::value;
         const int dst0 = jt * FBD + 4 * kh;
         const bool full = (int64_t)(jt + 1) * FBD <= Nd;
@@ -801,8 +833,13 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
             live = prune_check(jt);
             n_tested += 8;                             // 32 x 32 blocks tested / still alive (flags_out[4], [5])
             n_alive += __popc(live);
+            if constexpr (SCOUT) {
+                if (live && lane == 0) atomicOr(&tilemap[(int64_t)stg * map_words + (jt >> 5)], 1u << (jt & 31));
+            }
         }
-        if (ABL_WRAP_COND(wrap && live)) collect_tile(jt, std::true_type{});
+        if constexpr (!SCOUT) {
+            if (ABL_WRAP_COND(wrap && live)) collect_tile(jt, std::true_type{});
+        }
         if (wrap) {
             ++jt;
             live = 0xffu;
@@ -815,9 +852,14 @@ __global__ __launch_bounds__(THREADS, 2) void filter_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused prefetches of the last step
     // one pair of atomics per WAVE: per tile they serialise on two words (a counting call took 4.5 instead of 0.75 ms)
     if (count_blocks && lane == 0 && n_tested) {
-        atomicAdd(&flags[4], n_tested);
-        atomicAdd(&flags[5], n_alive);
+        if (!SCOUT && tilemap != nullptr) {
+            atomicAdd(&flags[7], n_tested);            // range plan: the blocks inside the spans (the scout counted [4], [5])
+        } else {
+            atomicAdd(&flags[4], n_tested);
+            atomicAdd(&flags[5], n_alive);
+        }
     }
+    if constexpr (SCOUT) return;
 
     // flush: the entries still inside the window of this lane's final maximum
 #pragma unroll
@@ -1365,7 +1407,7 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t na, nb, ah, al, bh, bl, amax, cnt, seedlb, cand, flags, ovf_cnt, ovf, pairs, rest_a, rest_bt, total;
+    size_t na, nb, ah, al, bh, bl, amax, cnt, seedlb, tilemap, cand, flags, ovf_cnt, ovf, pairs, rest_a, rest_bt, total;
     int64_t Ns_pad, Nd_pad, C64;
 };
 
@@ -1386,6 +1428,8 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     L.amax = take((size_t)rows_out * 4);      // amax, cnt and flags are contiguous: cleared together
     L.cnt = take((size_t)rows_out * 4);
     L.seedlb = take((size_t)rows_out * 4);    // certified lower bounds of the rows' exact maxima (seed_kernel -> exact_rows_kernel)
+    // the scout's map of live (src tile, dst tile) pairs: one bit per dst tile (inside the cleared range)
+    L.tilemap = take((size_t)B * (L.Ns_pad / FBS) * ((L.Nd_pad / FBD + 31) / 32) * 4);
     L.flags = take(256);
     L.ovf_cnt = take((size_t)B * 4);          // per-sample overflow-list lengths (inside the cleared range)
     L.cand = take((size_t)rows_out * CAP * 8);
@@ -1408,8 +1452,9 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
                                int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
                                int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
                                int64_t seed_L, int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table,
-                               vtm_stream_t stream) {
+                               int mode, vtm_stream_t stream) {
     VTM_REQUIRE(x0 && a_rows && b_rows && ws && best, "vtm_match_filtered: null pointer");
+    VTM_REQUIRE(mode == VTM_MATCH_ONE_LAUNCH || mode == VTM_MATCH_SCOUT_RANGE, "vtm_match_filtered: bad mode %d", mode);
     VTM_REQUIRE(B > 0 && C > 0 && C % 8 == 0 && Ns > 0 && Nd > 0, "vtm_match_filtered: bad sizes");
     VTM_REQUIRE(P1 == 0 || x1, "vtm_match_filtered: x1 is null but P1 > 0");
     VTM_REQUIRE(B * Nd < (1ll << 32) - 1, "vtm_match_filtered: index space overflow");
@@ -1562,10 +1607,30 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
             const int v = atoi(dbg);
             if (v >= 1 && (int64_t)v * FBK < L.C64) c_run = (int64_t)v * FBK;
         }
-        hipLaunchKernelGGL(filter_kernel, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
-                           L.Nd_pad, c_run, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles, amax,
-                           cnt, cand, (int)rows_out, flags, prune ? (const float *)rest_a : nullptr,
-                           prune ? (const float *)rest_bt : nullptr, prune ? KP : 0x7fffffff, flags_out != nullptr ? 1 : 0);
+        // scout + range plan (see filter_kernel): needs the pruning test, the seeds (without a starting maximum nothing is
+        // dead) and dst frames of whole tiles -- one split per dst frame, so that a span is the live tiles of ONE frame
+        const int map_words = (nd_tiles + 31) / 32;
+        unsigned int *tilemap = (unsigned int *)(w + L.tilemap);
+        const bool range_plan = mode == VTM_MATCH_SCOUT_RANGE && prune && seed_N >= 2 * FBD && seed_N % FBD == 0 && c_run == L.C64;
+        if (range_plan) {
+            hipLaunchKernelGGL(filter_kernel<true>, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
+                               L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles,
+                               amax, cnt, cand, (int)rows_out, flags, (const float *)rest_a, (const float *)rest_bt, KP,
+                               flags_out != nullptr ? 1 : 0, tilemap, map_words);
+            const int tps_r = (int)(seed_N / FBD);
+            const int nsplit_r = (int)vtm::cdiv(nd_tiles, tps_r);
+            const int64_t grid_r = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit_r;
+            hipLaunchKernelGGL(filter_kernel<false>, dim3((unsigned)grid_r), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd,
+                               L.Ns_pad, L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit_r, tps_r, total_src_tiles, patch_tiles,
+                               amax, cnt, cand, (int)rows_out, flags, (const float *)rest_a, (const float *)rest_bt, KP,
+                               flags_out != nullptr ? 1 : 0, tilemap, map_words);
+        } else {
+            hipLaunchKernelGGL(filter_kernel<false>, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
+                               L.Nd_pad, c_run, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles,
+                               amax, cnt, cand, (int)rows_out, flags, prune ? (const float *)rest_a : nullptr,
+                               prune ? (const float *)rest_bt : nullptr, prune ? KP : 0x7fffffff, flags_out != nullptr ? 1 : 0,
+                               (unsigned int *)nullptr, map_words);
+        }
     }
     {
         const dim3 grid((unsigned)vtm::cdiv(rows_out, RROWS)), block(256);
@@ -1609,7 +1674,8 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
     if (int rc = vtm::launch_status("vtm_match_filtered")) return rc;
 
     if (flags_out) {
-        const hipError_t e = hipMemcpyAsync(flags_out, flags, 8 * sizeof(int), hipMemcpyDeviceToDevice, s);
+        // (device or pinned host memory: the copy direction is taken from the pointers)
+        const hipError_t e = hipMemcpyAsync(flags_out, flags, 8 * sizeof(int), hipMemcpyDefault, s);
         if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: copy: %s", hipGetErrorString(e));
     }
     return VTM_OK;
@@ -1620,7 +1686,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
                                   int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
                                   vtm_stream_t stream) {
     return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, b_rows, Nd, align, ws, ws_bytes, best, flags_out, 0, 0,
-                               nullptr, nullptr, stream);
+                               nullptr, nullptr, VTM_MATCH_ONE_LAUNCH, stream);
 }
 
 VTM_EXPORT int vtm_match_filtered_seeded(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
@@ -1630,7 +1696,17 @@ VTM_EXPORT int vtm_match_filtered_seeded(const void *x0, int64_t P0, const void 
                                          vtm_stream_t stream) {
     VTM_REQUIRE(seed_N >= 0 && seed_L >= 0, "vtm_match_filtered_seeded: bad seed description");
     return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, b_rows, Nd, align, ws, ws_bytes, best, flags_out, seed_L,
-                               seed_N, seed_pos1, seed_table, stream);
+                               seed_N, seed_pos1, seed_table, VTM_MATCH_ONE_LAUNCH, stream);
+}
+
+VTM_EXPORT int vtm_match_filtered_plan(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                                       int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
+                                       int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
+                                       int64_t seed_L, int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table,
+                                       int mode, vtm_stream_t stream) {
+    VTM_REQUIRE(seed_N >= 0 && seed_L >= 0, "vtm_match_filtered_plan: bad seed description");
+    return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, b_rows, Nd, align, ws, ws_bytes, best, flags_out, seed_L,
+                               seed_N, seed_pos1, seed_table, mode, stream);
 }
 
 namespace vtm {

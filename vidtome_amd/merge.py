@@ -57,8 +57,52 @@ class Level:
         return self.Ns - self.r
 
 
+# Launch plan of the filtered matcher (same bits either way): "auto" = merge.MatchPlanner decides per
+# block from the previous call's counters, "one" = always the one-launch filter (rounds 1-4), "range" = always scout + range
+MATCH_PLAN = os.environ.get("VIDTOME_MATCH_PLAN", "auto")
+
+
+class MatchPlanner:
+    """Which launch plan the next call of ONE block's first local level takes (vtm_match_filtered_plan).
+
+    The scout + range plan is ~30 % faster when nearly all 256 x 128 tile pairs die at the scout's test -- frames of one clip
+    at low noise -- and ~40 % slower when most stay alive (uncorrelated tokens; a noisy clip, whose matches do not clear the
+    rest bound at that depth).  How many stay alive is a property of the data at that block, and consecutive calls (the next
+    chunk, the next denoising step) see similar data, so the planner steers by the PREVIOUS call's counters: every
+    scout + range call copies its 8 counters asynchronously into this planner's pinned host buffer; the next call reads
+    whatever has arrived -- never waiting, never synchronising; a stale or missing reading only delays a switch -- and falls
+    back to the one-launch plan for `COOL` calls when the spans the second launch had to stream covered more than `HIGH` of
+    the level, then tries again.  (The scout costs about half a one-launch filter and the second launch its share of the
+    rest, which puts the break-even near 0.45 -- on paper: measured, a top level 1 with 0.06 of its blocks in the spans gains
+    24 %, mid levels with 0.25 gain 11 % on low-noise clips and LOSE 50 % on noisier ones, a smooth field with 0.27 loses
+    17 %; hence 0.15.  profiles/r05_n_scout_range_plan.txt.)  Results never depend on the plan."""
+
+    HIGH, COOL = 0.15, 256
+
+    def __init__(self):
+        self.mode = _lib.MATCH_SCOUT_RANGE
+        self.buf = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.view = self.buf.numpy()
+        self.cool = 0
+        self.switches = 0
+
+    def next(self):
+        """-> (mode, pinned stats buffer or None) for the call about to be issued."""
+        if self.mode == _lib.MATCH_SCOUT_RANGE:
+            tested, in_spans = int(self.view[4]), int(self.view[7])       # the last call whose counters have arrived
+            if tested > 0 and in_spans > self.HIGH * tested:
+                self.mode, self.cool = _lib.MATCH_ONE_LAUNCH, self.COOL
+                self.switches += 1
+                self.view[4] = 0                                           # judged: do not judge it again after the cool-down
+        else:
+            self.cool -= 1
+            if self.cool <= 0:
+                self.mode = _lib.MATCH_SCOUT_RANGE
+        return (self.mode, self.buf) if self.mode == _lib.MATCH_SCOUT_RANGE else (self.mode, None)
+
+
 def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float, align_batch: bool,
-               want_indices: bool, seed=None) -> Level:
+               want_indices: bool, seed=None, planner: Optional[MatchPlanner] = None) -> Level:
     """normalise+split -> fused score/top-1 -> argsort -> index split  (merge.py:84-117 / 389-421)."""
     a_pos, b_pos, a_rows, b_rows = parts
     Ns, Nd = a_rows.shape[1], b_rows.shape[1]
@@ -68,7 +112,13 @@ def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float
         b_op, _ = _lib.normalize_gather(x0, x1, b_rows)
         best = _lib.match(a_op, b_op, Ns, Nd, align_batch)
     else:                                              # fp16 filter + fp32 refine: same bits, ~4x faster
-        best = _lib.match_filtered(x0, x1, a_rows, b_rows, align_batch, seed=seed)
+        mode, stats = _lib.MATCH_ONE_LAUNCH, None
+        if planner is not None and seed is not None and _lib.SEED_MATCHER and MATCH_PLAN != "one":
+            if MATCH_PLAN == "range":
+                mode = _lib.MATCH_SCOUT_RANGE
+            else:
+                mode, stats = planner.next()
+        best = _lib.match_filtered(x0, x1, a_rows, b_rows, align_batch, seed=seed, mode=mode, stats_host=stats)
     perm = _lib.sort_desc(best)
     new_cur, inv, unm_idx, src_idx, dst_idx = _lib.plan_apply(best, perm, a_pos, b_pos, a_rows, b_rows, r,
                                                               align_batch, want_indices)
@@ -77,7 +127,7 @@ def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float
 
 def local_level(x0: torch.Tensor, cur: Optional[torch.Tensor], N_in: int, F: int, ratio: float, unm_pre: int,
                 randf: int, target_stride: int, align_batch: bool, want_indices: bool = False,
-                tokens: Optional[int] = None) -> Level:
+                tokens: Optional[int] = None, planner: Optional[MatchPlanner] = None) -> Level:
     """One level of local merging on the joined chunk x0 (B, L, C); ``cur`` maps the current sequence to
     rows of x0 (None = identity).  ``tokens`` = tokens per frame of the joined chunk when its rows are (frame, position)
     ordered: the matcher is then seeded with, for every src token, the token at the same position of the first dst frame
@@ -87,7 +137,10 @@ def local_level(x0: torch.Tensor, cur: Optional[torch.Tensor], N_in: int, F: int
     ts = min(target_stride, F)                         # merge.py:56
     parts = _lib.partition_local(cur, B, N_in, unm_pre, tnum, ts, randf, x0.device)
     seed = (tokens, x0.shape[1], None, None) if (tokens and tokens == tnum) else None
-    return _run_level(x0, None, parts, ratio, align_batch, want_indices, seed)
+    # the scout + range plan is for rows in (frame, position) order on both sides: the first level (cur None).  (Measured
+    # with a planner on every level: levels 2 and the global level -- rows in similarity-rank order -- switch themselves off on
+    # every regime and only pay the exploration calls.)
+    return _run_level(x0, None, parts, ratio, align_batch, want_indices, seed, planner if cur is None else None)
 
 
 def global_level(x0: torch.Tensor, anchors: torch.Tensor, cur_local: Optional[torch.Tensor], Ml: int,

@@ -151,6 +151,18 @@ def content_ids(tokens: torch.Tensor, device, dtype) -> Optional[torch.Tensor]:
     return ids
 
 
+def _planner(module: torch.nn.Module, key) -> "merge.MatchPlanner":
+    """The launch planner of the block's first local level (merge.MatchPlanner), kept on the module next to its generator
+    and its anchors, one per chunk geometry; `remove_patch` drops them."""
+    plans = module.__dict__.get("_vtm_match_plans")
+    if plans is None:
+        plans = module.__dict__["_vtm_match_plans"] = {}
+    p = plans.get(key)
+    if p is None:
+        p = plans[key] = merge.MatchPlanner()
+    return p
+
+
 def _draw_coin(generator: torch.Generator) -> float:
     """patch.py:62: ``torch.rand(1, generator=generator, device=generator.device)``."""
     return float(torch.rand(1, generator=generator, device=generator.device))
@@ -203,7 +215,8 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
             else:
                 randf = merge.draw_randf(generator, min(args["target_stride"], curF))
                 lv = merge.local_level(xj, cur, n_cur, curF, ratio, unm, randf, args["target_stride"],
-                                       args["align_batch"], want_indices, tokens=tsize)
+                                       args["align_batch"], want_indices, tokens=tsize,
+                                       planner=_planner(module, (xj.shape[1], curF)) if cur is None else None)
                 plan.levels.append(lv)
                 unm += lv.unm_num
                 cur = lv.new_cur
@@ -1072,6 +1085,7 @@ def remove_patch(model: torch.nn.Module):
             # for SD-1.5; they are rebuilt on demand if the model is patched again
             module.__dict__.pop("_vtm_packed", None)
             module.__dict__.pop("_vtm_wcache", None)
+            module.__dict__.pop("_vtm_match_plans", None)      # the matcher's launch planners (pinned 32-byte buffers)
     _lib.release_workspaces()            # the cached scratch buffers of the patched path (re-created on demand)
     return roots[-1]                     # the reference returns its loop variable: the last tree walked
 
