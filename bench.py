@@ -71,6 +71,11 @@ WORKLOADS = {
                  label="SD-2.1-768 16 frames 768x768, head dim 64, merge ratio 0.6 (cfg-5)"),
 }
 HEADLINE_REGIME = "corr01"        # SURVEY.md 8d names N(0,1) and base + 0.1 N(0,1); the harder of the two is the headline
+# untimed passes in front of a secondary regime's region: the launch planners (merge.MatchPlanner, one per block and level)
+# start every regime afresh, spend one exploring call each -- the global level's first one comes with the first anchors -- and
+# read its counters a call later; in a real run that happens once per 256 calls of a level, in a ten-pass region it would be a
+# tenth of the time
+REGIME_WARMUP = 5
 REGIME_NOTES = {
     "n01": "h ~ N(0,1), frames uncorrelated (SURVEY 8d)",
     "corr01": "h[f] = base + 0.1 N(0,1) (SURVEY 8d: realistic cross-frame cosine)",
@@ -336,11 +341,15 @@ class KernelTimer:
             # a device tensor; which plan the timed passes took is reported separately (matching.plan)
             kw.pop("stats_host", None)
             self.plan_modes.append(kw.pop("mode", 0))
-            best, flag = timed_match(x0, x1, ar, br, align, True, seed=seed)
+            best, flag = timed_match(x0, x1, ar, br, align, True, seed=seed, **kw)     # (kw: the position order's inverse maps)
             self.match_flags.append((flag, ar.shape[1] if align else x0.shape[0] * ar.shape[1], x0.shape[2]))
             return best
         self.lib_mod.match_filtered = match_with_counters
         self._wrap("match", "matching", lambda a, b, Ns, Nd, align: 2.0 * a.shape[0] * Ns * Nd * a.shape[1] * 8)
+        # the position sort in front of levels 2 / global (vtm_position_order) is matcher time (its calls are not counted as
+        # matcher calls: `order_calls`)
+        self.records["position_order"] = []
+        self._wrap("position_order", "position_order", lambda *a, **k: 0.0)
         # the HBM-bound kernels: algorithmic BYTES per call (rows read + rows written, indices ignored)
         esz = lambda t: t.element_size()
         self._wrap("layernorm", "layernorm", lambda x, w, b, eps: 2.0 * x.numel() * esz(x))
@@ -758,7 +767,7 @@ def main():
         """The per-regime entry of `regimes`: step time, the two big components, what is left, and the matcher's counters."""
         mt, tp = r["mt"], r["timed_passes"]
         comp = mt.ms_by_kind()
-        att, mat = comp.get("attention", 0.0) / tp, comp.get("matching", 0.0) / tp
+        att, mat = comp.get("attention", 0.0) / tp, (comp.get("matching", 0.0) + comp.get("position_order", 0.0)) / tp
         cnt = mt.match_counters() or {}
         return {"ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "steps_per_s": round(world * r["steps"] / r["dt"], 3),
                 "steps": r["steps"], "attention_ms": round(att, 3), "matching_ms": round(mat, 3),
@@ -775,6 +784,8 @@ def main():
     aflops, ams, an = mt.summary("attention")
     top_flops, top_ms, top_n = mt.largest("attention")
     mflops, mms, mn = mt.summary("matching")
+    _, oms, on = mt.summary("position_order")
+    mms += oms
     line = None
 
     if rank == 0:
@@ -811,7 +822,7 @@ def main():
         # gaps and host time
         comp = {k: round(v / timed_passes, 3) for k, v in sorted(mt.ms_by_kind().items(), key=lambda kv: -kv[1])}
         comp_sum = sum(comp.values())
-        side = comp_sum - comp.get("attention", 0.0) - comp.get("matching", 0.0)
+        side = comp_sum - comp.get("attention", 0.0) - comp.get("matching", 0.0) - comp.get("position_order", 0.0)
 
         par = f"chunk-parallel x{world}"
         if mode is not None:
@@ -892,12 +903,13 @@ def main():
             # its partial-sum pruning skips the MFMAs of 32 x 32 blocks that can no longer matter -- `counters` carries the
             # fraction of blocks pruned and of MFMA work really executed (device-side counters of one extra untimed pass).
             # The exact fallback kernel runs on the fp32 MFMA (157.3 TFLOP/s).
-            "matching": {"kernels": "prep_operand + filter_kernel + refine_kernel + exact_rows_kernel (vtm_match_filtered)" if filtered
+            "matching": {"kernels": "prep_operand + filter_kernel + refine_kernel + exact_rows_kernel (vtm_match_filtered{,_ordered}) + vtm_position_order" if filtered
                                     else "match_kernel (vtm_match)",
                          "nominal_tflops": round(mat_tf, 1),
                          "peak": FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS,
                          "nominal_frac": round(mat_tf / (FP16_PEAK_TFLOPS if filtered else FP32_PEAK_TFLOPS), 4),
                          "calls": mn, "matching_ms_per_step": round(mms / timed_passes, 3),
+                         "position_order_calls": on, "position_order_ms_per_step": round(oms / timed_passes, 3),
                          # device-side counters of one extra untimed pass: pairs the exact refine pass evaluated per src row,
                          # rows whose candidate list overflowed (exact_rows_kernel), calls recomputed as a whole, blocks pruned
                          "counters": mt.match_counters() if filtered else None},
@@ -955,7 +967,7 @@ def main():
                 continue
             if name not in REGIME_NOTES:
                 raise SystemExit(f"bench.py: unknown regime {name!r}")
-            regs[name] = compact(run_region(name, max(1, args.regime_steps), min(args.warmup, 2), None, False))
+            regs[name] = compact(run_region(name, max(1, args.regime_steps), REGIME_WARMUP, None, False))
         base = regs.get("corr05", {}).get("ms_per_step")
         for name, r in regs.items():
             r["vs_corr05"] = round(r["ms_per_step"] / base, 3) if base else None

@@ -151,6 +151,36 @@ int vtm_match_filtered_plan(const void *x0, int64_t P0, const void *x1, int64_t 
                             int64_t seed_L, int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table,
                             int mode, vtm_stream_t stream);
 
+/* vtm_position_order + vtm_match_filtered_ordered (round 5) -- the matcher on POSITION-ORDERED rows, result in the caller's
+ * indexing.  The reference's sequence order behind the first level is [unmerged tokens by descending score | dst tokens]
+ * (merge.py:98-117): a 32 x 32 score block then holds a same-position pair of two frames with probability 0.25-0.4 and a
+ * quarter of the blocks survive the filter's pruning test, against 1 % when the rows lie in position order.  The matcher's
+ * result -- per src row the maximal canonical score and the LOWEST dst index attaining it -- does not depend on the order in
+ * which the rows are met, so:
+ *   vtm_position_order sorts both row lists of a call by token position (position of pool row r: r % N for r < L, the
+ *   chunk's (frame, position) rows; pos1[b, r - P0] for the rows of x1, pos1 NULL or out of range = none: such rows go behind
+ *   the last position) -- a counting sort, stable (ties by original index), 3 small launches for both operands of all B
+ *   samples.  Outputs: a_sorted / b_sorted = the lists in position order, a_order / b_order = the original index of every
+ *   sorted entry, table (B, N; optional) = position -> first sorted dst entry holding it, -1 = none (the seed table of the
+ *   call).  counters: vtm_position_order_counter_ints(B, N) int32 that must be ZERO on entry and are zero again when the call
+ *   has run (allocate zeroed once, reuse); ws: vtm_position_order_ws_bytes bytes of scratch.
+ *   vtm_match_filtered_ordered = vtm_match_filtered_plan on the sorted lists (never aligned), with refine / escape reporting
+ *   row and column through a_order / b_order and breaking ties by the ORIGINAL dst index: `best` is bit-identical to
+ *   vtm_match_filtered(a_rows, b_rows).  With VTM_MATCH_SCOUT_RANGE the dst axis is one position-major run cut
+ *   into the one-launch plan's splits (a src tile's span lies in one or two of them).  N <= VTM_POSITION_ORDER_MAX_N. */
+#define VTM_POSITION_ORDER_MAX_N 16360   /* tokens per frame: N + 2 offsets in 64 KB of LDS */
+size_t vtm_position_order_counter_ints(int64_t B, int64_t N);
+size_t vtm_position_order_ws_bytes(int64_t B, int64_t Ns, int64_t Nd, int64_t N);
+int vtm_position_order(const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd, int64_t B, int64_t L,
+                       int64_t N, const int32_t *pos1, int64_t P0, int64_t P1, int32_t *counters, void *ws,
+                       size_t ws_bytes, int32_t *a_sorted, int32_t *a_order, int32_t *b_sorted, int32_t *b_order,
+                       int32_t *table, vtm_stream_t stream);
+int vtm_match_filtered_ordered(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                               int64_t C, const int32_t *a_sorted, int64_t Ns, const int32_t *b_sorted, int64_t Nd,
+                               void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out, int64_t seed_L,
+                               int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table, int mode,
+                               const int32_t *a_order, const int32_t *b_order, vtm_stream_t stream);
+
 /* node_max (fp32, -0 canonicalised to +0) and node_idx (int32) out of packed keys; either output may
  * be NULL. */
 int vtm_decode_best(const uint64_t *best, int64_t n, float *node_max, int32_t *node_idx,

@@ -363,10 +363,118 @@ def test_match_scout_range_plan_equals_exact(L, align):
             assert torch.equal(got, L.match(a_op, b_op, Ns, Nd, align)) and int(flag[0]) == 1
 
 
+def test_position_order_is_a_stable_sort_by_position(L):
+    """vtm_position_order: both lists sorted by token position (chunk rows: row % N; x1 rows: pos1; rows without a position
+    last), ties in original order, `order` = the original index of every sorted entry, `table` = position -> first sorted dst
+    entry holding it, and the counter block all zero again afterwards."""
+    g = torch.Generator().manual_seed(3)
+    for (B, Ns, Nd, Lrows, N, P1) in [(2, 1000, 1500, 2048, 256, 700), (1, 37, 5, 64, 16, 0), (3, 4096, 4096, 8192, 1024, 3000),
+                                       (2, 300, 200, 0, 7, 600)]:
+        pool = Lrows + P1
+        ra = torch.randint(0, pool, (B, Ns), generator=g, dtype=torch.int32).to(DEV)
+        rb = torch.randint(0, pool, (B, Nd), generator=g, dtype=torch.int32).to(DEV)
+        pos1 = torch.randint(-2, N + 3, (B, P1), generator=g, dtype=torch.int32).to(DEV) if P1 else None
+        a_s, a_o, b_s, b_o, table = L.position_order(ra, rb, Lrows, N, pos1, Lrows)
+        torch.cuda.synchronize()
+
+        def pos_of(rows):
+            r = rows.long()
+            p = torch.where(r < Lrows, r % N, torch.full_like(r, N))
+            if pos1 is not None:
+                idx = (r - Lrows).clamp(0, P1 - 1)
+                pp = torch.gather(pos1.long(), 1, idx)
+                pp = torch.where((pp >= 0) & (pp < N), pp, torch.full_like(pp, N))
+                p = torch.where(r >= Lrows, pp, p)
+            return p
+        for rows, srt, order in ((ra, a_s, a_o), (rb, b_s, b_o)):
+            assert torch.equal(torch.gather(rows, 1, order.long()), srt)
+            key = pos_of(rows) * rows.shape[1] + torch.arange(rows.shape[1], device=DEV)       # (position, original index)
+            want = torch.argsort(key, dim=1).to(torch.int32)
+            assert torch.equal(order, want)
+        pb = pos_of(b_s)
+        for b in range(B):
+            t = table[b].tolist()
+            pbl = pb[b].tolist()
+            for p_ in range(N):
+                first = pbl.index(p_) if p_ in pbl else -1
+                assert t[p_] == first, (b, p_)
+        key = next(k for k in L._ZEROED)
+        assert int(L._ZEROED[key].abs().sum()) == 0
+
+
+def test_match_position_ordered_equals_exact(L):
+    """vtm_match_filtered_ordered: the matcher handed both row lists sorted by token position must report, in the ORIGINAL
+    indexing, the bits of the exact matcher on the original lists -- rows in random order (what levels 2 / global see), rows
+    listed twice (exact ties between dst rows: the lowest ORIGINAL index wins, in refine and in the escape), every data regime
+    incl. the flat region (escape) and duplicates, a two-part pool with positions, rows without a position, a zero dst token
+    (whole-call escape, NaN rule by original index), both launch plans."""
+    from vidtome_amd import sites
+    g = torch.Generator().manual_seed(91)
+    cases = [("corr01", 2, 8, 256, 320, 6), ("corr002", 2, 8, 256, 320, 6), ("corr05", 2, 8, 256, 320, 6),
+             ("smooth", 2, 8, 256, 320, 6), ("dup", 2, 8, 256, 320, 6), ("flat25", 2, 8, 256, 320, 6),
+             ("n01", 2, 8, 256, 320, 6), ("corr01", 3, 5, 384, 256, 3), ("corr05", 2, 6, 512, 640, 4),
+             ("corr01", 1, 7, 441, 320, 5), ("corr01", 2, 12, 1024, 320, 9), ("flat25", 1, 6, 1024, 320, 4)]
+    for ci, (regime, B, F, N, C, fs) in enumerate(cases):
+        x = sites.regime_tokens(regime, B, F, N, C, g)
+        x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, F * N, C).half().to(DEV)
+        Ns0, Nd0 = fs * N, (F - fs) * N
+        # random order, a tenth of the rows listed twice, ragged lengths
+        def listing(lo, n):
+            extra = torch.randint(lo, lo + n, (B, n // 10 + 3), generator=g)
+            rows = torch.cat([torch.arange(lo, lo + n).expand(B, n), extra], 1)
+            perm = torch.stack([torch.randperm(rows.shape[1], generator=g) for _ in range(B)])
+            return torch.gather(rows, 1, perm).to(torch.int32).to(DEV).contiguous()
+        ra, rb = listing(0, Ns0), listing(Ns0, Nd0)
+        Ns, Nd = ra.shape[1], rb.shape[1]
+        a_op, _ = L.normalize_gather(x, None, ra)
+        b_op, _ = L.normalize_gather(x, None, rb)
+        exact = L.match(a_op, b_op, Ns, Nd, False)
+        a_s, a_o, b_s, b_o, table = L.position_order(ra, rb, F * N, N, None, F * N)
+        seed = (N, F * N, None, table)
+        for mode in (L.MATCH_ONE_LAUNCH, L.MATCH_SCOUT_RANGE):
+            got, flag = L.match_filtered(x, None, a_s, b_s, False, want_flag=True, seed=seed, mode=mode, order=(a_o, b_o))
+            assert torch.equal(got, exact), (regime, B, F, N, C, mode)
+            f = flag.tolist()
+            if mode == L.MATCH_SCOUT_RANGE and Nd > 128:
+                assert f[4] > 0 and 0 < f[7] <= f[4], (regime, f)
+                if regime in ("corr01", "corr002") and N >= 1024:
+                    assert f[7] < 0.3 * f[4], (regime, f)
+            if regime == "flat25":
+                assert f[2] > 0, (regime, f)                       # the escape ran (and broke its ties by original index)
+        # no seeds / garbage seeds
+        assert torch.equal(L.match_filtered(x, None, a_s, b_s, False, order=(a_o, b_o)), exact)
+        junk = torch.randint(-3, Nd + 50, (B, N), generator=g, dtype=torch.int32).to(DEV)
+        assert torch.equal(L.match_filtered(x, None, a_s, b_s, False, seed=(N, F * N, None, junk), mode=L.MATCH_SCOUT_RANGE,
+                                            order=(a_o, b_o)), exact)
+        if ci in (2, 5):
+            # a zero dst token: the whole call is recomputed by the escape; NaN maxima report the lowest ORIGINAL NaN index
+            x2 = x.clone()
+            x2[B - 1, Ns0 + 7] = 0
+            a2, _ = L.normalize_gather(x2, None, ra)
+            b2, _ = L.normalize_gather(x2, None, rb)
+            got, flag = L.match_filtered(x2, None, a_s, b_s, False, want_flag=True, seed=seed, mode=L.MATCH_SCOUT_RANGE,
+                                         order=(a_o, b_o))
+            assert torch.equal(got, L.match(a2, b2, Ns, Nd, False)) and int(flag[0]) == 1
+        if ci in (0, 4, 8):
+            # two-part pool: the dst rows (and then the src rows) are x1 rows with positions, some of them unknown
+            x0, x1 = x[:, :Ns0].contiguous(), x[:, Ns0:].contiguous()
+            pos1 = (torch.arange(Nd0, dtype=torch.int32) % N).expand(B, Nd0).clone()
+            pos1[:, ::17] = -1
+            pos1 = pos1.to(DEV).contiguous()
+            for (la, lb, ea, eb) in ((ra, rb, a_op, b_op), (rb, ra, b_op, a_op)):
+                ex = L.match(ea, eb, la.shape[1], lb.shape[1], False)
+                s_a, o_a, s_b, o_b, tb = L.position_order(la, lb, Ns0, N, pos1, Ns0)
+                for mode in (L.MATCH_ONE_LAUNCH, L.MATCH_SCOUT_RANGE):
+                    got = L.match_filtered(x0, x1, s_a, s_b, False, seed=(N, Ns0, pos1, tb), mode=mode, order=(o_a, o_b))
+                    assert torch.equal(got, ex), (regime, mode)
+
+
 def test_match_planner_steers_by_the_previous_calls_counters(L):
     """merge.MatchPlanner: a scout + range call copies its counters into the planner's pinned buffer (no synchronisation in
     the product path; the test synchronises to look); uncorrelated tokens (every wave tile alive) send the block's first level
-    back to the one-launch plan for COOL calls, frames of a low-noise clip keep the scout + range plan."""
+    back to the one-launch plan for COOL calls, frames of a low-noise clip keep the scout + range plan.  Behind the first level
+    the planner also says whether the rows are position-ordered while the plan is off: the global level keeps the ordering
+    (`order_alone`) unless nothing at all died at the scout's test, level 2 drops it."""
     from vidtome_amd import merge, sites
     g = torch.Generator().manual_seed(5)
     B, F, N, C, fs = 2, 8, 4096, 320, 6          # 4 096 tokens per frame: a src tile's matches sit in 2 of a frame's 32 dst tiles
@@ -378,8 +486,8 @@ def test_match_planner_steers_by_the_previous_calls_counters(L):
         x = sites.regime_tokens(regime, B, F, N, C, g)
         x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, F * N, C).half().to(DEV)
         pl = merge.MatchPlanner()
-        mode, buf = pl.next()
-        assert mode == L.MATCH_SCOUT_RANGE and buf.is_pinned()
+        mode, buf, keep = pl.next()
+        assert mode == L.MATCH_SCOUT_RANGE and buf.is_pinned() and keep
         L.match_filtered(x, None, ra, rb, False, seed=seed, mode=mode, stats_host=buf)
         torch.cuda.synchronize()
         assert int(buf[4]) > 0, buf.tolist()
@@ -388,6 +496,31 @@ def test_match_planner_steers_by_the_previous_calls_counters(L):
             for _ in range(merge.MatchPlanner.COOL - 1):
                 assert pl.next()[0] == L.MATCH_ONE_LAUNCH
             assert pl.next()[0] == L.MATCH_SCOUT_RANGE          # ... and tries again
+    # a position-ordered level (rows in random order, sorted for the matcher): low-noise clip -> ordered + range; a noisy one
+    # -> one launch, ordered at the global level (order_alone) and not at level 2; uncorrelated tokens -> the first one-launch
+    # call reports that nothing dies in the filter either and the ordering is dropped
+    perm_a = torch.stack([torch.randperm(Ns, generator=g) for _ in range(B)]).to(torch.int32).to(DEV)
+    perm_b = torch.stack([Ns + torch.randperm(Nd, generator=g) for _ in range(B)]).to(torch.int32).to(DEV)
+    for regime, order_alone, expect, settled in (("corr01", True, (L.MATCH_SCOUT_RANGE, True), None),
+                                                 ("corr05", True, (L.MATCH_ONE_LAUNCH, True), True),
+                                                 ("corr05", False, (L.MATCH_ONE_LAUNCH, False), None),
+                                                 ("n01", True, (L.MATCH_ONE_LAUNCH, True), False)):
+        x = sites.regime_tokens(regime, B, F, N, C, g)
+        x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, F * N, C).half().to(DEV)
+        pl = merge.MatchPlanner(order_alone)
+        mode, buf, keep = pl.next()
+        assert mode == L.MATCH_SCOUT_RANGE and keep
+        a_s, a_o, b_s, b_o, tb = L.position_order(perm_a, perm_b, F * N, N, None, F * N)
+        L.match_filtered(x, None, a_s, b_s, False, seed=(N, F * N, None, tb), mode=mode, stats_host=buf, order=(a_o, b_o))
+        torch.cuda.synchronize()
+        mode, buf, keep = pl.next()
+        assert (mode, keep) == expect, (regime, order_alone, pl.view.tolist())
+        if settled is not None:
+            assert buf is not None                    # the one-launch call is asked for its counters once ...
+            L.match_filtered(x, None, a_s, b_s, False, seed=(N, F * N, None, tb), mode=mode, stats_host=buf, order=(a_o, b_o))
+            torch.cuda.synchronize()
+            mode, buf, keep = pl.next()
+            assert mode == L.MATCH_ONE_LAUNCH and buf is None and keep == settled, (regime, pl.view.tolist())
 
 
 def test_refine_many_candidates_per_row(L):
@@ -733,8 +866,19 @@ def _tie_aware_equal(level, ref_unm, ref_src, ref_dst, align):
         assert np.array_equal(exp_dst, ref_dst[b])
 
 
+@pytest.fixture(params=["by_geometry", "every_level"])
+def order_rule(request, monkeypatch):
+    """Which levels behind the first meet their rows in position order (merge.order_level): the product's rule (levels of
+    >= 2^26 pairs -- none of the small fixtures), or every one (the fixtures then run through vtm_position_order +
+    vtm_match_filtered_ordered end to end)."""
+    from vidtome_amd import merge
+    if request.param == "every_level":
+        monkeypatch.setattr(merge, "POSITION_ORDER_MIN_PAIRS", 0)
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["chain_cfg_f4", "chain_cfg_f8", "chain_pnp_f4", "chain_local_f4"])
-def test_chain_golden_gpu(L, name):
+def test_chain_golden_gpu(L, name, order_rule):
     import vidtome_amd
     from vidtome_amd import patch as vpatch
     from vidtome_amd import pnp
@@ -807,7 +951,7 @@ def test_chain_golden_gpu(L, name):
 @pytest.mark.parametrize("name,proj", [("chain16_cfg_f4_d40", "auto"), ("chain16_pnp_f4_d64", "auto"),
                                        ("chain16_pnp_f4_d64", "panels"), ("chain16_cfg_f8_d80", "auto"),
                                        ("chain16_cfg_f8_d80", "panels")])
-def test_default_fp16_path_vs_reference_chain(L, name, proj, monkeypatch):
+def test_default_fp16_path_vs_reference_chain(L, name, proj, monkeypatch, order_rule):
     """The DEFAULT path of an fp16 model -- gather-fed projection GEMMs (C <= 320) / panel GEMMs (C = 640), live and
     compacted queries, the fp16 attention core -- against BLOCK OUTPUTS RECORDED FROM THE REFERENCE
     (tests/golden/make_golden_chain16.py: the reference's apply_patch + ToMeBlock.forward + sa_forward on its CPU fp32 path,
@@ -2234,7 +2378,7 @@ def test_full_size_properties(L):
                            torch.arange(lv.Ns, device=DEV, dtype=torch.int32)[None].expand(B, -1))
 
 
-def test_compute_merge_reference_fuzz_gpu(L):
+def test_compute_merge_reference_fuzz_gpu(L, order_rule):
     """The same 115 reference-generated configurations as tests/test_oracle_golden.py::test_oracle_vs_reference_fuzz,
     through the HIP planner: merged tokens, stored anchor tokens and u(merged) hash-equal to the reference's."""
     import os
@@ -2264,7 +2408,7 @@ def test_compute_merge_reference_fuzz_gpu(L):
             assert fuzz_hash(u(merged).cpu().numpy()) == want[2], (cfg, ck)
 
 
-def test_compute_merge_fuzz_vs_oracle(L, oracle):
+def test_compute_merge_fuzz_vs_oracle(L, oracle, order_rule):
     """End-to-end planner fuzz: random (B, F per chunk, token grid, C, ratios, align_batch, global merging, coin
     threshold) over three consecutive chunks of a block; merged tokens, anchor tokens and the unmerge of a random
     tensor must equal the CPU oracle's (patch.py:14-91 restated) exactly -- they are row copies, so any index

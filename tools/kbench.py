@@ -55,6 +55,10 @@ def main():
                     "first dst frame)")
     ap.add_argument("--plan", default="one", choices=["one", "range"], help="match: launch plan of the filtered matcher "
                     "(one launch / scout + range; same bits)")
+    ap.add_argument("--shuffle", action="store_true", help="match: src rows and the dst rows behind the first dst frame in "
+                    "random order (what levels 2 / global see: similarity-rank order) instead of (frame, position) order")
+    ap.add_argument("--ordered", action="store_true", help="match: sort both row lists by token position first "
+                    "(vtm_position_order + vtm_match_filtered_ordered, what levels 2 / global do); the sort is inside the timing")
     ap.add_argument("--C", type=int, default=320)
     ap.add_argument("--data", default="random", help="attn: random | zeros | const (operand values); match: n01 | corr01 | "
                     "corr05 | flat25 | dup | zero | all (token regime; random = n01 in fp16 straight from the device generator)")
@@ -70,6 +74,10 @@ def main():
         N = 4096
         while Ns % N or Nd % N:
             N //= 2
+        if a.shuffle:
+            gp = torch.Generator().manual_seed(5)
+            ra = ra[:, torch.randperm(Ns, generator=gp).to(dev)].contiguous()
+            rb = torch.cat([rb[:, :N], rb[:, N:][:, torch.randperm(Nd - N, generator=gp).to(dev)]], 1).contiguous()
         seed = None if a.no_seed else (N, Ns + Nd, None, None)
 
         def tokens(regime):
@@ -84,7 +92,7 @@ def main():
 
         regimes = ["n01", "corr01", "corr002", "corr05", "smooth", "flat25", "dup", "zero"] if a.data == "all" else [a.data]
         fl = 2.0 * B * Ns * Nd * C
-        print(f"match {a.shape} B={B} Ns={Ns} Nd={Nd} C={C} align={a.align} seeded={bool(seed)} plan={a.plan}")
+        print(f"match {a.shape} B={B} Ns={Ns} Nd={Nd} C={C} align={a.align} seeded={bool(seed)} plan={a.plan} shuffled={a.shuffle} ordered={a.ordered}")
         print(f"{'data':8s} {'filtered ms':>12s} {'nom TFLOP/s':>12s} {'exact ms':>9s} {'pairs/row':>10s} {'escape rows':>12s} {'whole-call':>10s} {'blocks alive':>12s} equal")
         for regime in regimes:
             x = tokens(regime)
@@ -92,12 +100,22 @@ def main():
             bop, _ = _lib.normalize_gather(x, None, rb)
             med, best = timeit(lambda: _lib.match(aop, bop, Ns, Nd, a.align), a.iters)
             mode = _lib.MATCH_SCOUT_RANGE if a.plan == "range" else _lib.MATCH_ONE_LAUNCH
-            medf, bestf = timeit(lambda: _lib.match_filtered(x, None, ra, rb, a.align, seed=seed, mode=mode), a.iters)
-            out, fl_ = _lib.match_filtered(x, None, ra, rb, a.align, want_flag=True, seed=seed, mode=mode)
+            def run(want_flag=False):
+                if not a.ordered:
+                    return _lib.match_filtered(x, None, ra, rb, a.align, want_flag=want_flag, seed=seed, mode=mode)
+                a_s, a_o, b_s, b_o, tb = _lib.position_order(ra, rb, Ns + Nd, N, None, Ns + Nd)
+                return _lib.match_filtered(x, None, a_s, b_s, a.align, want_flag=want_flag, seed=(N, Ns + Nd, None, tb), mode=mode,
+                                           order=(a_o, b_o))
+            medf, bestf = timeit(run, a.iters)
+            if a.ordered:
+                meds, _ = timeit(lambda: _lib.position_order(ra, rb, Ns + Nd, N, None, Ns + Nd), a.iters)
+                print(f"  (vtm_position_order alone: {meds * 1e3:.1f} us)")
+            out, fl_ = run(True)
             same = bool(torch.equal(out, _lib.match(aop, bop, Ns, Nd, a.align)))
             f = fl_.tolist()                # [whole-call exact, non-finite, escape rows, refined pairs, blocks tested, alive, 0, 0]
             rows = Ns if a.align else B * Ns
-            print(f"{regime:8s} {medf:12.3f} {fl / medf / 1e9:12.1f} {med:9.3f} {f[3] / rows:10.2f} {f[2]:12d} {f[0]:10d} {(f[5] / f[4] if f[4] else 1.0):12.3f} {same}")
+            print(f"{regime:8s} {medf:12.3f} {fl / medf / 1e9:12.1f} {med:9.3f} {f[3] / rows:10.2f} {f[2]:12d} {f[0]:10d} {(f[5] / f[4] if f[4] else 1.0):12.3f} {same}"
+                  + (f"  spans {f[7] / f[4]:.3f}" if f[4] and f[7] else ""))
             del aop, bop
     elif a.what == "attn":
         B, M, h, d = a.B, a.M, a.heads, a.d

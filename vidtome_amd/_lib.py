@@ -41,6 +41,12 @@ _SIGNATURES = {
                             _vp, _vp, _vp], _int),
     "vtm_match_filtered_plan": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
                                  _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp], _int),
+    "vtm_match_filtered_ordered": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _vp, ctypes.c_size_t,
+                                    _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp], _int),
+    "vtm_position_order_counter_ints": ([_i64, _i64], ctypes.c_size_t),
+    "vtm_position_order_ws_bytes": ([_i64, _i64, _i64, _i64], ctypes.c_size_t),
+    "vtm_position_order": ([_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp, _vp,
+                            _vp, _vp, _vp], _int),
     "vtm_match_filtered_seeded": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
                                    _vp, _vp, _i64, _i64, _vp, _vp, _vp], _int),
     "vtm_anchor_pos": ([_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp], _int),
@@ -173,6 +179,7 @@ def release_workspaces() -> None:
     """Drop the cached scratch buffers (they are re-created on demand)."""
     with _WS_LOCK:
         _WS.clear()
+        _ZEROED.clear()
 
 
 def _req(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -232,7 +239,7 @@ MATCH_ONE_LAUNCH, MATCH_SCOUT_RANGE = 0, 1         # include/vidtome_hip.h: VTM_
 @_on_device
 def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.Tensor, b_rows: torch.Tensor,
                    align: bool, want_flag: bool = False, seed=None, mode: int = MATCH_ONE_LAUNCH,
-                   stats_host: Optional[torch.Tensor] = None):
+                   stats_host: Optional[torch.Tensor] = None, order=None):
     """Same packed result as normalize_gather x2 + match, through the fp16-filter / fp32-refine path.  ``seed`` (optional,
     never changes the result): (tokens per frame N, L = pool rows that are chunk tokens, pos1 (B, P1) int32 positions of the
     x1 rows or None, table (B, N) int32 position -> dst index or None for identity) -- every src row then starts from the
@@ -240,7 +247,9 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
     launch + the filter over the spans of live dst tiles, for levels with position-ordered rows; same bits;
     include/vidtome_hip.h, vtm_match_filtered_plan).  ``stats_host``: a PINNED host tensor of 8 int32 that receives the
     call's counters asynchronously (flags_out of the C ABI) -- what merge.MatchPlanner steers by; ``want_flag`` returns them
-    as a device tensor instead."""
+    as a device tensor instead.  ``order`` = (a_order, b_order) from `position_order`: a_rows / b_rows are then its SORTED lists
+    and the result is reported (and ties are broken) in the original indexing -- the same bits as the call on the unsorted
+    lists (vtm_match_filtered_ordered; never aligned)."""
     _req(x0, "x0"), _req(a_rows, "a_rows"), _req(b_rows, "b_rows")
     B, P0, C = x0.shape
     P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
@@ -264,11 +273,67 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
             raise RuntimeError("match_filtered: seed positions must be a contiguous (B, P1) int32 tensor")
         if table is not None and (table.dtype != torch.int32 or tuple(table.shape) != (B, sN) or not table.is_contiguous()):
             raise RuntimeError("match_filtered: the seed table must be a contiguous (B, N) int32 tensor")
+    if order is not None:
+        a_order, b_order = order
+        if align:
+            raise RuntimeError("match_filtered: position-ordered calls are never aligned")
+        for o, n, name in ((a_order, Ns, "a_order"), (b_order, Nd, "b_order")):
+            if o.dtype != torch.int32 or tuple(o.shape) != (B, n) or not o.is_contiguous() or not o.is_cuda:
+                raise RuntimeError(f"match_filtered: {name} must be a contiguous (B, {n}) int32 device tensor")
+        _check(lib().vtm_match_filtered_ordered(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(a_rows), Ns,
+                                                _ptr(b_rows), Nd, _ptr(ws), nbytes, _ptr(best), flags_out, int(sL), int(sN),
+                                                _ptr(pos1), _ptr(table), int(mode), _ptr(a_order), _ptr(b_order), _stream()),
+               "vtm_match_filtered_ordered")
+        return (best, flag) if want_flag else best
     _check(lib().vtm_match_filtered_plan(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(a_rows), Ns,
                                          _ptr(b_rows), Nd, int(align), _ptr(ws), nbytes, _ptr(best), flags_out,
                                          int(sL), int(sN), _ptr(pos1), _ptr(table), int(mode), _stream()),
            "vtm_match_filtered_plan")
     return (best, flag) if want_flag else best
+
+
+POSITION_ORDER_MAX_N = 16360        # include/vidtome_hip.h: VTM_POSITION_ORDER_MAX_N
+_ZEROED: dict = {}
+
+
+def _zeroed_counters(n_ints: int, device: torch.device) -> torch.Tensor:
+    """The counter block of vtm_position_order: zero when a call starts, zero again when it has run -- allocated (zeroed)
+    once per (device, stream, thread) like the scratch buffers, re-allocated when a larger one is needed."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
+    buf = _ZEROED.get(key)
+    if buf is None or buf.numel() < n_ints:
+        buf = torch.zeros((max(int(n_ints), 16),), dtype=torch.int32, device=device)
+        with _WS_LOCK:
+            _ZEROED[key] = buf
+    return buf
+
+
+@_on_device
+def position_order(a_rows: torch.Tensor, b_rows: torch.Tensor, L: int, N: int, pos1: Optional[torch.Tensor], P0: int,
+                   want_table: bool = True):
+    """Both row lists of a matcher call sorted by token position (vtm_position_order, include/vidtome_hip.h):
+    -> (a_sorted, a_order, b_sorted, b_order, table).  Position of pool row r: r % N below L, pos1[b, r - P0] for the rows of
+    x1 (``pos1`` (B, P1) int32 or None)."""
+    _req(a_rows, "a_rows"), _req(b_rows, "b_rows")
+    B, Ns = a_rows.shape
+    Nd = b_rows.shape[1]
+    P1 = 0
+    if pos1 is not None:
+        if pos1.dtype != torch.int32 or pos1.dim() != 2 or pos1.shape[0] != B or not pos1.is_contiguous():
+            raise RuntimeError("position_order: positions must be a contiguous (B, P1) int32 tensor")
+        P1 = pos1.shape[1]
+    dev = a_rows.device
+    counters = _zeroed_counters(lib().vtm_position_order_counter_ints(B, N), dev)
+    nbytes = lib().vtm_position_order_ws_bytes(B, Ns, Nd, N)
+    ws = _workspace("order", nbytes, dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    a_sorted, a_order = torch.empty((B, Ns), **i32), torch.empty((B, Ns), **i32)
+    b_sorted, b_order = torch.empty((B, Nd), **i32), torch.empty((B, Nd), **i32)
+    table = torch.empty((B, N), **i32) if want_table else None
+    _check(lib().vtm_position_order(_ptr(a_rows), Ns, _ptr(b_rows), Nd, B, int(L), int(N), _ptr(pos1), int(P0), P1,
+                                    _ptr(counters), _ptr(ws), nbytes, _ptr(a_sorted), _ptr(a_order), _ptr(b_sorted),
+                                    _ptr(b_order), _ptr(table), _stream()), "vtm_position_order")
+    return a_sorted, a_order, b_sorted, b_order, table
 
 
 @_on_device

@@ -978,7 +978,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
                                                      const uint2 *__restrict__ cand, int *__restrict__ ovf_cnt,
                                                      int *__restrict__ ovf_rows, uint2 *__restrict__ pairs,
                                                      const float *__restrict__ tile_rest, int64_t n_tile_rest,
-                                                     unsigned long long *__restrict__ best) {
+                                                     unsigned long long *__restrict__ best,
+                                                     const int32_t *__restrict__ src_order,
+                                                     const int32_t *__restrict__ dst_order) {
     __shared__ int wave_tot[4];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1113,7 +1115,11 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
             load8(pb + k, fb);
             chain8(fa, fb);
         }
-        atomicMax(&best[prow], ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~col));
+        // position-ordered call (vtm_match_filtered_ordered; never aligned): row and column in the caller's ORIGINAL indexing,
+        // so that the packed maximum's tie rule -- lowest dst index -- is the original one
+        const int64_t orow = src_order ? bi * Ns + src_order[prow] : prow;
+        const uint32_t ocol = dst_order ? (uint32_t)dst_order[bi * Nd + j] : col;
+        atomicMax(&best[orow], ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~ocol));
     }
 }
 
@@ -1142,15 +1148,20 @@ static_assert(XS == 128 || XS == 256, "src tile");
 
 __device__ __forceinline__ int64_t xcdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-template <typename T>
+template <typename T, bool ORD>
 __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
     const T *__restrict__ x0, int64_t P0, const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
     const int32_t *__restrict__ a_rows, int64_t Ns, const int32_t *__restrict__ b_rows, int64_t Nd,
     const float *__restrict__ na, const float *__restrict__ nb, int align, const int *__restrict__ flags,
     const int *__restrict__ ovf_cnt, const int *__restrict__ ovf_rows, unsigned long long *__restrict__ best, int nsplit,
     int tiles_per_split, const float *__restrict__ rest_a, const float *__restrict__ rest_bt, int KX, int64_t Ns_pad,
-    int64_t rest_tiles, const unsigned int *__restrict__ seed_lb, int *__restrict__ work) {
+    int64_t rest_tiles, const unsigned int *__restrict__ seed_lb, int *__restrict__ work,
+    const int32_t *__restrict__ src_order, const int32_t *__restrict__ dst_order) {
     __shared__ __attribute__((aligned(16))) float sD[8 * XPD * 4];
+    // position-ordered call: the ORIGINAL index of every dst row of the tile being scored (double-buffered like the row
+    // pointers: the next tile's are staged behind the current tile's last step) -- a lane's running argmax is kept and
+    // tie-broken in the original indexing
+    __shared__ uint32_t sOrd[ORD ? 2 : 1][ORD ? XD : 1];
     __shared__ __attribute__((aligned(16))) float sS[8 * XPS * 4];
     constexpr int RAW = sizeof(T) == 4 ? 2 : 1;      // 16-byte loads per 8-channel piece
 
@@ -1222,6 +1233,8 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
                 const int64_t jj = vd[u] ? j : 0;
                 pd[u] = pool_row(x0, P0, x1, P1, bi, b_rows[bi * Nd + jj], C);
                 dd[u] = row_divisor(nb[bi * Nd + jj]);
+                if constexpr (ORD)
+                    if (pg == 0) sOrd[jt & 1][prow + 64 * u] = vd[u] ? (uint32_t)dst_order[bi * Nd + jj] : 0xffffffffu;
             }
         };
         uint4 raw[2 + XSU][RAW];                       // pieces in flight: dst rows 0 / 1, then the src rows
@@ -1355,9 +1368,16 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
                             const int d = dst0 + ib * 32 + (r & 3) + 8 * (r >> 2);
                             const float sc = acc[ib][sb][r];
                             bool upd = !(sc <= bv_) && (bv_ == bv_);   // greater, or the first NaN (torch.max)
+                            uint32_t od = (uint32_t)d;
+                            if constexpr (ORD) {
+                                // rows arrive in position order: "first" means lowest ORIGINAL index -- among equal
+                                // scores, and among NaNs
+                                od = sOrd[jt & 1][d - jt * XD];
+                                upd = upd || (((sc == bv_) || (sc != sc && bv_ != bv_)) && od < bi_);
+                            }
                             if (!full) upd = upd && (d < Nd);
                             bv_ = upd ? sc : bv_;
-                            bi_ = upd ? (uint32_t)d : bi_;
+                            bi_ = upd ? od : bi_;
                         }
                     }
                     bestv[sb] = bv_;
@@ -1397,7 +1417,8 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
             const int64_t i = listed(wave * (32 * XSB) + sb * 32 + l31);
             if (i >= 0 && besti[sb] != 0xffffffffu) {
                 const uint32_t col = besti[sb] + (align ? (uint32_t)(bi * Nd) : 0u);
-                atomicMax(&best[align ? i : l * Ns + i], ((unsigned long long)orderable(bestv[sb]) << 32) | (uint32_t)(~col));
+                const int64_t orow = align ? i : l * Ns + (ORD ? (int64_t)src_order[l * Ns + i] : i);
+                atomicMax(&best[orow], ((unsigned long long)orderable(bestv[sb]) << 32) | (uint32_t)(~col));
             }
         }
         item = next_item();
@@ -1452,8 +1473,10 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
                                int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
                                int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
                                int64_t seed_L, int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table,
-                               int mode, vtm_stream_t stream) {
+                               int mode, const int32_t *src_order, const int32_t *dst_order, vtm_stream_t stream) {
     VTM_REQUIRE(x0 && a_rows && b_rows && ws && best, "vtm_match_filtered: null pointer");
+    VTM_REQUIRE((src_order == nullptr) == (dst_order == nullptr), "vtm_match_filtered_ordered: both inverse maps or none");
+    VTM_REQUIRE(!(src_order && align), "vtm_match_filtered_ordered: not for aligned calls (one order per sample)");
     VTM_REQUIRE(mode == VTM_MATCH_ONE_LAUNCH || mode == VTM_MATCH_SCOUT_RANGE, "vtm_match_filtered: bad mode %d", mode);
     VTM_REQUIRE(B > 0 && C > 0 && C % 8 == 0 && Ns > 0 && Nd > 0, "vtm_match_filtered: bad sizes");
     VTM_REQUIRE(P1 == 0 || x1, "vtm_match_filtered: x1 is null but P1 > 0");
@@ -1611,13 +1634,18 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
         // dead) and dst frames of whole tiles -- one split per dst frame, so that a span is the live tiles of ONE frame
         const int map_words = (nd_tiles + 31) / 32;
         unsigned int *tilemap = (unsigned int *)(w + L.tilemap);
-        const bool range_plan = mode == VTM_MATCH_SCOUT_RANGE && prune && seed_N >= 2 * FBD && seed_N % FBD == 0 && c_run == L.C64;
+        // (position-ordered call: the whole dst axis is ONE position-major run; the splits stay the one-launch plan's -- a src
+        // tile's span then lies in one or two of them and the other workgroups leave at once, while a level whose spans are long
+        // keeps its parallelism: with a single split corr05's top global level took 2.9 ms instead of 1.3)
+        const bool ordered = src_order != nullptr;
+        const bool range_plan = mode == VTM_MATCH_SCOUT_RANGE && prune && c_run == L.C64 &&
+                                (ordered ? seed_N > 0 && nd_tiles >= 2 : seed_N >= 2 * FBD && seed_N % FBD == 0);
         if (range_plan) {
             hipLaunchKernelGGL(filter_kernel<true>, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
                                L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles,
                                amax, cnt, cand, (int)rows_out, flags, (const float *)rest_a, (const float *)rest_bt, KP,
                                flags_out != nullptr ? 1 : 0, tilemap, map_words);
-            const int tps_r = (int)(seed_N / FBD);
+            const int tps_r = ordered ? tiles_per_split : (int)(seed_N / FBD);
             const int nsplit_r = (int)vtm::cdiv(nd_tiles, tps_r);
             const int64_t grid_r = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit_r;
             hipLaunchKernelGGL(filter_kernel<false>, dim3((unsigned)grid_r), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd,
@@ -1637,7 +1665,7 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
         unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
         const int64_t n_tile_rest = B * (L.Nd_pad / FBD);
 #define VTM_REFINE_ARGS a_rows, Ns, b_rows, Nd, na, nb, align, flags, rows_out, amax, cnt, cand, ovf_cnt, ovf_rows, pairs, \
-                        (const float *)rest_bt, n_tile_rest, bp
+                        (const float *)rest_bt, n_tile_rest, bp, src_order, dst_order
         // the escape: a fixed grid strides over the (device-side) lists of overflowed rows -- normally empty, then the
         // workgroups leave at once; dst splits of >= 8 tiles so that a short list still spreads over the chip
         const int xd_tiles = (int)vtm::cdiv(Nd, XD);
@@ -1649,24 +1677,24 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
         // exact_rows_kernel's tile pruning: the rest norms prep_operand wrote for the filter's cut, in 32-channel steps
         const int KX = getenv("VTM_DEBUG_NOXPRUNE") ? 0 : (int)(cut / XK);
 #define VTM_XPRUNE_ARGS (const float *)rest_a, (const float *)rest_bt, KX, L.Ns_pad, L.Nd_pad / FBD, (const unsigned int *)(w + L.seedlb), \
-                        flags + 6
+                        flags + 6, src_order, dst_order
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(refine_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
                                    B, C, VTM_REFINE_ARGS);
-                hipLaunchKernelGGL(exact_rows_kernel<float>, xgrid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
+                hipLaunchKernelGGL((src_order ? exact_rows_kernel<float, true> : exact_rows_kernel<float, false>), xgrid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
                                    B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt, ovf_rows, bp, xsplit, xtps, VTM_XPRUNE_ARGS);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(refine_kernel<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
                                    P1, B, C, VTM_REFINE_ARGS);
-                hipLaunchKernelGGL(exact_rows_kernel<__half>, xgrid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
+                hipLaunchKernelGGL((src_order ? exact_rows_kernel<__half, true> : exact_rows_kernel<__half, false>), xgrid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
                                    P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt, ovf_rows, bp, xsplit, xtps, VTM_XPRUNE_ARGS);
                 break;
             default:
                 hipLaunchKernelGGL(refine_kernel<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
                                    (const vtm_bf16 *)x1, P1, B, C, VTM_REFINE_ARGS);
-                hipLaunchKernelGGL(exact_rows_kernel<vtm_bf16>, xgrid, block, 0, s, (const vtm_bf16 *)x0, P0,
+                hipLaunchKernelGGL((src_order ? exact_rows_kernel<vtm_bf16, true> : exact_rows_kernel<vtm_bf16, false>), xgrid, block, 0, s, (const vtm_bf16 *)x0, P0,
                                    (const vtm_bf16 *)x1, P1, B, C, a_rows, Ns, b_rows, Nd, na, nb, align, flags, ovf_cnt,
                                    ovf_rows, bp, xsplit, xtps, VTM_XPRUNE_ARGS);
         }
@@ -1686,7 +1714,7 @@ VTM_EXPORT int vtm_match_filtered(const void *x0, int64_t P0, const void *x1, in
                                   int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,
                                   vtm_stream_t stream) {
     return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, b_rows, Nd, align, ws, ws_bytes, best, flags_out, 0, 0,
-                               nullptr, nullptr, VTM_MATCH_ONE_LAUNCH, stream);
+                               nullptr, nullptr, VTM_MATCH_ONE_LAUNCH, nullptr, nullptr, stream);
 }
 
 VTM_EXPORT int vtm_match_filtered_seeded(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
@@ -1696,7 +1724,7 @@ VTM_EXPORT int vtm_match_filtered_seeded(const void *x0, int64_t P0, const void 
                                          vtm_stream_t stream) {
     VTM_REQUIRE(seed_N >= 0 && seed_L >= 0, "vtm_match_filtered_seeded: bad seed description");
     return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, b_rows, Nd, align, ws, ws_bytes, best, flags_out, seed_L,
-                               seed_N, seed_pos1, seed_table, VTM_MATCH_ONE_LAUNCH, stream);
+                               seed_N, seed_pos1, seed_table, VTM_MATCH_ONE_LAUNCH, nullptr, nullptr, stream);
 }
 
 VTM_EXPORT int vtm_match_filtered_plan(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
@@ -1706,7 +1734,18 @@ VTM_EXPORT int vtm_match_filtered_plan(const void *x0, int64_t P0, const void *x
                                        int mode, vtm_stream_t stream) {
     VTM_REQUIRE(seed_N >= 0 && seed_L >= 0, "vtm_match_filtered_plan: bad seed description");
     return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_rows, Ns, b_rows, Nd, align, ws, ws_bytes, best, flags_out, seed_L,
-                               seed_N, seed_pos1, seed_table, mode, stream);
+                               seed_N, seed_pos1, seed_table, mode, nullptr, nullptr, stream);
+}
+
+VTM_EXPORT int vtm_match_filtered_ordered(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
+                                          int64_t C, const int32_t *a_sorted, int64_t Ns, const int32_t *b_sorted, int64_t Nd,
+                                          void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out, int64_t seed_L,
+                                          int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table, int mode,
+                                          const int32_t *a_order, const int32_t *b_order, vtm_stream_t stream) {
+    VTM_REQUIRE(seed_N >= 0 && seed_L >= 0, "vtm_match_filtered_ordered: bad seed description");
+    VTM_REQUIRE(a_order && b_order, "vtm_match_filtered_ordered: null inverse map");
+    return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_sorted, Ns, b_sorted, Nd, 0, ws, ws_bytes, best, flags_out, seed_L,
+                               seed_N, seed_pos1, seed_table, mode, a_order, b_order, stream);
 }
 
 namespace vtm {

@@ -63,7 +63,7 @@ MATCH_PLAN = os.environ.get("VIDTOME_MATCH_PLAN", "auto")
 
 
 class MatchPlanner:
-    """Which launch plan the next call of ONE block's first local level takes (vtm_match_filtered_plan).
+    """How the next call of ONE matching level of one block is launched (vtm_match_filtered_plan / _ordered).
 
     The scout + range plan is ~30 % faster when nearly all 256 x 128 tile pairs die at the scout's test -- frames of one clip
     at low noise -- and ~40 % slower when most stay alive (uncorrelated tokens; a noisy clip, whose matches do not clear the
@@ -72,38 +72,72 @@ class MatchPlanner:
     scout + range call copies its 8 counters asynchronously into this planner's pinned host buffer; the next call reads
     whatever has arrived -- never waiting, never synchronising; a stale or missing reading only delays a switch -- and falls
     back to the one-launch plan for `COOL` calls when the spans the second launch had to stream covered more than `HIGH` of
-    the level, then tries again.  (The scout costs about half a one-launch filter and the second launch its share of the
-    rest, which puts the break-even near 0.45 -- on paper: measured, a top level 1 with 0.06 of its blocks in the spans gains
-    24 %, mid levels with 0.25 gain 11 % on low-noise clips and LOSE 50 % on noisier ones, a smooth field with 0.27 loses
-    17 %; hence 0.15.  profiles/r05_n_scout_range_plan.txt.)  Results never depend on the plan."""
+    the level, then tries again.  Measured per call (profiles/r05_n_scout_range_plan.txt, r05_q_position_order.txt): the plan
+    wins up to 0.08 of the level inside the spans (top level 1 on low-noise clips 0.06: -24 %; position-ordered top global level
+    0.014: -43 % on top of the ordering; a smooth field's level 2 0.077: -8 %) and loses from 0.11 on (0.25: -11 % ... +50 %;
+    ~1.0 on noisy clips and uncorrelated tokens: +40 %).
 
-    HIGH, COOL = 0.15, 256
+    Levels behind the first are handed to the matcher in position order (vtm_position_order) -- which the plan needs, and which
+    by itself costs a 40 us sort and saves 12-26 % of a top global call (more blocks die) but nothing at level 2.  So
+    `order_alone` says what the level does while the plan is off: keep the ordering (global level) or go back to the reference's
+    row order (level 2); and a level in which NOTHING died at the scout's test (uncorrelated tokens) drops the ordering too.
+    Results never depend on any of this."""
 
-    def __init__(self):
+    HIGH, COOL = 0.09, 256
+
+    def __init__(self, order_alone: bool = False):
         self.mode = _lib.MATCH_SCOUT_RANGE
         self.buf = torch.zeros(8, dtype=torch.int32).pin_memory()
         self.view = self.buf.numpy()
         self.cool = 0
         self.switches = 0
+        self.order_alone = order_alone
+        self.order_off = False
+        self.order_probe = False
 
     def next(self):
-        """-> (mode, pinned stats buffer or None) for the call about to be issued."""
+        """-> (mode, pinned stats buffer or None, position-order the level?) for the call about to be issued."""
         if self.mode == _lib.MATCH_SCOUT_RANGE:
-            tested, in_spans = int(self.view[4]), int(self.view[7])       # the last call whose counters have arrived
+            tested, in_spans = int(self.view[4]), int(self.view[7])        # the last call whose counters have arrived
             if tested > 0 and in_spans > self.HIGH * tested:
                 self.mode, self.cool = _lib.MATCH_ONE_LAUNCH, self.COOL
                 self.switches += 1
                 self.view[4] = 0                                           # judged: do not judge it again after the cool-down
+                # does the ordering pay without the plan?  Not when nothing dies in the ONE-LAUNCH filter either (its running
+                # maxima grow along the dst axis, the scout only has the seeds: a drifting smooth field leaves every block
+                # alive in the scout and 22 % in the filter) -- asked of the first one-launch call's own counters
+                self.order_off, self.order_probe = False, self.order_alone
         else:
+            if self.order_probe and int(self.view[4]) > 0:
+                self.order_off = int(self.view[5]) > 0.9 * int(self.view[4])
+                self.order_probe = False
             self.cool -= 1
             if self.cool <= 0:
                 self.mode = _lib.MATCH_SCOUT_RANGE
-        return (self.mode, self.buf) if self.mode == _lib.MATCH_SCOUT_RANGE else (self.mode, None)
+                self.view[4] = 0
+        if self.mode == _lib.MATCH_SCOUT_RANGE:
+            return self.mode, self.buf, True
+        return self.mode, (self.buf if self.order_probe else None), self.order_alone and not self.order_off
+
+
+# Levels 2 / global meet their rows in position order (vtm_position_order + vtm_match_filtered_ordered: same bits, fewer live
+# blocks; "0" = the reference's sequence order as in rounds 1-4) ...
+POSITION_ORDER = os.environ.get("VIDTOME_POSITION_ORDER", "1") != "0"
+# ... when the level is large enough for the sort (3 launches, ~40 us) to pay: src rows x dst rows per sample
+POSITION_ORDER_MIN_PAIRS = int(os.environ.get("VIDTOME_POSITION_ORDER_MIN_PAIRS", str(1 << 26)))
+
+
+def order_level(Ns: int, Nd: int, tokens: int, align_batch: bool) -> bool:
+    """Does a level of this geometry (not the first local one) meet its rows in position order?"""
+    return (POSITION_ORDER and not align_batch and Ns * Nd >= POSITION_ORDER_MIN_PAIRS and
+            0 < tokens <= _lib.POSITION_ORDER_MAX_N)
 
 
 def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float, align_batch: bool,
-               want_indices: bool, seed=None, planner: Optional[MatchPlanner] = None) -> Level:
-    """normalise+split -> fused score/top-1 -> argsort -> index split  (merge.py:84-117 / 389-421)."""
+               want_indices: bool, seed=None, planner: Optional[MatchPlanner] = None, reorder: bool = False) -> Level:
+    """normalise+split -> fused score/top-1 -> argsort -> index split  (merge.py:84-117 / 389-421).  ``reorder``: the level's
+    rows are NOT in (frame, position) order (every level but the first local one) -- the matcher is then handed both lists
+    sorted by token position and reports in the original indexing; everything behind it sees the reference's order."""
     a_pos, b_pos, a_rows, b_rows = parts
     Ns, Nd = a_rows.shape[1], b_rows.shape[1]
     r = min(Ns, int(Ns * ratio))                       # merge.py:90 (Python float -> int truncation)
@@ -112,13 +146,24 @@ def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float
         b_op, _ = _lib.normalize_gather(x0, x1, b_rows)
         best = _lib.match(a_op, b_op, Ns, Nd, align_batch)
     else:                                              # fp16 filter + fp32 refine: same bits, ~4x faster
-        mode, stats = _lib.MATCH_ONE_LAUNCH, None
-        if planner is not None and seed is not None and _lib.SEED_MATCHER and MATCH_PLAN != "one":
+        mode, stats, order = _lib.MATCH_ONE_LAUNCH, None, None
+        m_a, m_b = a_rows, b_rows
+        seeded = seed is not None and _lib.SEED_MATCHER
+        can_order = reorder and seeded and order_level(Ns, Nd, seed[0], align_batch)
+        use_order = can_order
+        if seeded and (can_order or not reorder) and MATCH_PLAN != "one":     # (rows in similarity-rank order: no plan)
             if MATCH_PLAN == "range":
                 mode = _lib.MATCH_SCOUT_RANGE
-            else:
-                mode, stats = planner.next()
-        best = _lib.match_filtered(x0, x1, a_rows, b_rows, align_batch, seed=seed, mode=mode, stats_host=stats)
+            elif planner is not None:
+                mode, stats, keep = planner.next()
+                use_order = can_order and keep
+        if use_order:
+            tokens, L, pos1, _ = seed
+            m_a, a_order, m_b, b_order, table = _lib.position_order(a_rows, b_rows, L, tokens, pos1, x0.shape[1])
+            order, seed = (a_order, b_order), (tokens, L, pos1, table)     # the sort's offsets ARE the position -> dst table
+        elif can_order and seed[2] is not None and seed[3] is None:
+            seed = None        # a global level left in the reference's order without a position -> dst table: unseeded
+        best = _lib.match_filtered(x0, x1, m_a, m_b, align_batch, seed=seed, mode=mode, stats_host=stats, order=order)
     perm = _lib.sort_desc(best)
     new_cur, inv, unm_idx, src_idx, dst_idx = _lib.plan_apply(best, perm, a_pos, b_pos, a_rows, b_rows, r,
                                                               align_batch, want_indices)
@@ -137,15 +182,16 @@ def local_level(x0: torch.Tensor, cur: Optional[torch.Tensor], N_in: int, F: int
     ts = min(target_stride, F)                         # merge.py:56
     parts = _lib.partition_local(cur, B, N_in, unm_pre, tnum, ts, randf, x0.device)
     seed = (tokens, x0.shape[1], None, None) if (tokens and tokens == tnum) else None
-    # the scout + range plan is for rows in (frame, position) order on both sides: the first level (cur None).  (Measured
-    # with a planner on every level: levels 2 and the global level -- rows in similarity-rank order -- switch themselves off on
-    # every regime and only pay the exploration calls.)
-    return _run_level(x0, None, parts, ratio, align_batch, want_indices, seed, planner if cur is None else None)
+    # the scout + range plan is for position-ordered rows on both sides: the first level (cur None) as it comes, the later
+    # ones through vtm_position_order.  (Measured with a planner on every level while levels 2 / global still met their rows in
+    # similarity-rank order: they switched themselves off on every regime and only paid the exploring calls.)
+    return _run_level(x0, None, parts, ratio, align_batch, want_indices, seed, planner, reorder=cur is not None)
 
 
 def global_level(x0: torch.Tensor, anchors: torch.Tensor, cur_local: Optional[torch.Tensor], Ml: int,
                  local_is_src: bool, ratio: float, align_batch: bool, want_indices: bool = False,
-                 tokens: Optional[int] = None, anchor_positions: Optional[torch.Tensor] = None) -> Level:
+                 tokens: Optional[int] = None, anchor_positions: Optional[torch.Tensor] = None,
+                 planner: Optional[MatchPlanner] = None) -> Level:
     """Global merging of the chunk's local tokens against the block's anchor tokens (patch.py:59-82).  ``tokens`` (tokens
     per frame) / ``anchor_positions`` (B, Mg) int32 seed the matcher with the dst token at every src token's position."""
     B, L, _ = x0.shape
@@ -157,10 +203,12 @@ def global_level(x0: torch.Tensor, anchors: torch.Tensor, cur_local: Optional[to
     # local-is-dst: they are the src rows).  Anchors that arrived without positions (an exchange's single-message form, a
     # user-supplied tensor): no table, no seed launch
     if tokens and _lib.SEED_MATCHER and anchor_positions is not None:
-        table = torch.empty((B, tokens), dtype=torch.int32, device=x0.device)
+        src_len = Ml if local_is_src else anchors.shape[1]
+        if not order_level(src_len, Ml + anchors.shape[1] - src_len, tokens, align_batch):   # (position-ordered calls get their table from the sort)
+            table = torch.empty((B, tokens), dtype=torch.int32, device=x0.device)
         seed = (tokens, L, anchor_positions, table)
     parts = _lib.partition_global(cur_local, L, anchors.shape[1], local_is_src, table, tokens or 0, anchor_positions)
-    return _run_level(x0, anchors, parts, ratio, align_batch, want_indices, seed)
+    return _run_level(x0, anchors, parts, ratio, align_batch, want_indices, seed, planner, reorder=True)
 
 
 def draw_randf(generator: torch.Generator, ts: int) -> int:

@@ -151,15 +151,15 @@ def content_ids(tokens: torch.Tensor, device, dtype) -> Optional[torch.Tensor]:
     return ids
 
 
-def _planner(module: torch.nn.Module, key) -> "merge.MatchPlanner":
-    """The launch planner of the block's first local level (merge.MatchPlanner), kept on the module next to its generator
-    and its anchors, one per chunk geometry; `remove_patch` drops them."""
+def _planner(module: torch.nn.Module, key, order_alone: bool = False) -> "merge.MatchPlanner":
+    """The launch planner of one matching level of the block (merge.MatchPlanner), kept on the module next to its generator
+    and its anchors, one per level geometry; `remove_patch` drops them."""
     plans = module.__dict__.get("_vtm_match_plans")
     if plans is None:
         plans = module.__dict__["_vtm_match_plans"] = {}
     p = plans.get(key)
     if p is None:
-        p = plans[key] = merge.MatchPlanner()
+        p = plans[key] = merge.MatchPlanner(order_alone)
     return p
 
 
@@ -216,7 +216,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 randf = merge.draw_randf(generator, min(args["target_stride"], curF))
                 lv = merge.local_level(xj, cur, n_cur, curF, ratio, unm, randf, args["target_stride"],
                                        args["align_batch"], want_indices, tokens=tsize,
-                                       planner=_planner(module, (xj.shape[1], curF)) if cur is None else None)
+                                       planner=_planner(module, (xj.shape[1], curF, n_cur)))
                 plan.levels.append(lv)
                 unm += lv.unm_num
                 cur = lv.new_cur
@@ -248,7 +248,8 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                     # merge.py:364-365 returns a 2-tuple which patch.py:73 unpacks into 3 names
                     raise ValueError("not enough values to unpack (expected 3, got 2)")
                 gl = merge.global_level(xj, gt, cur, Ml, local_is_src, res_ratio, args["align_batch"],
-                                        want_indices, tokens=tsize, anchor_positions=gt_pos)
+                                        want_indices, tokens=tsize, anchor_positions=gt_pos,
+                                        planner=_planner(module, ("global", xj.shape[1]), order_alone=True))
                 plan.global_level, plan.local_chunk = gl, (0 if local_is_src else 1)
                 plan.anchors_in = gt
                 off = 0 if local_is_src else gt.shape[1]                           # merge.py:459
