@@ -333,6 +333,7 @@ class KernelTimer:
 
         self.count = False             # set for ONE untimed pass after the timed region
         self.plan_modes = []           # the launch plan merge.MatchPlanner chose for each call of that pass
+        self.plan_scouts, self.plan_ordered = [], []    # ... the scout's depth (1 = one channel step), position-ordered rows?
 
         def match_with_counters(x0, x1, ar, br, align, want_flag=False, seed=None, **kw):
             if not self.count or want_flag:
@@ -341,6 +342,8 @@ class KernelTimer:
             # a device tensor; which plan the timed passes took is reported separately (matching.plan)
             kw.pop("stats_host", None)
             self.plan_modes.append(kw.pop("mode", 0))
+            self.plan_scouts.append(kw.pop("scout_steps", 0))
+            self.plan_ordered.append(kw.get("order") is not None)
             best, flag = timed_match(x0, x1, ar, br, align, True, seed=seed, **kw)     # (kw: the position order's inverse maps)
             self.match_flags.append((flag, ar.shape[1] if align else x0.shape[0] * ar.shape[1], x0.shape[2]))
             return best
@@ -396,6 +399,8 @@ class KernelTimer:
         f = torch.stack([fl for fl, _, _ in self.match_flags]).cpu().long()
         rows = sum(r for _, r, _ in self.match_flags)
         out = {"scout_range_calls": int(sum(1 for m_ in self.plan_modes if m_ == 1)),
+               "shallow_scout_calls": int(sum(1 for m_, k_ in zip(self.plan_modes, self.plan_scouts) if m_ == 1 and k_ > 0)),
+               "position_ordered_calls": int(sum(self.plan_ordered)),
                "refined_pairs_per_src_row": round(float(f[:, 3].sum()) / rows, 3),
                "escaped_rows": int(f[:, 2].sum()), "escaped_row_fraction": round(float(f[:, 2].sum()) / rows, 5),
                "whole_call_escapes": int(f[:, 0].sum()), "calls": len(self.match_flags)}

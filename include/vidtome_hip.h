@@ -145,6 +145,11 @@ int vtm_match_filtered_seeded(const void *x0, int64_t P0, const void *x1, int64_
  * shorter than 256 channels or seed_N is not a multiple of 128 >= 256. */
 #define VTM_MATCH_ONE_LAUNCH 0
 #define VTM_MATCH_SCOUT_RANGE 1
+/* mode = VTM_MATCH_SCOUT_RANGE | VTM_MATCH_SCOUT_STEPS(k): the scout tests after k 64-channel steps instead of the filter's own
+ * test depth (40 % of the channels: 2 steps at C = 320, 4 at C = 640) -- with rest norms of its own, so the certificate is as
+ * rigorous; k = 0 or k >= that depth: the filter's depth.  The scout's cost is its steps (1 step: -34 % at C = 320); a low-noise
+ * clip's dead tiles are dead after one step already, on noisier data more tiles stay marked and the spans grow. */
+#define VTM_MATCH_SCOUT_STEPS(k) (((k) & 0xff) << 8)
 int vtm_match_filtered_plan(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
                             int64_t C, const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd,
                             int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out,

@@ -355,6 +355,12 @@ def test_match_scout_range_plan_equals_exact(L, align):
         assert torch.equal(L.match_filtered(x, None, ra, rb, align, seed=(N, F * N, None, table), mode=L.MATCH_SCOUT_RANGE), exact)
         assert torch.equal(L.match_filtered(x, None, ra, rb, align, mode=L.MATCH_SCOUT_RANGE), exact)
         assert torch.equal(L.match_filtered(x, None, ra, rb, align, seed=seed), exact)
+        # a shallower scout (VTM_MATCH_SCOUT_STEPS: its own rest norms) marks more tiles, never fewer than needed
+        for k in (1, 3, 200):
+            got1, f1 = L.match_filtered(x, None, ra, rb, align, want_flag=True, seed=seed, mode=L.MATCH_SCOUT_RANGE, scout_steps=k)
+            assert torch.equal(got1, exact), (regime, k)
+            if k == 1 and N % 128 == 0:
+                assert f1[7] >= f[7], (regime, f, f1.tolist())
         if regime == "corr05":
             x[B - 1, Ns + 7] = 0
             a_op, _ = L.normalize_gather(x, None, ra)
@@ -441,6 +447,8 @@ def test_match_position_ordered_equals_exact(L):
                     assert f[7] < 0.3 * f[4], (regime, f)
             if regime == "flat25":
                 assert f[2] > 0, (regime, f)                       # the escape ran (and broke its ties by original index)
+        assert torch.equal(L.match_filtered(x, None, a_s, b_s, False, seed=seed, mode=L.MATCH_SCOUT_RANGE, order=(a_o, b_o),
+                                            scout_steps=1), exact)
         # no seeds / garbage seeds
         assert torch.equal(L.match_filtered(x, None, a_s, b_s, False, order=(a_o, b_o)), exact)
         junk = torch.randint(-3, Nd + 50, (B, N), generator=g, dtype=torch.int32).to(DEV)
@@ -486,12 +494,21 @@ def test_match_planner_steers_by_the_previous_calls_counters(L):
         x = sites.regime_tokens(regime, B, F, N, C, g)
         x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, F * N, C).half().to(DEV)
         pl = merge.MatchPlanner()
-        mode, buf, keep = pl.next()
-        assert mode == L.MATCH_SCOUT_RANGE and buf.is_pinned() and keep
+        pl.LOW = pl.HIGH                              # (the product keeps a margin between the two)
+        mode, buf, keep, scout = pl.next()
+        assert mode == L.MATCH_SCOUT_RANGE and buf.is_pinned() and keep and scout == 0
         L.match_filtered(x, None, ra, rb, False, seed=seed, mode=mode, stats_host=buf)
         torch.cuda.synchronize()
         assert int(buf[4]) > 0, buf.tolist()
-        assert pl.next()[0] == expect, (regime, buf.tolist())
+        mode, buf, keep, scout = pl.next()
+        assert mode == expect, (regime, pl.view.tolist())
+        if expect == L.MATCH_SCOUT_RANGE:
+            # short spans (below LOW; this planner: LOW = HIGH): the next scout tests after ONE channel step, and stays there
+            # while its own spans are short
+            assert scout == 1
+            L.match_filtered(x, None, ra, rb, False, seed=seed, mode=mode, stats_host=buf, scout_steps=scout)
+            torch.cuda.synchronize()
+            assert pl.next()[3] == 1, pl.view.tolist()
         if expect == L.MATCH_ONE_LAUNCH:
             for _ in range(merge.MatchPlanner.COOL - 1):
                 assert pl.next()[0] == L.MATCH_ONE_LAUNCH
@@ -508,18 +525,18 @@ def test_match_planner_steers_by_the_previous_calls_counters(L):
         x = sites.regime_tokens(regime, B, F, N, C, g)
         x = torch.nn.functional.layer_norm(x, (C,)).reshape(B, F * N, C).half().to(DEV)
         pl = merge.MatchPlanner(order_alone)
-        mode, buf, keep = pl.next()
+        mode, buf, keep, scout = pl.next()
         assert mode == L.MATCH_SCOUT_RANGE and keep
         a_s, a_o, b_s, b_o, tb = L.position_order(perm_a, perm_b, F * N, N, None, F * N)
         L.match_filtered(x, None, a_s, b_s, False, seed=(N, F * N, None, tb), mode=mode, stats_host=buf, order=(a_o, b_o))
         torch.cuda.synchronize()
-        mode, buf, keep = pl.next()
+        mode, buf, keep, scout = pl.next()
         assert (mode, keep) == expect, (regime, order_alone, pl.view.tolist())
         if settled is not None:
             assert buf is not None                    # the one-launch call is asked for its counters once ...
             L.match_filtered(x, None, a_s, b_s, False, seed=(N, F * N, None, tb), mode=mode, stats_host=buf, order=(a_o, b_o))
             torch.cuda.synchronize()
-            mode, buf, keep = pl.next()
+            mode, buf, keep, scout = pl.next()
             assert mode == L.MATCH_ONE_LAUNCH and buf is None and keep == settled, (regime, pl.view.tolist())
 
 

@@ -57,6 +57,8 @@ def main():
                     "(one launch / scout + range; same bits)")
     ap.add_argument("--shuffle", action="store_true", help="match: src rows and the dst rows behind the first dst frame in "
                     "random order (what levels 2 / global see: similarity-rank order) instead of (frame, position) order")
+    ap.add_argument("--scout-steps", type=int, default=0, help="match --plan range: the scout's test depth in 64-channel steps "
+                    "(0 = the filter's own)")
     ap.add_argument("--ordered", action="store_true", help="match: sort both row lists by token position first "
                     "(vtm_position_order + vtm_match_filtered_ordered, what levels 2 / global do); the sort is inside the timing")
     ap.add_argument("--C", type=int, default=320)
@@ -102,10 +104,11 @@ def main():
             mode = _lib.MATCH_SCOUT_RANGE if a.plan == "range" else _lib.MATCH_ONE_LAUNCH
             def run(want_flag=False):
                 if not a.ordered:
-                    return _lib.match_filtered(x, None, ra, rb, a.align, want_flag=want_flag, seed=seed, mode=mode)
+                    return _lib.match_filtered(x, None, ra, rb, a.align, want_flag=want_flag, seed=seed, mode=mode,
+                                               scout_steps=a.scout_steps)
                 a_s, a_o, b_s, b_o, tb = _lib.position_order(ra, rb, Ns + Nd, N, None, Ns + Nd)
                 return _lib.match_filtered(x, None, a_s, b_s, a.align, want_flag=want_flag, seed=(N, Ns + Nd, None, tb), mode=mode,
-                                           order=(a_o, b_o))
+                                           order=(a_o, b_o), scout_steps=a.scout_steps)
             medf, bestf = timeit(run, a.iters)
             if a.ordered:
                 meds, _ = timeit(lambda: _lib.position_order(ra, rb, Ns + Nd, N, None, Ns + Nd), a.iters)

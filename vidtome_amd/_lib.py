@@ -239,7 +239,7 @@ MATCH_ONE_LAUNCH, MATCH_SCOUT_RANGE = 0, 1         # include/vidtome_hip.h: VTM_
 @_on_device
 def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.Tensor, b_rows: torch.Tensor,
                    align: bool, want_flag: bool = False, seed=None, mode: int = MATCH_ONE_LAUNCH,
-                   stats_host: Optional[torch.Tensor] = None, order=None):
+                   stats_host: Optional[torch.Tensor] = None, order=None, scout_steps: int = 0):
     """Same packed result as normalize_gather x2 + match, through the fp16-filter / fp32-refine path.  ``seed`` (optional,
     never changes the result): (tokens per frame N, L = pool rows that are chunk tokens, pos1 (B, P1) int32 positions of the
     x1 rows or None, table (B, N) int32 position -> dst index or None for identity) -- every src row then starts from the
@@ -249,7 +249,8 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
     call's counters asynchronously (flags_out of the C ABI) -- what merge.MatchPlanner steers by; ``want_flag`` returns them
     as a device tensor instead.  ``order`` = (a_order, b_order) from `position_order`: a_rows / b_rows are then its SORTED lists
     and the result is reported (and ties are broken) in the original indexing -- the same bits as the call on the unsorted
-    lists (vtm_match_filtered_ordered; never aligned)."""
+    lists (vtm_match_filtered_ordered; never aligned).  ``scout_steps`` (scout + range plan): the scout tests after that many
+    64-channel steps instead of the filter's own test depth (VTM_MATCH_SCOUT_STEPS; 0 = the filter's depth)."""
     _req(x0, "x0"), _req(a_rows, "a_rows"), _req(b_rows, "b_rows")
     B, P0, C = x0.shape
     P1 = 0 if x1 is None else _req(x1, "x1").shape[1]
@@ -265,6 +266,7 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
         if not (stats_host.is_pinned() and stats_host.dtype == torch.int32 and stats_host.numel() >= 8):
             raise RuntimeError("match_filtered: stats_host must be a pinned int32 tensor of 8 elements")
         flags_out = stats_host.data_ptr()
+    mode = int(mode) | ((int(scout_steps) & 0xff) << 8)
     sN = sL = 0
     pos1 = table = None
     if seed is not None and SEED_MATCHER:

@@ -172,6 +172,8 @@ struct SplitArgs {   // one operand: gathered rows, their norms (out), the panel
     // partial-sum pruning (filter_kernel): the norm of the hi operand's channels >= `cut`, per row (src operand) or as
     // the maximum over every 128-row tile (dst operand); nullptr = not wanted
     float *rest, *tile_rest;
+    // the same for a second, EARLIER cut (the shallow scout of the scout + range plan); nullptr = not wanted
+    float *rest2, *tile_rest2;
 };
 
 #ifndef VTM_PREP_PIECES
@@ -189,10 +191,11 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
                                                     const T *__restrict__ x1, int64_t P1, int64_t B, int64_t C,
                                                     SplitArgs A0, SplitArgs A1, int64_t C_pad,
                                                     uint32_t *__restrict__ zero, int64_t zero_words,
-                                                    unsigned long long *__restrict__ best, int64_t nbest, int64_t cut) {
+                                                    unsigned long long *__restrict__ best, int64_t nbest, int64_t cut,
+                                                    int64_t cut2) {
     static_assert(sizeof(T) == 2 || sizeof(T) == 4, "element size");
     static_assert(PREP_WAVES % 2 == 0, "a 128-row tile is two waves of one workgroup");
-    __shared__ float wave_rest[PREP_WAVES];
+    __shared__ float wave_rest[PREP_WAVES], wave_rest2[PREP_WAVES];
     constexpr int EPP = 16 / (int)sizeof(T);           // elements per 16-byte piece (8 for the 16-bit types, 4 for fp32)
     __shared__ __attribute__((aligned(16))) char slab[PREP_WAVES][64 * PREP_STRIDE];
     const int64_t G = C_pad / 8;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
     uint4 *__restrict__ out_hi = in_range ? A.out_hi + (b * G) * n_pad + i : nullptr;
     uint4 *__restrict__ out_lo = (in_range && A.out_lo) ? A.out_lo + (b * G) * n_pad + i : nullptr;
     constexpr int PPG = 8 / EPP;                                        // pieces per 8-channel panel group (1 or 2)
-    float rest = 0.0f;                                                  // sum of hi^2 over the channels >= cut
+    float rest = 0.0f, rest2 = 0.0f;                                    // sum of hi^2 over the channels >= cut / >= cut2
     issue(0);
     for (int c = 0; c < nchunks; ++c) {
         to_lds();
@@ -296,9 +299,12 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
             }
             if (!real) vh = vl = make_uint4(0, 0, 0, 0);               // padding rows: all-zero operands
             const int64_t g = ((int64_t)c * PREP_PIECES + col) / PPG;
-            if (g * 8 >= cut) {
+            if (g * 8 >= cut2) {                                         // (cut2 <= cut)
+                float sq = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rest = __builtin_fmaf((float)ph[e], (float)ph[e], rest);
+                for (int e = 0; e < 8; ++e) sq = __builtin_fmaf((float)ph[e], (float)ph[e], sq);
+                rest2 += sq;
+                if (g * 8 >= cut) rest += sq;
             }
             if (in_range) {
                 out_hi[g * n_pad] = vh;
@@ -324,9 +330,17 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void prep_operand(const T *__restr
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
     if (lane == 0) wave_rest[wave] = wm;
+    const float rnorm2 = !real ? 0.0f : bad_row ? INFINITY : __builtin_sqrtf(rest2) * (1.0f + 0x1p-16f);
+    if (in_range && A.rest2) A.rest2[b * n_pad + i] = rnorm2;
+    float wm2 = rnorm2;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wm2 = fmaxf(wm2, __shfl_xor(wm2, off, 64));
+    if (lane == 0) wave_rest2[wave] = wm2;
     __syncthreads();
     if (in_range && A.tile_rest && (threadIdx.x & 127) == 0)            // n_pad is a multiple of 256: tiles do not straddle
         A.tile_rest[(b * n_pad + i) / 128] = fmaxf(wave_rest[wave], wave_rest[wave + 1]);
+    if (in_range && A.tile_rest2 && (threadIdx.x & 127) == 0)
+        A.tile_rest2[(b * n_pad + i) / 128] = fmaxf(wave_rest2[wave], wave_rest2[wave + 1]);
 }
 
 // ---- filter: approximate scores on the fp16 MFMA, candidate collection ----
@@ -1428,7 +1442,7 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t na, nb, ah, al, bh, bl, amax, cnt, seedlb, tilemap, cand, flags, ovf_cnt, ovf, pairs, rest_a, rest_bt, total;
+    size_t na, nb, ah, al, bh, bl, amax, cnt, seedlb, tilemap, cand, flags, ovf_cnt, ovf, pairs, rest_a, rest_bt, rest_a2, rest_bt2, total;
     int64_t Ns_pad, Nd_pad, C64;
 };
 
@@ -1458,6 +1472,8 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     L.pairs = take((size_t)rows_out * CAP * 8);
     L.rest_a = take((size_t)B * L.Ns_pad * 4);
     L.rest_bt = take((size_t)B * (L.Nd_pad / FBD) * 4);
+    L.rest_a2 = take((size_t)B * L.Ns_pad * 4);              // ... for the shallow scout's cut
+    L.rest_bt2 = take((size_t)B * (L.Nd_pad / FBD) * 4);
     L.total = o;
     return L;
 }
@@ -1475,6 +1491,8 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
                                int64_t seed_L, int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table,
                                int mode, const int32_t *src_order, const int32_t *dst_order, vtm_stream_t stream) {
     VTM_REQUIRE(x0 && a_rows && b_rows && ws && best, "vtm_match_filtered: null pointer");
+    const int scout_steps = (mode >> 8) & 0xff;      // VTM_MATCH_SCOUT_STEPS(k): the scout tests after k pipeline steps
+    mode &= 0xff;
     VTM_REQUIRE((src_order == nullptr) == (dst_order == nullptr), "vtm_match_filtered_ordered: both inverse maps or none");
     VTM_REQUIRE(!(src_order && align), "vtm_match_filtered_ordered: not for aligned calls (one order per sample)");
     VTM_REQUIRE(mode == VTM_MATCH_ONE_LAUNCH || mode == VTM_MATCH_SCOUT_RANGE, "vtm_match_filtered: bad mode %d", mode);
@@ -1515,11 +1533,16 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
     // (the per-tile values are written for every call: refine_kernel reads the "row without a usable norm" mark from them)
     float *rest_a = (float *)(w + L.rest_a), *rest_bt = (float *)(w + L.rest_bt);
     const int64_t cut = prune ? (int64_t)KP * FBK : L.C64;
+    // the scout of the scout + range plan may test EARLIER than the filter proper (its own rest norms): a low-noise clip's
+    // dead tiles are dead after one step already, and the scout's cost is its steps
+    const int KPS = (prune && mode == VTM_MATCH_SCOUT_RANGE && scout_steps > 0 && scout_steps < KP) ? scout_steps : KP;
+    float *rest_a2 = (float *)(w + L.rest_a2), *rest_bt2 = (float *)(w + L.rest_bt2);
+    const int64_t cut2 = KPS < KP ? (int64_t)KPS * FBK : cut;
     {
         // one launch: canonical norms + fp16 panels of both operands; it also clears amax / cnt / flags (contiguous)
         // and zero-fills `best`
-        const SplitArgs A0{a_rows, Ns, na, ah, SRC_LO ? al : nullptr, L.Ns_pad, rest_a, nullptr};
-        const SplitArgs A1{b_rows, Nd, nb, bh, DST_LO ? bl : nullptr, L.Nd_pad, nullptr, rest_bt};
+        const SplitArgs A0{a_rows, Ns, na, ah, SRC_LO ? al : nullptr, L.Ns_pad, rest_a, nullptr, KPS < KP ? rest_a2 : nullptr, nullptr};
+        const SplitArgs A1{b_rows, Nd, nb, bh, DST_LO ? bl : nullptr, L.Nd_pad, nullptr, rest_bt, nullptr, KPS < KP ? rest_bt2 : nullptr};
         const int64_t total = B * (L.Ns_pad + L.Nd_pad);
         unsigned long long *bp0 = reinterpret_cast<unsigned long long *>(best);
         uint32_t *zp = reinterpret_cast<uint32_t *>(w + L.amax);
@@ -1528,15 +1551,15 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(prep_operand<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
-                                   B, C, A0, A1, L.C64, zp, zw, bp0, rows_out, cut);
+                                   B, C, A0, A1, L.C64, zp, zw, bp0, rows_out, cut, cut2);
                 break;
             case VTM_F16:
                 hipLaunchKernelGGL(prep_operand<__half>, grid, block, 0, s, (const __half *)x0, P0, (const __half *)x1,
-                                   P1, B, C, A0, A1, L.C64, zp, zw, bp0, rows_out, cut);
+                                   P1, B, C, A0, A1, L.C64, zp, zw, bp0, rows_out, cut, cut2);
                 break;
             default:
                 hipLaunchKernelGGL(prep_operand<vtm_bf16>, grid, block, 0, s, (const vtm_bf16 *)x0, P0,
-                                   (const vtm_bf16 *)x1, P1, B, C, A0, A1, L.C64, zp, zw, bp0, rows_out, cut);
+                                   (const vtm_bf16 *)x1, P1, B, C, A0, A1, L.C64, zp, zw, bp0, rows_out, cut, cut2);
         }
     }
 
@@ -1643,8 +1666,8 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
         if (range_plan) {
             hipLaunchKernelGGL(filter_kernel<true>, dim3((unsigned)grid), dim3(THREADS), 0, s, ah, al, bh, bl, Ns, Nd, L.Ns_pad,
                                L.Nd_pad, L.C64, align, ns_tiles, nd_tiles, nsplit, tiles_per_split, total_src_tiles, patch_tiles,
-                               amax, cnt, cand, (int)rows_out, flags, (const float *)rest_a, (const float *)rest_bt, KP,
-                               flags_out != nullptr ? 1 : 0, tilemap, map_words);
+                               amax, cnt, cand, (int)rows_out, flags, (const float *)(KPS < KP ? rest_a2 : rest_a),
+                               (const float *)(KPS < KP ? rest_bt2 : rest_bt), KPS, flags_out != nullptr ? 1 : 0, tilemap, map_words);
             const int tps_r = ordered ? tiles_per_split : (int)(seed_N / FBD);
             const int nsplit_r = (int)vtm::cdiv(nd_tiles, tps_r);
             const int64_t grid_r = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit_r;

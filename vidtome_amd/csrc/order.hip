@@ -126,6 +126,7 @@ __global__ __launch_bounds__(ST) void scatter_kernel(Lists ls, int64_t B, int64_
     const int32_t r = ls.rows[op][b * ls.n[op] + i];
     const int64_t p = position_of(r, b, L, N, pos1, P0, P1);
     const int64_t slot = s_off[p] + atomicAdd(&fill[bo * (N + 1) + p], 1);
+    if (slot >= ls.n[op]) return;        // (only a counter block that was NOT zero on entry gets here: stay inside the lists)
     const int64_t at = b * (ls.n[0] + ls.n[1]) + (op ? ls.n[0] : 0) + slot;
     stage_rows[at] = r;
     stage_order[at] = (int32_t)i;
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(OT) void settle_kernel(Lists ls, int64_t B, int64_t
         rank = 0;
         for (int64_t q = g0; q < g1; ++q) rank += stage_order[base + q] < mine;
     }
+    if (g0 + rank >= ls.n[op]) return;
     ls.sorted[op][b * ls.n[op] + g0 + rank] = r;
     ls.order[op][b * ls.n[op] + g0 + rank] = mine;
     if (slot == g0) {                                   // nobody reads the counters any more: leave them zeroed

@@ -60,6 +60,8 @@ class Level:
 # Launch plan of the filtered matcher (same bits either way): "auto" = merge.MatchPlanner decides per
 # block from the previous call's counters, "one" = always the one-launch filter (rounds 1-4), "range" = always scout + range
 MATCH_PLAN = os.environ.get("VIDTOME_MATCH_PLAN", "auto")
+# ... and whether the planner may let the scout test after one channel step ("0": always at the filter's own depth)
+SHALLOW_SCOUT = os.environ.get("VIDTOME_SHALLOW_SCOUT", "1") != "0"
 
 
 class MatchPlanner:
@@ -83,7 +85,7 @@ class MatchPlanner:
     row order (level 2); and a level in which NOTHING died at the scout's test (uncorrelated tokens) drops the ordering too.
     Results never depend on any of this."""
 
-    HIGH, COOL = 0.09, 256
+    HIGH, LOW, COOL = 0.09, 0.07, 256
 
     def __init__(self, order_alone: bool = False):
         self.mode = _lib.MATCH_SCOUT_RANGE
@@ -94,30 +96,46 @@ class MatchPlanner:
         self.order_alone = order_alone
         self.order_off = False
         self.order_probe = False
+        # the scout's depth: the filter's own test depth, or ONE 64-channel step (VTM_MATCH_SCOUT_STEPS(1): -20 ... -28 % per
+        # call where a tile that is dead at 40 % of the channels is dead at 20 % already -- low-noise clips: same spans;
+        # elsewhere more tiles stay marked).  Tried once the deep scout's spans are below LOW, kept while its own are below HIGH
+        self.shallow = False
+        self.shallow_ban = 0
+        self.issued_shallow = False
 
     def next(self):
-        """-> (mode, pinned stats buffer or None, position-order the level?) for the call about to be issued."""
+        """-> (mode, pinned stats buffer or None, position-order the level?, scout steps) for the call about to be issued."""
         if self.mode == _lib.MATCH_SCOUT_RANGE:
             tested, in_spans = int(self.view[4]), int(self.view[7])        # the last call whose counters have arrived
-            if tested > 0 and in_spans > self.HIGH * tested:
-                self.mode, self.cool = _lib.MATCH_ONE_LAUNCH, self.COOL
-                self.switches += 1
-                self.view[4] = 0                                           # judged: do not judge it again after the cool-down
-                # does the ordering pay without the plan?  Not when nothing dies in the ONE-LAUNCH filter either (its running
-                # maxima grow along the dst axis, the scout only has the seeds: a drifting smooth field leaves every block
-                # alive in the scout and 22 % in the filter) -- asked of the first one-launch call's own counters
-                self.order_off, self.order_probe = False, self.order_alone
+            if tested > 0:
+                self.view[4] = 0                                           # judged once
+                wide = in_spans > self.HIGH * tested
+                if self.issued_shallow:                                    # (that call scouted after one step)
+                    if wide:
+                        self.shallow, self.shallow_ban = False, self.COOL
+                elif wide:
+                    self.mode, self.cool = _lib.MATCH_ONE_LAUNCH, self.COOL
+                    self.switches += 1
+                    # does the ordering pay without the plan?  Not when nothing dies in the ONE-LAUNCH filter either (its
+                    # running maxima grow along the dst axis, the scout only has the seeds: a drifting smooth field leaves
+                    # every block alive in the scout and 29 % in the filter) -- asked of the first one-launch call's counters
+                    self.order_off, self.order_probe = False, self.order_alone
+                elif self.shallow_ban <= 0 and in_spans < self.LOW * tested:      # (some margin: a level at the edge of the
+                    self.shallow = True                                           # plan is not the place for a cheaper scout)
+            if self.shallow_ban > 0:
+                self.shallow_ban -= 1
         else:
             if self.order_probe and int(self.view[4]) > 0:
                 self.order_off = int(self.view[5]) > 0.9 * int(self.view[4])
                 self.order_probe = False
             self.cool -= 1
             if self.cool <= 0:
-                self.mode = _lib.MATCH_SCOUT_RANGE
+                self.mode, self.shallow = _lib.MATCH_SCOUT_RANGE, False
                 self.view[4] = 0
         if self.mode == _lib.MATCH_SCOUT_RANGE:
-            return self.mode, self.buf, True
-        return self.mode, (self.buf if self.order_probe else None), self.order_alone and not self.order_off
+            self.issued_shallow = self.shallow
+            return self.mode, self.buf, True, (1 if self.shallow else 0)
+        return self.mode, (self.buf if self.order_probe else None), self.order_alone and not self.order_off, 0
 
 
 # Levels 2 / global meet their rows in position order (vtm_position_order + vtm_match_filtered_ordered: same bits, fewer live
@@ -146,7 +164,7 @@ def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float
         b_op, _ = _lib.normalize_gather(x0, x1, b_rows)
         best = _lib.match(a_op, b_op, Ns, Nd, align_batch)
     else:                                              # fp16 filter + fp32 refine: same bits, ~4x faster
-        mode, stats, order = _lib.MATCH_ONE_LAUNCH, None, None
+        mode, stats, order, scout = _lib.MATCH_ONE_LAUNCH, None, None, 0
         m_a, m_b = a_rows, b_rows
         seeded = seed is not None and _lib.SEED_MATCHER
         can_order = reorder and seeded and order_level(Ns, Nd, seed[0], align_batch)
@@ -155,15 +173,18 @@ def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float
             if MATCH_PLAN == "range":
                 mode = _lib.MATCH_SCOUT_RANGE
             elif planner is not None:
-                mode, stats, keep = planner.next()
+                mode, stats, keep, scout = planner.next()
                 use_order = can_order and keep
+                if not SHALLOW_SCOUT:
+                    scout = 0
         if use_order:
             tokens, L, pos1, _ = seed
             m_a, a_order, m_b, b_order, table = _lib.position_order(a_rows, b_rows, L, tokens, pos1, x0.shape[1])
             order, seed = (a_order, b_order), (tokens, L, pos1, table)     # the sort's offsets ARE the position -> dst table
         elif can_order and seed[2] is not None and seed[3] is None:
             seed = None        # a global level left in the reference's order without a position -> dst table: unseeded
-        best = _lib.match_filtered(x0, x1, m_a, m_b, align_batch, seed=seed, mode=mode, stats_host=stats, order=order)
+        best = _lib.match_filtered(x0, x1, m_a, m_b, align_batch, seed=seed, mode=mode, stats_host=stats, order=order,
+                                   scout_steps=scout)
     perm = _lib.sort_desc(best)
     new_cur, inv, unm_idx, src_idx, dst_idx = _lib.plan_apply(best, perm, a_pos, b_pos, a_rows, b_rows, r,
                                                               align_batch, want_indices)
