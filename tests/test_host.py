@@ -409,3 +409,59 @@ def test_generator_modes_follow_the_reference_rules():
     u = vidtome_amd.apply_patch(StandInUNet(16, 2), generator_device="device")
     assert u._tome_info["args"]["generator_device"] == "device"
     vidtome_amd.remove_patch(u)
+
+
+def test_match_planner_state_machine_without_a_gpu():
+    """merge.MatchPlanner's decisions as a pure function of the counters it is shown (the GPU tests drive it with real calls):
+    plan on while < HIGH of the level lies inside the spans; the one-step scout is tried below LOW and dropped (for COOL
+    calls) when ITS spans are wide -- without giving the plan up; wide spans of the deep scout -> one launch for COOL calls,
+    position-ordered only at levels built with order_alone, and not even there when the first one-launch call reports that
+    nothing dies in the filter either."""
+    import torch
+    from vidtome_amd import _lib, merge
+
+    def planner(order_alone):
+        pl = object.__new__(merge.MatchPlanner)        # (the constructor pins its buffer: needs a GPU)
+        pl.mode, pl.buf = _lib.MATCH_SCOUT_RANGE, torch.zeros(8, dtype=torch.int32)
+        pl.view, pl.cool, pl.switches = pl.buf.numpy(), 0, 0
+        pl.order_alone, pl.order_off, pl.order_probe = order_alone, False, False
+        pl.shallow, pl.shallow_ban, pl.issued_shallow = False, 0, False
+        return pl
+
+    def show(pl, tested, alive, spans):
+        pl.view[4], pl.view[5], pl.view[7] = tested, alive, spans
+
+    R, O = _lib.MATCH_SCOUT_RANGE, _lib.MATCH_ONE_LAUNCH
+    pl = planner(True)
+    assert pl.next()[0::2] == (R, True) and pl.next()[3] == 0          # nothing has arrived yet: deep scout, ordered
+    show(pl, 1000, 10, 80)                                             # 0.08: inside the plan, but above LOW
+    assert pl.next()[3] == 0
+    show(pl, 1000, 10, 20)                                             # 0.02 < LOW: try the one-step scout
+    assert pl.next()[0::3] == (R, 1)
+    show(pl, 1000, 10, 25)
+    assert pl.next()[0::3] == (R, 1)                                   # its spans are short too: keep it
+    show(pl, 1000, 900, 700)                                           # ... now they are wide: back to the deep scout, plan kept
+    assert pl.next()[0::3] == (R, 0) and pl.shallow_ban > 0
+    show(pl, 1000, 10, 20)
+    assert pl.next()[0::3] == (R, 0)                                   # (banned for COOL calls)
+    show(pl, 1000, 300, 500)                                           # the DEEP scout's spans are wide: one launch
+    mode, buf, keep, scout = pl.next()
+    assert (mode, keep, scout) == (O, True, 0) and buf is not None     # ordered (order_alone), asks the filter for its counters
+    show(pl, 1000, 290, 0)                                             # 29 % alive in the one-launch filter: the ordering stays
+    mode, buf, keep, _ = pl.next()
+    assert (mode, keep) == (O, True) and buf is None
+    for _ in range(merge.MatchPlanner.COOL - 3):
+        assert pl.next()[0] == O
+    assert pl.next()[0] == R                                           # ... and tries the plan again
+    # nothing dies in the filter either (uncorrelated tokens): the ordering goes too; level 2 never orders without the plan
+    pl = planner(True)
+    pl.next()
+    show(pl, 1000, 1000, 1000)
+    assert pl.next()[0::2] == (O, True)
+    show(pl, 1000, 1000, 0)
+    assert pl.next()[0::2] == (O, False)
+    pl = planner(False)
+    pl.next()
+    show(pl, 1000, 300, 500)
+    mode, buf, keep, _ = pl.next()
+    assert (mode, keep) == (O, False) and buf is None
