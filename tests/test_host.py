@@ -450,7 +450,7 @@ def test_match_planner_state_machine_without_a_gpu():
     show(pl, 1000, 290, 0)                                             # 29 % alive in the one-launch filter: the ordering stays
     mode, buf, keep, _ = pl.next()
     assert (mode, keep) == (O, True) and buf is None
-    for _ in range(merge.MatchPlanner.COOL - 3):
+    for _ in range(merge.MatchPlanner.COOL - 2):
         assert pl.next()[0] == O
     assert pl.next()[0] == R                                           # ... and tries the plan again
     # nothing dies in the filter either (uncorrelated tokens): the ordering goes too; level 2 never orders without the plan
