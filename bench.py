@@ -679,7 +679,7 @@ def main():
             # ... and like a new clip: the matcher's launch planners (merge.MatchPlanner) start over -- a planner that the
             # PREVIOUS regime sent to the one-launch plan would sit out its cool-down in this one (regimes do not alternate in
             # a real run; the populate / warm-up passes below absorb the planner's first, exploring call)
-            b.__dict__.pop("_vtm_match_plans", None)
+            b.__dict__.pop("_vtm_match_plans", None)      # (the previous region ended on a fence: no counter copy in flight)
         ex = None
         if xmode is not None:
             # every rank owns one chunk per pass; per merging block the global level takes its anchor tokens from the

@@ -1073,6 +1073,10 @@ def _patched_roots(model: torch.nn.Module, controlnet_on_unet: bool):
 def remove_patch(model: torch.nn.Module):
     """vidtome/patch.py:337-355: drop the hooks, give every ToMeBlock its parent class back; returns the UNet."""
     unet, roots = _patched_roots(model, controlnet_on_unet=True)
+    # the launch planners' pinned counter buffers are written by asynchronous copies the LIBRARY issued (torch's host
+    # allocator does not know about them): let the last ones land before the buffers go back to its pool
+    if torch.cuda.is_available() and any("_vtm_match_plans" in m.__dict__ for root in roots for m in root.modules()):
+        torch.cuda.synchronize()
     for root in roots:
         for module in root.modules():
             info = getattr(module, "_tome_info", None)
