@@ -168,8 +168,10 @@ int vtm_match_filtered_plan(const void *x0, int64_t P0, const void *x1, int64_t 
  *   samples.  Outputs: a_sorted / b_sorted = the lists in position order, a_order / b_order = the original index of every
  *   sorted entry, table (B, N; optional) = position -> first sorted dst entry holding it, -1 = none (the seed table of the
  *   call).  counters: vtm_position_order_counter_ints(B, N) int32 that must be ZERO on entry and are zero again when the call
- *   has run (allocate zeroed once, reuse); ws: vtm_position_order_ws_bytes bytes of scratch.
- *   vtm_match_filtered_ordered = vtm_match_filtered_plan on the sorted lists (never aligned), with refine / escape reporting
+ *   has run (allocate zeroed once, reuse); ws: vtm_position_order_ws_bytes bytes of scratch.  shared_order != 0 (aligned
+ *   matching): sample 0's positions decide ONE order and every sample's lists (and table) are written in it.
+ *   vtm_match_filtered_ordered = vtm_match_filtered_plan on the sorted lists (aligned calls: the lists must come from a
+ *   shared_order sort -- entry i is the same original index in every sample -- and sample 0's a_order names the rows), with refine / escape reporting
  *   row and column through a_order / b_order and breaking ties by the ORIGINAL dst index: `best` is bit-identical to
  *   vtm_match_filtered(a_rows, b_rows).  With VTM_MATCH_SCOUT_RANGE the dst axis is one position-major run cut
  *   into the one-launch plan's splits (a src tile's span lies in one or two of them).  N <= VTM_POSITION_ORDER_MAX_N. */
@@ -179,10 +181,10 @@ size_t vtm_position_order_ws_bytes(int64_t B, int64_t Ns, int64_t Nd, int64_t N)
 int vtm_position_order(const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd, int64_t B, int64_t L,
                        int64_t N, const int32_t *pos1, int64_t P0, int64_t P1, int32_t *counters, void *ws,
                        size_t ws_bytes, int32_t *a_sorted, int32_t *a_order, int32_t *b_sorted, int32_t *b_order,
-                       int32_t *table, vtm_stream_t stream);
+                       int32_t *table, int shared_order, vtm_stream_t stream);
 int vtm_match_filtered_ordered(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
                                int64_t C, const int32_t *a_sorted, int64_t Ns, const int32_t *b_sorted, int64_t Nd,
-                               void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out, int64_t seed_L,
+                               int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out, int64_t seed_L,
                                int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table, int mode,
                                const int32_t *a_order, const int32_t *b_order, vtm_stream_t stream);
 

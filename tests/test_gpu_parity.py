@@ -449,6 +449,18 @@ def test_match_position_ordered_equals_exact(L):
                 assert f[2] > 0, (regime, f)                       # the escape ran (and broke its ties by original index)
         assert torch.equal(L.match_filtered(x, None, a_s, b_s, False, seed=seed, mode=L.MATCH_SCOUT_RANGE, order=(a_o, b_o),
                                             scout_steps=1), exact)
+        # aligned matching (one result row per src index over all samples' dst rows): ONE order for every sample, sample 0's --
+        # the samples' lists here are different rows in different orders, the shared order only has to keep entry i the same
+        # original index everywhere
+        if B > 1 and ci in (0, 3, 4, 5, 7, 10):
+            exact_al = L.match(a_op, b_op, Ns, Nd, True)
+            sa, oa, sb, ob, tb_al = L.position_order(ra, rb, F * N, N, None, F * N, shared=True)
+            assert all(torch.equal(oa[0], oa[b_]) and torch.equal(ob[0], ob[b_]) for b_ in range(B))
+            assert torch.equal(torch.gather(ra, 1, oa.long()), sa) and torch.equal(torch.gather(rb, 1, ob.long()), sb)
+            for mode in (L.MATCH_ONE_LAUNCH, L.MATCH_SCOUT_RANGE):
+                got = L.match_filtered(x, None, sa, sb, True, seed=(N, F * N, None, tb_al), mode=mode, order=(oa, ob),
+                                       scout_steps=1 if ci == 0 else 0)
+                assert torch.equal(got, exact_al), (regime, "aligned", mode)
         # no seeds / garbage seeds
         assert torch.equal(L.match_filtered(x, None, a_s, b_s, False, order=(a_o, b_o)), exact)
         junk = torch.randint(-3, Nd + 50, (B, N), generator=g, dtype=torch.int32).to(DEV)

@@ -41,12 +41,12 @@ _SIGNATURES = {
                             _vp, _vp, _vp], _int),
     "vtm_match_filtered_plan": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
                                  _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp], _int),
-    "vtm_match_filtered_ordered": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _vp, ctypes.c_size_t,
+    "vtm_match_filtered_ordered": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
                                     _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp], _int),
     "vtm_position_order_counter_ints": ([_i64, _i64], ctypes.c_size_t),
     "vtm_position_order_ws_bytes": ([_i64, _i64, _i64, _i64], ctypes.c_size_t),
     "vtm_position_order": ([_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp, _vp,
-                            _vp, _vp, _vp], _int),
+                            _vp, _vp, _int, _vp], _int),
     "vtm_match_filtered_seeded": ([_vp, _i64, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, ctypes.c_size_t,
                                    _vp, _vp, _i64, _i64, _vp, _vp, _vp], _int),
     "vtm_anchor_pos": ([_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp], _int),
@@ -249,7 +249,7 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
     call's counters asynchronously (flags_out of the C ABI) -- what merge.MatchPlanner steers by; ``want_flag`` returns them
     as a device tensor instead.  ``order`` = (a_order, b_order) from `position_order`: a_rows / b_rows are then its SORTED lists
     and the result is reported (and ties are broken) in the original indexing -- the same bits as the call on the unsorted
-    lists (vtm_match_filtered_ordered; never aligned).  ``scout_steps`` (scout + range plan): the scout tests after that many
+    lists (vtm_match_filtered_ordered; aligned calls: lists from a ``shared`` position_order).  ``scout_steps`` (scout + range plan): the scout tests after that many
     64-channel steps instead of the filter's own test depth (VTM_MATCH_SCOUT_STEPS; 0 = the filter's depth)."""
     _req(x0, "x0"), _req(a_rows, "a_rows"), _req(b_rows, "b_rows")
     B, P0, C = x0.shape
@@ -277,13 +277,11 @@ def match_filtered(x0: torch.Tensor, x1: Optional[torch.Tensor], a_rows: torch.T
             raise RuntimeError("match_filtered: the seed table must be a contiguous (B, N) int32 tensor")
     if order is not None:
         a_order, b_order = order
-        if align:
-            raise RuntimeError("match_filtered: position-ordered calls are never aligned")
         for o, n, name in ((a_order, Ns, "a_order"), (b_order, Nd, "b_order")):
             if o.dtype != torch.int32 or tuple(o.shape) != (B, n) or not o.is_contiguous() or not o.is_cuda:
                 raise RuntimeError(f"match_filtered: {name} must be a contiguous (B, {n}) int32 device tensor")
         _check(lib().vtm_match_filtered_ordered(_ptr(x0), P0, _ptr(x1), P1, dtype_code(x0), B, C, _ptr(a_rows), Ns,
-                                                _ptr(b_rows), Nd, _ptr(ws), nbytes, _ptr(best), flags_out, int(sL), int(sN),
+                                                _ptr(b_rows), Nd, int(align), _ptr(ws), nbytes, _ptr(best), flags_out, int(sL), int(sN),
                                                 _ptr(pos1), _ptr(table), int(mode), _ptr(a_order), _ptr(b_order), _stream()),
                "vtm_match_filtered_ordered")
         return (best, flag) if want_flag else best
@@ -312,10 +310,10 @@ def _zeroed_counters(n_ints: int, device: torch.device) -> torch.Tensor:
 
 @_on_device
 def position_order(a_rows: torch.Tensor, b_rows: torch.Tensor, L: int, N: int, pos1: Optional[torch.Tensor], P0: int,
-                   want_table: bool = True):
+                   want_table: bool = True, shared: bool = False):
     """Both row lists of a matcher call sorted by token position (vtm_position_order, include/vidtome_hip.h):
     -> (a_sorted, a_order, b_sorted, b_order, table).  Position of pool row r: r % N below L, pos1[b, r - P0] for the rows of
-    x1 (``pos1`` (B, P1) int32 or None)."""
+    x1 (``pos1`` (B, P1) int32 or None).  ``shared`` (aligned matching): ONE order, sample 0's, for every sample's lists."""
     _req(a_rows, "a_rows"), _req(b_rows, "b_rows")
     B, Ns = a_rows.shape
     Nd = b_rows.shape[1]
@@ -334,7 +332,7 @@ def position_order(a_rows: torch.Tensor, b_rows: torch.Tensor, L: int, N: int, p
     table = torch.empty((B, N), **i32) if want_table else None
     _check(lib().vtm_position_order(_ptr(a_rows), Ns, _ptr(b_rows), Nd, B, int(L), int(N), _ptr(pos1), int(P0), P1,
                                     _ptr(counters), _ptr(ws), nbytes, _ptr(a_sorted), _ptr(a_order), _ptr(b_sorted),
-                                    _ptr(b_order), _ptr(table), _stream()), "vtm_position_order")
+                                    _ptr(b_order), _ptr(table), int(shared), _stream()), "vtm_position_order")
     return a_sorted, a_order, b_sorted, b_order, table
 
 

@@ -1131,8 +1131,10 @@ __global__ __launch_bounds__(256) void refine_kernel(const T *__restrict__ x0, i
         }
         // position-ordered call (vtm_match_filtered_ordered; never aligned): row and column in the caller's ORIGINAL indexing,
         // so that the packed maximum's tie rule -- lowest dst index -- is the original one
-        const int64_t orow = src_order ? bi * Ns + src_order[prow] : prow;
-        const uint32_t ocol = dst_order ? (uint32_t)dst_order[bi * Nd + j] : col;
+        // (aligned calls: one result row per src index over all samples' dst rows; the samples' lists are the same rows in the
+        // same order, so sample 0's inverse map names the row and the column keeps its sample offset)
+        const int64_t orow = src_order ? (align ? (int64_t)src_order[i] : bi * Ns + src_order[prow]) : prow;
+        const uint32_t ocol = dst_order ? (uint32_t)dst_order[bi * Nd + j] + (align ? (uint32_t)(bi * Nd) : 0u) : col;
         atomicMax(&best[orow], ((unsigned long long)orderable(acc) << 32) | (uint32_t)(~ocol));
     }
 }
@@ -1431,7 +1433,7 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
             const int64_t i = listed(wave * (32 * XSB) + sb * 32 + l31);
             if (i >= 0 && besti[sb] != 0xffffffffu) {
                 const uint32_t col = besti[sb] + (align ? (uint32_t)(bi * Nd) : 0u);
-                const int64_t orow = align ? i : l * Ns + (ORD ? (int64_t)src_order[l * Ns + i] : i);
+                const int64_t orow = align ? (ORD ? (int64_t)src_order[i] : i) : l * Ns + (ORD ? (int64_t)src_order[l * Ns + i] : i);
                 atomicMax(&best[orow], ((unsigned long long)orderable(bestv[sb]) << 32) | (uint32_t)(~col));
             }
         }
@@ -1494,7 +1496,6 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
     const int scout_steps = (mode >> 8) & 0xff;      // VTM_MATCH_SCOUT_STEPS(k): the scout tests after k pipeline steps
     mode &= 0xff;
     VTM_REQUIRE((src_order == nullptr) == (dst_order == nullptr), "vtm_match_filtered_ordered: both inverse maps or none");
-    VTM_REQUIRE(!(src_order && align), "vtm_match_filtered_ordered: not for aligned calls (one order per sample)");
     VTM_REQUIRE(mode == VTM_MATCH_ONE_LAUNCH || mode == VTM_MATCH_SCOUT_RANGE, "vtm_match_filtered: bad mode %d", mode);
     VTM_REQUIRE(B > 0 && C > 0 && C % 8 == 0 && Ns > 0 && Nd > 0, "vtm_match_filtered: bad sizes");
     VTM_REQUIRE(P1 == 0 || x1, "vtm_match_filtered: x1 is null but P1 > 0");
@@ -1762,12 +1763,12 @@ VTM_EXPORT int vtm_match_filtered_plan(const void *x0, int64_t P0, const void *x
 
 VTM_EXPORT int vtm_match_filtered_ordered(const void *x0, int64_t P0, const void *x1, int64_t P1, int dtype, int64_t B,
                                           int64_t C, const int32_t *a_sorted, int64_t Ns, const int32_t *b_sorted, int64_t Nd,
-                                          void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out, int64_t seed_L,
+                                          int align, void *ws, size_t ws_bytes, uint64_t *best, int32_t *flags_out, int64_t seed_L,
                                           int64_t seed_N, const int32_t *seed_pos1, const int32_t *seed_table, int mode,
                                           const int32_t *a_order, const int32_t *b_order, vtm_stream_t stream) {
     VTM_REQUIRE(seed_N >= 0 && seed_L >= 0, "vtm_match_filtered_ordered: bad seed description");
     VTM_REQUIRE(a_order && b_order, "vtm_match_filtered_ordered: null inverse map");
-    return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_sorted, Ns, b_sorted, Nd, 0, ws, ws_bytes, best, flags_out, seed_L,
+    return match_filtered_impl(x0, P0, x1, P1, dtype, B, C, a_sorted, Ns, b_sorted, Nd, align, ws, ws_bytes, best, flags_out, seed_L,
                                seed_N, seed_pos1, seed_table, mode, a_order, b_order, stream);
 }
 

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(ST) void scatter_kernel(Lists ls, int64_t B, int64_
                                                      int64_t P0, int64_t P1, const int32_t *__restrict__ cnt,
                                                      int32_t *__restrict__ off, int32_t *__restrict__ table,
                                                      int32_t *__restrict__ fill, int32_t *__restrict__ stage_rows,
-                                                     int32_t *__restrict__ stage_order) {
+                                                     int32_t *__restrict__ stage_order, int64_t n_out) {
     __shared__ int s_off[MAX_N + 2];
     __shared__ int wave_tot[ST / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(ST) void scatter_kernel(Lists ls, int64_t B, int64_
     __syncthreads();
     int run = incl - sum;
     for (int ww = 0; ww < wave; ++ww) run += wave_tot[ww];
-    int32_t *tb = (w == 0 && op == 1 && table != nullptr) ? table + b * N : nullptr;
+    int32_t *tb = (w == 0 && op == 1 && table != nullptr) ? table + b * N : nullptr;      // (shared order: replicated below)
     int32_t *og = w == 0 ? off + bo * (N + 2) : nullptr;
     for (int k = 0; k < per; ++k) {
         const int64_t p = p0 + k;
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(ST) void scatter_kernel(Lists ls, int64_t B, int64_
             const int v = c[p];
             s_off[p] = run;
             if (og) og[p] = run;
-            if (tb && p < N) tb[p] = v > 0 ? run : -1;
+            if (tb && p < N)
+                for (int64_t bb = 0; bb < n_out; ++bb) tb[bb * N + p] = v > 0 ? run : -1;
             run += v;
         }
     }
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(OT) void settle_kernel(Lists ls, int64_t B, int64_t
                                                     int64_t P0, int64_t P1, const int32_t *__restrict__ off,
                                                     int32_t *__restrict__ cnt, int32_t *__restrict__ fill,
                                                     const int32_t *__restrict__ stage_rows,
-                                                    const int32_t *__restrict__ stage_order) {
+                                                    const int32_t *__restrict__ stage_order, int64_t n_out) {
     int64_t b, slot;
     int op;
     if (!entry_of((int64_t)blockIdx.x * OT + threadIdx.x, ls, B, b, op, slot)) return;
@@ -154,6 +155,10 @@ __global__ __launch_bounds__(OT) void settle_kernel(Lists ls, int64_t B, int64_t
     if (g0 + rank >= ls.n[op]) return;
     ls.sorted[op][b * ls.n[op] + g0 + rank] = r;
     ls.order[op][b * ls.n[op] + g0 + rank] = mine;
+    for (int64_t bb = 1; bb < n_out; ++bb) {          // shared order (b == 0): every sample's list in sample 0's order
+        ls.sorted[op][bb * ls.n[op] + g0 + rank] = ls.rows[op][bb * ls.n[op] + mine];
+        ls.order[op][bb * ls.n[op] + g0 + rank] = mine;
+    }
     if (slot == g0) {                                   // nobody reads the counters any more: leave them zeroed
         cnt[(b * 2 + op) * (N + 1) + p] = 0;
         fill[(b * 2 + op) * (N + 1) + p] = 0;
@@ -175,7 +180,7 @@ VTM_EXPORT size_t vtm_position_order_ws_bytes(int64_t B, int64_t Ns, int64_t Nd,
 VTM_EXPORT int vtm_position_order(const int32_t *a_rows, int64_t Ns, const int32_t *b_rows, int64_t Nd, int64_t B, int64_t L,
                                   int64_t N, const int32_t *pos1, int64_t P0, int64_t P1, int32_t *counters, void *ws,
                                   size_t ws_bytes, int32_t *a_sorted, int32_t *a_order, int32_t *b_sorted, int32_t *b_order,
-                                  int32_t *table, vtm_stream_t stream) {
+                                  int32_t *table, int shared_order, vtm_stream_t stream) {
     VTM_REQUIRE(a_rows && b_rows && counters && ws && a_sorted && a_order && b_sorted && b_order, "vtm_position_order: null pointer");
     VTM_REQUIRE(B > 0 && Ns > 0 && Nd > 0 && N > 0 && L >= 0 && P0 >= 0 && P1 >= 0, "vtm_position_order: bad sizes");
     VTM_REQUIRE(B * (Ns + Nd) < (1ll << 31), "vtm_position_order: too many rows");
@@ -188,12 +193,16 @@ VTM_EXPORT int vtm_position_order(const int32_t *a_rows, int64_t Ns, const int32
     int32_t *off = static_cast<int32_t *>(ws);
     int32_t *stage_rows = off + B * 2 * (N + 2), *stage_order = stage_rows + B * (Ns + Nd);
     const Lists ls{{a_rows, b_rows}, {Ns, Nd}, {a_sorted, b_sorted}, {a_order, b_order}};
-    const dim3 grid((unsigned)vtm::cdiv(B * (Ns + Nd), OT)), block(OT);
-    hipLaunchKernelGGL(count_kernel, grid, block, 0, s, ls, B, L, N, pos1, P0, P1, cnt);
-    const dim3 sgrid((unsigned)(B * (vtm::cdiv(Ns, ST) + vtm::cdiv(Nd, ST))));
-    hipLaunchKernelGGL(scatter_kernel, sgrid, dim3(ST), 0, s, ls, B, L, N, pos1, P0, P1, (const int32_t *)cnt, off, table, fill,
-                       stage_rows, stage_order);
-    hipLaunchKernelGGL(settle_kernel, grid, block, 0, s, ls, B, L, N, pos1, P0, P1, (const int32_t *)off, cnt, fill,
-                       (const int32_t *)stage_rows, (const int32_t *)stage_order);
+    // shared order (aligned matching: one result row per src index over all samples): sample 0's positions decide, every
+    // sample's lists are written in that order -- whatever the other samples' positions are, entry i is the same original index
+    // in all of them
+    const int64_t Bs = shared_order ? 1 : B, n_out = shared_order ? B : 1;
+    const dim3 grid((unsigned)vtm::cdiv(Bs * (Ns + Nd), OT)), block(OT);
+    hipLaunchKernelGGL(count_kernel, grid, block, 0, s, ls, Bs, L, N, pos1, P0, P1, cnt);
+    const dim3 sgrid((unsigned)(Bs * (vtm::cdiv(Ns, ST) + vtm::cdiv(Nd, ST))));
+    hipLaunchKernelGGL(scatter_kernel, sgrid, dim3(ST), 0, s, ls, Bs, L, N, pos1, P0, P1, (const int32_t *)cnt, off, table, fill,
+                       stage_rows, stage_order, n_out);
+    hipLaunchKernelGGL(settle_kernel, grid, block, 0, s, ls, Bs, L, N, pos1, P0, P1, (const int32_t *)off, cnt, fill,
+                       (const int32_t *)stage_rows, (const int32_t *)stage_order, n_out);
     return vtm::launch_status("vtm_position_order");
 }

@@ -142,12 +142,14 @@ class MatchPlanner:
 # blocks; "0" = the reference's sequence order as in rounds 1-4) ...
 POSITION_ORDER = os.environ.get("VIDTOME_POSITION_ORDER", "1") != "0"
 # ... when the level is large enough for the sort (3 launches, ~40 us) to pay: src rows x dst rows per sample
+# ... also with align_batch (ONE order for all samples, sample 0's: entry i is the same original index in every sample)
+ALIGNED_ORDER = os.environ.get("VIDTOME_ALIGNED_ORDER", "1") != "0"
 POSITION_ORDER_MIN_PAIRS = int(os.environ.get("VIDTOME_POSITION_ORDER_MIN_PAIRS", str(1 << 26)))
 
 
 def order_level(Ns: int, Nd: int, tokens: int, align_batch: bool) -> bool:
     """Does a level of this geometry (not the first local one) meet its rows in position order?"""
-    return (POSITION_ORDER and not align_batch and Ns * Nd >= POSITION_ORDER_MIN_PAIRS and
+    return (POSITION_ORDER and (ALIGNED_ORDER or not align_batch) and Ns * Nd >= POSITION_ORDER_MIN_PAIRS and
             0 < tokens <= _lib.POSITION_ORDER_MAX_N)
 
 
@@ -179,7 +181,8 @@ def _run_level(x0: torch.Tensor, x1: Optional[torch.Tensor], parts, ratio: float
                     scout = 0
         if use_order:
             tokens, L, pos1, _ = seed
-            m_a, a_order, m_b, b_order, table = _lib.position_order(a_rows, b_rows, L, tokens, pos1, x0.shape[1])
+            m_a, a_order, m_b, b_order, table = _lib.position_order(a_rows, b_rows, L, tokens, pos1, x0.shape[1],
+                                                                    shared=align_batch)
             order, seed = (a_order, b_order), (tokens, L, pos1, table)     # the sort's offsets ARE the position -> dst table
         elif can_order and seed[2] is not None and seed[3] is None:
             seed = None        # a global level left in the reference's order without a position -> dst table: unseeded
