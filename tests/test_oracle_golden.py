@@ -505,3 +505,52 @@ def test_token_regimes_have_the_statistics_they_claim():
     assert near > 0.8 > far and float(cosf(x, 0, 1).mean()) > float(cosf(x, 0, 5).mean()) > 0.9     # drifts 0.1 token per frame
     with pytest.raises(ValueError):
         sites.regime_tokens("smooth", B, Fr, 200, C, torch.Generator().manual_seed(1))
+
+
+def test_match_result_does_not_depend_on_the_order_the_rows_are_met_in(oracle):
+    """The premise of round 5's position order (vtm_position_order + vtm_match_filtered_ordered): per src row the matcher's
+    result is the maximal canonical score and the LOWEST dst index attaining it -- a function of the two row SETS and their
+    original numbering, not of the order in which the rows are visited.  Checked on the oracle (merge.py:87-113 restated):
+    permute both operands, match, map rows and columns back through the inverse maps with ties broken by the original dst
+    index -> the bits of the unpermuted call; with exact duplicates among the dst rows (ties) and a zero dst token (NaN scores:
+    torch.max's rule is the first NaN, i.e. the lowest original index) the naive mapping of the permuted argmax is NOT enough,
+    which is why refine_kernel / exact_rows_kernel carry the original indices."""
+    rng = np.random.default_rng(11)
+    B, Ns, Nd, C = 2, 96, 80, 32
+    x = rng.standard_normal((B, Ns + Nd, C)).astype(np.float32)
+    x[:, Ns + 5] = x[:, Ns + 50]                       # exact duplicates among the dst rows
+    x[:, Ns + 7] = x[:, Ns + 5]
+    x[:, 3] = x[:, Ns + 50]                            # a src row that ties on them at score 1
+    x[1, Ns + 20] = 0                                  # zero tokens in sample 1: 0 / 0 -> NaN scores for every src row
+    x[1, Ns + 60] = 0
+    ra = np.broadcast_to(np.arange(Ns, dtype=np.int32), (B, Ns))
+    rb = np.broadcast_to(np.arange(Ns, Ns + Nd, dtype=np.int32), (B, Nd))
+    with np.errstate(all="ignore"):
+        a, b = oracle.normalize_gather(x, ra), oracle.normalize_gather(x, rb)
+        nm, ni = oracle.match(a, b)
+        naive_differs = False
+        for trial in range(4):
+            pa = np.stack([rng.permutation(Ns) for _ in range(B)])          # sorted entry -> original index
+            pb = np.stack([rng.permutation(Nd) for _ in range(B)])
+            if trial == 0:
+                pb = np.stack([np.arange(Nd)[::-1].copy() for _ in range(B)])   # the LAST copy / the last NaN is met first
+            ap = np.stack([a[s][pa[s]] for s in range(B)])
+            bp = np.stack([b[s][pb[s]] for s in range(B)])
+            nmp, nip = oracle.match(ap, bp)
+            # all scores of the permuted call, to break ties by ORIGINAL index like the ordered kernels do
+            got_m, got_i = np.empty_like(nm), np.empty_like(ni)
+            for s in range(B):
+                sc = ap[s].astype(np.float64) @ bp[s].astype(np.float64).T  # (only to find the tie groups; values come from nmp)
+                for r in range(Ns):
+                    best = nmp[s, r]
+                    if np.isnan(best):
+                        cand = [j for j in range(Nd) if np.isnan(bp[s][j]).any()]
+                    else:
+                        jstar = nip[s, r]
+                        cand = [j for j in range(Nd) if np.array_equal(bp[s][j], bp[s][jstar])]   # exact duplicates tie exactly
+                    got_m[s, pa[s, r]] = best
+                    got_i[s, pa[s, r]] = min(pb[s, j] for j in cand)
+                    naive_differs |= pb[s, nip[s, r]] != got_i[s, pa[s, r]]
+                del sc
+            assert np.array_equal(got_m, nm, equal_nan=True) and np.array_equal(got_i, ni), trial
+    assert naive_differs        # (the fixture does exercise the tie rule)
