@@ -465,3 +465,19 @@ def test_match_planner_state_machine_without_a_gpu():
     show(pl, 1000, 300, 500)
     mode, buf, keep, _ = pl.next()
     assert (mode, keep) == (O, False) and buf is None
+
+
+def test_position_order_size_helpers():
+    """vtm_position_order's host-side size helpers (no GPU): the counter block holds two counters per (sample, operand,
+    position + the no-position bucket), the scratch the offsets and the staging copies of both lists."""
+    from vidtome_amd import _lib
+    L = _lib.lib()
+    B, Ns, Nd, N = 2, 34816, 34816, 4096
+    assert L.vtm_position_order_counter_ints(B, N) == 2 * B * 2 * (N + 1)
+    assert L.vtm_position_order_ws_bytes(B, Ns, Nd, N) == 4 * (B * 2 * (N + 2) + 2 * B * (Ns + Nd))
+    assert L.vtm_position_order_counter_ints(0, N) == 0 and L.vtm_position_order_ws_bytes(B, 0, Nd, N) == 0
+    assert _lib.POSITION_ORDER_MAX_N == 16360
+    from vidtome_amd import merge
+    assert merge.order_level(34816, 34816, 4096, False) and merge.order_level(34816, 34816, 4096, True)
+    assert not merge.order_level(3072, 7168, 1024, False)            # a mid level 2: below the pair threshold
+    assert not merge.order_level(34816, 34816, 16384, False)         # 1024 x 1024 images: the offsets would not fit the LDS
