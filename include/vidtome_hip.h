@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define VTM_ABI_VERSION 1
+/* 2 (round 6): `flags_out` of the vtm_match_filtered* family is 8 int32 (it was 4 in version 1: a host built against the
+ * version-1 header would see a 16-byte overrun, hence the bump -- check vtm_version() before calling). */
+#define VTM_ABI_VERSION 2
 
 enum vtm_dtype { VTM_F32 = 0, VTM_F16 = 1, VTM_BF16 = 2 };
 
@@ -141,7 +143,8 @@ int vtm_match_filtered_seeded(const void *x0, int64_t P0, const void *x1, int64_
  * pure overhead (+ 40 %).  The host steers by the counters of the previous call of the same level: flags_out may be PINNED HOST
  * memory (the 32-byte copy is asynchronous either way); with this plan flags_out[4] / [5] = blocks tested / alive in the scout
  * and flags_out[7] = blocks inside the spans the second launch processed ([7] / [4] = the fraction of the level it had to stream:
- * the plan pays below about 0.45).  Falls back to one launch when there are no seeds, the rows are
+ * the plan pays below about 0.09 -- merge.MatchPlanner's HIGH; round 5's first measurement, "below about 0.45", did not survive
+ * the per-level runs of profiles/r05_n_scout_range_plan.txt).  Falls back to one launch when there are no seeds, the rows are
  * shorter than 256 channels or seed_N is not a multiple of 128 >= 256. */
 #define VTM_MATCH_ONE_LAUNCH 0
 #define VTM_MATCH_SCOUT_RANGE 1

@@ -552,6 +552,71 @@ def test_match_planner_steers_by_the_previous_calls_counters(L):
             assert mode == L.MATCH_ONE_LAUNCH and buf is None and keep == settled, (regime, pl.view.tolist())
 
 
+def test_planner_cost_is_bounded_on_alternating_regimes(L):
+    """what merge.MatchPlanner's hysteresis costs when a clip keeps changing character.  One top
+    level-1 geometry (cfg-2: 49 152 x 16 384 x 320), the data alternating between a low-noise clip (corr01: the scout + range
+    plan wins) and uncorrelated tokens (n01: it loses) every 2, 8 and 300 calls.  Each (regime, plan) pair is timed once
+    (median of 9); the planner is then driven with REAL calls (its decisions are functions of the counters those calls copy
+    back) and the sequence is priced with the medians -- independent of timer noise.  Bounds: never more than 3 % above
+    ALWAYS the one-launch plan (rounds 1-4's: the planner cannot cost more than its exploring calls), and within 5 % of a
+    per-call oracle once a regime lasts 300 calls.  (Against faster alternation nothing that steers by the previous call can
+    follow; measured in round 6: at period 2 always scouting after one step is 12 % cheaper than what the planner does --
+    the scout saves 0.42 ms on the clip and costs 0.19 ms on the noise -- at the price of +17 % on data it never pays for.
+    Consecutive calls of one level are consecutive chunks of one video at one noise level: the planner is tuned for that.)"""
+    from vidtome_amd import merge, sites
+    g = torch.Generator().manual_seed(11)
+    B, F, N, C, fs = 2, 16, 4096, 320, 12
+    Ns, Nd = fs * N, (F - fs) * N
+    ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+    rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+    seed = (N, F * N, None, None)
+    xs = {}
+    for regime in ("corr01", "n01"):
+        x = sites.regime_tokens(regime, B, F, N, C, g)
+        xs[regime] = torch.nn.functional.layer_norm(x, (C,)).reshape(B, F * N, C).half().to(DEV)
+    plans = {"one": (L.MATCH_ONE_LAUNCH, 0), "range": (L.MATCH_SCOUT_RANGE, 0), "range1": (L.MATCH_SCOUT_RANGE, 1)}
+    t = {}
+    for regime, x in xs.items():
+        ref = None
+        for pname, (mode, scout) in plans.items():
+            call = lambda: L.match_filtered(x, None, ra, rb, False, seed=seed, mode=mode, scout_steps=scout)
+            best = call()
+            ref = best if ref is None else ref
+            assert torch.equal(best, ref), (regime, pname)
+            ts = []
+            for _ in range(9):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                call()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            t[regime, pname] = sorted(ts)[4]
+    assert t["corr01", "range"] < t["corr01", "one"] and t["n01", "range"] > t["n01", "one"], t   # the premise
+    report = {}
+    for period, ncalls in ((2, 600), (8, 600), (300, 1200)):
+        pl = merge.MatchPlanner()
+        total = oracle_total = 0.0
+        fixed = {p: 0.0 for p in plans}
+        issued = {p: 0 for p in plans}
+        for i in range(ncalls):
+            regime = ("corr01", "n01")[(i // period) % 2]
+            mode, buf, _, scout = pl.next()
+            L.match_filtered(xs[regime], None, ra, rb, False, seed=seed, mode=mode, stats_host=buf, scout_steps=scout)
+            torch.cuda.synchronize()                    # (the product never waits; the test makes the reading deterministic)
+            pname = "one" if mode == L.MATCH_ONE_LAUNCH else ("range1" if scout else "range")
+            issued[pname] += 1
+            total += t[regime, pname]
+            oracle_total += min(t[regime, p] for p in plans)
+            for p in plans:
+                fixed[p] += t[regime, p]
+        report[period] = (total / fixed["one"], total / min(fixed.values()), total / oracle_total, issued)
+        assert total <= 1.03 * fixed["one"], (period, report[period], t)
+    assert report[300][2] <= 1.05, (report, t)
+    print("planner cost (vs the one-launch plan, vs the best fixed plan, vs a per-call oracle, calls per plan):", report,
+          "ms per call:", t)
+
+
 def test_refine_many_candidates_per_row(L):
     """Rows with MANY candidates inside the fp16 filter's window (what frames of one clip at low noise produce: 4-17 per
     row): every src row has 6-12 dst rows whose scores differ by ~1e-7 ... 1e-3, exact duplicates among them, C up to 1280,
@@ -844,6 +909,171 @@ def test_planted_mid_and_full_size_golden_gpu(L, mode, fname, monkeypatch):
             assert tuple(got.shape) == tuple(c[n + "_shape"]), (name, n, got.shape)
             assert np.array_equal(got[..., :16], c[n + "_head"]), (name, n)
             assert idx_sha(got) == str(c[n + "_sha256"]), (name, n)
+
+
+class _FixedPlan:
+    """Stands in for merge.MatchPlanner in the pinning tests below: ALWAYS the same launch plan (mode, scout depth, position
+    order or not), counters copied into a pinned buffer the test reads behind a synchronise."""
+
+    def __init__(self, mode, scout, order):
+        self.mode, self.scout, self.order = mode, scout, order
+        self.buf = torch.zeros(8, dtype=torch.int32).pin_memory()
+
+    def next(self):
+        self.buf.zero_()
+        return self.mode, self.buf, self.order, self.scout
+
+
+@pytest.mark.parametrize("fname", ["planted.npz", "planted_mid.npz", "planted_cfg14.npz"])
+def test_launch_plans_vs_reference_sha_at_full_size(L, fname, monkeypatch):
+    """VERDICT r05 missing 3: the launch plans round 5 added -- scout + range, the one-step scout, position-ordered levels
+    with the shared (aligned) order -- held to the REFERENCE's own index arrays (sha256, tests/golden/make_golden*.py) at the
+    level shapes of every BASELINE configuration, not only to the one-launch HIP plan at <= 12 288 rows.  Every case runs
+    under each plan {one launch, scout + range} x scout depth {the filter's own, ONE channel step}; the global
+    (`bipartite_soft_matching_2s`) cases additionally with the rows handed over in position order (vtm_position_order;
+    merge.POSITION_ORDER_MIN_PAIRS lifted so that the small ones order too), the anchors' positions chosen so that a src
+    row's planted partner sits at ITS position wherever that is free (the seeds then start every row at its true maximum);
+    `flags_out[7]` (blocks inside the spans of the second launch) says the plan really ran.  (Planted cosines go down to 0.55,
+    below the rest bound at the scout's depth, so most tiles stay marked here; the sparse-span regime at full size is the
+    low-noise clip of test_compute_merge_with_live_planners_equals_exact_at_cfg2.)  merge.py:87-117, 392-421."""
+    from inputs import idx_sha, planted_batch, planted_local_chunk
+    from vidtome_amd import merge
+    monkeypatch.setattr(merge, "MATCH_MODE", "filtered")
+    monkeypatch.setattr(merge, "MATCH_PLAN", "auto")
+    monkeypatch.setattr(merge, "SHALLOW_SCOUT", True)
+    monkeypatch.setattr(merge, "POSITION_ORDER_MIN_PAIRS", 1)
+    R, O = L.MATCH_SCOUT_RANGE, L.MATCH_ONE_LAUNCH
+    ran_range = ran_ordered = 0
+
+    def check(c, lv, what):
+        name = str(c["name"])
+        assert lv.unm_num == int(c["unm_num"]) if "unm_num" in c else True, (name, what)
+        for n in ("unm_idx", "src_idx", "dst_idx"):
+            got = getattr(lv, n).cpu().numpy().astype(np.int32)
+            if str(c["kind"]) == "planted":
+                got = got[0]
+            assert np.array_equal(got[..., :16], c[n + "_head"]), (name, what, n)
+            sha = hashlib.sha256(got.tobytes()).hexdigest() if str(c["kind"]) == "planted" else idx_sha(got)
+            assert sha == str(c[n + "_sha256"]), (name, what, n)
+
+    for c in load_cases(fname):
+        kind, name = str(c["kind"]), str(c["name"])
+        if kind in ("planted", "local"):
+            if kind == "planted":
+                a, b = planted_inputs(int(c["Ns"]), int(c["Nd"]), int(c["C"]), seed=int(c["seed"]))
+                F, randf, unm_pre, align = int(c["F"]), int(c["randf"]), 0, False
+                Ltot = a.shape[1] + b.shape[1]
+                tnum = Ltot // F
+                x = np.empty((1, Ltot, a.shape[2]), np.float32)
+                is_dst = (np.arange(Ltot) // tnum) % 4 == randf
+                x[0, is_dst], x[0, ~is_dst] = b[0], a[0]
+            else:
+                F, randf, unm_pre, align, tnum = int(c["F"]), int(c["randf"]), int(c["unm_pre"]), bool(c["align"]), int(c["tnum"])
+                x = planted_local_chunk(int(c["B"]), F, tnum, unm_pre, int(c["C"]), randf, int(c["seed"]))
+            if unm_pre:
+                continue                 # (a level-2 SHAPE without the sequence behind it has no positions: compute_merge test below)
+            xt = _t(x)
+            can_range = tnum >= 256 and tnum % 128 == 0 and x.shape[2] >= 256     # include/vidtome_hip.h: the plan's conditions
+            for mode, scout in ((O, 0), (R, 0), (R, 1)):
+                fp = _FixedPlan(mode, scout, True)
+                lv = merge.local_level(xt, None, x.shape[1], F, float(c["ratio"]), 0, randf, 4, align, True, tokens=tnum,
+                                       planner=fp)
+                torch.cuda.synchronize()
+                if mode == R and can_range:
+                    assert int(fp.buf[7]) > 0 and int(fp.buf[4]) > 0, (name, scout, fp.buf.tolist())
+                    ran_range += 1
+                check(c, lv, (mode, scout))
+        else:
+            src_len, dst_len, B, C = int(c["src_len"]), int(c["dst_len"]), int(c["B"]), int(c["C"])
+            a, b = planted_batch(src_len, dst_len, C, int(c["seed"]), B)
+            xs, xd = _t(a), _t(b)
+            tokens = 4096 if C == 320 else 1024
+            align = bool(c["align"])
+            # positions: local (src) row i sits at i % tokens (rows of the joined chunk); dst row j gets the position of the src
+            # row the REFERENCE-equal unseeded run matched to it (last writer wins), else j % tokens
+            lv0 = merge.global_level(xs, xd, None, src_len, True, float(c["ratio"]), align, True)
+            check(c, lv0, "unseeded")
+            pos = (torch.arange(dst_len, device=DEV) % tokens).to(torch.int32).expand(B, dst_len).contiguous()
+            _, node_idx = L.decode_best(lv0.best)                   # (B, Ns), aligned: (1, Ns) over the B * Nd concatenation
+            node_idx = node_idx.long().reshape(-1, src_len)
+            src_pos = (torch.arange(src_len, device=DEV) % tokens).to(torch.int32)
+            for bi in range(B):
+                if node_idx.shape[0] == B:
+                    pos[bi, node_idx[bi]] = src_pos
+                else:                                               # the sample whose dst row won the aligned maximum
+                    mine = (node_idx[0] // dst_len) == bi
+                    pos[bi, (node_idx[0] % dst_len)[mine]] = src_pos[mine]
+            for mode, scout, order in ((O, 0, False), (O, 0, True), (R, 0, True), (R, 1, True)):
+                fp = _FixedPlan(mode, scout, order)
+                lv = merge.global_level(xs, xd, None, src_len, True, float(c["ratio"]), align, True, tokens=tokens,
+                                        anchor_positions=pos, planner=fp)
+                torch.cuda.synchronize()
+                if mode == R and C >= 256 and dst_len >= 256:
+                    assert int(fp.buf[7]) > 0 and int(fp.buf[4]) > 0, (name, scout, fp.buf.tolist())
+                    ran_range += 1
+                ran_ordered += order
+                check(c, lv, (mode, scout, order))
+    assert ran_range > 0 and (fname == "planted.npz" or ran_ordered > 0)
+
+
+@pytest.mark.parametrize("regime", ["corr01", "n01"])
+def test_compute_merge_with_live_planners_equals_exact_at_cfg2(L, regime, monkeypatch):
+    """VERDICT r05 missing 3, second half: the code the bench times.  cfg-2's top and mid merging sites (16 frames of 64 x 64
+    / 32 x 32 tokens, batch 2, local 0.5 + global 0.5), five chunks of one clip, `compute_merge` with the block's
+    MatchPlanners LIVE (they switch plans between the chunks: scout + range and the one-step scout on the low-noise clip,
+    back to one launch and out of the position order on uncorrelated tokens) -- every level's unm / src / dst indices and
+    the anchors it leaves behind equal the run with the exact fp32 matcher (VIDTOME_MATCH=exact, itself pinned to the
+    reference's sha256 at these shapes: test_planted_mid_and_full_size_golden_gpu).  patch.py:44-85."""
+    import vidtome_amd
+    from vidtome_amd import merge, sites
+    from vidtome_amd import patch as vpatch
+    B, F, latent = 2, 16, (64, 64)
+    sl = [sites.Site("up3.0", 1, 320, 8), sites.Site("up2.0", 2, 640, 8)]
+    issued = []
+    orig = L.match_filtered
+
+    def logged(*a, **k):
+        issued.append((k.get("mode", 0), k.get("scout_steps", 0), k.get("order") is not None))
+        return orig(*a, **k)
+
+    runs = {}
+    for mode in ("exact", "filtered"):
+        monkeypatch.setattr(merge, "MATCH_MODE", mode)
+        monkeypatch.setattr(L, "match_filtered", logged)
+        unet = sites.SiteUNet(sl, seed=4).to(device=DEV, dtype=torch.float16)
+        vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B)
+        unet.set_size(latent)
+        torch.manual_seed(123)
+        rec = []
+        with torch.no_grad():
+            for ck in range(5):
+                for i, (site, blk) in enumerate(zip(sl, unet.blocks)):
+                    if not hasattr(blk, "generator"):
+                        blk.generator = vpatch.init_generator(torch.device(DEV))
+                    h = sites.synthetic_hidden(site, B, F, latent, torch.float16, DEV, seed=700 + 13 * (ck % 3) + i,
+                                               clip_seed=77 + i, regime=regime, frame0=(ck % 3) * F)
+                    m, _, _ = vpatch.compute_merge(blk, vpatch.layer_norm(blk.norm1, h), blk._tome_info, want_indices=True,
+                                                   materialize=False)
+                    plan = m.plan
+                    lvs = list(plan.levels) + ([plan.global_level] if plan.global_level is not None else [])
+                    rec.append([(lv.unm_idx.cpu(), lv.src_idx.cpu(), lv.dst_idx.cpu()) for lv in lvs]
+                               + [blk.global_tokens.float().cpu()])
+        runs[mode] = rec
+        vidtome_amd.remove_patch(unet)
+    assert len(runs["exact"]) == len(runs["filtered"]) == 10
+    for ra, rb in zip(runs["exact"], runs["filtered"]):
+        assert len(ra) == len(rb)
+        for la, lb in zip(ra[:-1], rb[:-1]):
+            for ta, tb in zip(la, lb):
+                assert torch.equal(ta, tb)
+        assert torch.equal(ra[-1], rb[-1])
+    modes = {m for m, _, _ in issued}
+    assert len(issued) >= 24, len(issued)
+    if regime == "corr01":
+        assert (L.MATCH_SCOUT_RANGE, 1, True) in issued and (L.MATCH_SCOUT_RANGE, 1, False) in issued, sorted(set(issued))
+    else:
+        assert modes == {L.MATCH_SCOUT_RANGE, L.MATCH_ONE_LAUNCH}, sorted(set(issued))
+        assert (L.MATCH_ONE_LAUNCH, 0, False) in issued[-6:], issued[-6:]      # out of the position order at the end
 
 
 @pytest.mark.parametrize("shape", ["top_l2", "top_g", "mid_g"])

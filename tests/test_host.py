@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.exported_symbols())
-    assert _lib.lib().vtm_version() == 1
+    assert _lib.lib().vtm_version() == _lib.ABI_VERSION == 2
     assert _lib.lib().vtm_pad_rows(257) == 512 and _lib.lib().vtm_pad_k(320) == 320 and _lib.lib().vtm_pad_k(40) == 64
 
 
@@ -424,12 +424,17 @@ def test_match_planner_state_machine_without_a_gpu():
         pl = object.__new__(merge.MatchPlanner)        # (the constructor pins its buffer: needs a GPU)
         pl.mode, pl.buf = _lib.MATCH_SCOUT_RANGE, torch.zeros(8, dtype=torch.int32)
         pl.view, pl.cool, pl.switches = pl.buf.numpy(), 0, 0
+        pl.probe_buf = torch.zeros(8, dtype=torch.int32)
+        pl.probe_view = pl.probe_buf.numpy()
         pl.order_alone, pl.order_off, pl.order_probe = order_alone, False, False
         pl.shallow, pl.shallow_ban, pl.issued_shallow = False, 0, False
         return pl
 
     def show(pl, tested, alive, spans):
         pl.view[4], pl.view[5], pl.view[7] = tested, alive, spans
+
+    def show_probe(pl, tested, alive):         # the one-launch call's own counters arrive in the OTHER buffer
+        pl.probe_view[4], pl.probe_view[5] = tested, alive
 
     R, O = _lib.MATCH_SCOUT_RANGE, _lib.MATCH_ONE_LAUNCH
     pl = planner(True)
@@ -447,10 +452,12 @@ def test_match_planner_state_machine_without_a_gpu():
     show(pl, 1000, 300, 500)                                           # the DEEP scout's spans are wide: one launch
     mode, buf, keep, scout = pl.next()
     assert (mode, keep, scout) == (O, True, 0) and buf is not None     # ordered (order_alone), asks the filter for its counters
-    show(pl, 1000, 290, 0)                                             # 29 % alive in the one-launch filter: the ordering stays
+    show(pl, 1000, 1000, 1000)                                         # a LATE copy of an earlier scout call: must not be read as the probe
+    assert pl.order_probe and pl.next()[0::2] == (O, True) and pl.order_probe
+    show_probe(pl, 1000, 290)                                          # 29 % alive in the one-launch filter: the ordering stays
     mode, buf, keep, _ = pl.next()
     assert (mode, keep) == (O, True) and buf is None
-    for _ in range(merge.MatchPlanner.COOL - 2):
+    for _ in range(merge.MatchPlanner.COOL - 3):
         assert pl.next()[0] == O
     assert pl.next()[0] == R                                           # ... and tries the plan again
     # nothing dies in the filter either (uncorrelated tokens): the ordering goes too; level 2 never orders without the plan
@@ -458,7 +465,7 @@ def test_match_planner_state_machine_without_a_gpu():
     pl.next()
     show(pl, 1000, 1000, 1000)
     assert pl.next()[0::2] == (O, True)
-    show(pl, 1000, 1000, 0)
+    show_probe(pl, 1000, 1000)
     assert pl.next()[0::2] == (O, False)
     pl = planner(False)
     pl.next()

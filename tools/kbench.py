@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--ordered", action="store_true", help="match: sort both row lists by token position first "
                     "(vtm_position_order + vtm_match_filtered_ordered, what levels 2 / global do); the sort is inside the timing")
     ap.add_argument("--C", type=int, default=320)
+    ap.add_argument("--share", type=int, default=1, help="attn: share_groups (B must be a multiple)")
+    ap.add_argument("--bounded", type=float, default=0.0, help="attn: device-side query count = this fraction of Mq")
+    ap.add_argument("--check", action="store_true", help="attn: compare a few rows with an fp32 torch reference")
     ap.add_argument("--data", default="random", help="attn: random | zeros | const (operand values); match: n01 | corr01 | "
                     "corr05 | flat25 | dup | zero | all (token regime; random = n01 in fp16 straight from the device generator)")
     a = ap.parse_args()
@@ -129,18 +132,38 @@ def main():
         if a.data != "random":       # how much of the time is the operands' switching activity (power-limited clock)?
             qk = torch.zeros_like(qk) if a.data == "zeros" else torch.full_like(qk, 0.25)
             vt = torch.zeros_like(vt) if a.data == "zeros" else torch.full_like(vt, 0.25)
-        if a.Mq:
-            Mq = a.Mq
-            q = torch.randn(B, (Mq + 7) // 8 * 8, C, generator=g, device=dev, dtype=torch.float16)
-            if a.data != "random":
-                q = torch.zeros_like(q) if a.data == "zeros" else torch.full_like(q, 0.25)
-            med, best = timeit(lambda: _lib.attention_kv(q, qk[:, :, C:], vt, h, Mq, M, d ** -0.5), a.iters)
+        Mq = a.Mq or M
+        q = torch.randn(B, (Mq + 7) // 8 * 8, C, generator=g, device=dev, dtype=torch.float16) if a.Mq else qk[:, :, :C]
+        if a.Mq and a.data != "random":
+            q = torch.zeros_like(q) if a.data == "zeros" else torch.full_like(q, 0.25)
+        kk = qk[:, :, C:]
+        G = a.share                      # shared probabilities (pnp_utils.py:57-67): q / k of the first B / G samples
+        qc = None
+        if a.bounded:                    # device-side live-query counts (vtm_attention_kv_bounded)
+            qc = torch.full((B,), int(Mq * a.bounded), dtype=torch.int32, device=dev)
+        if a.Mq or G > 1 or qc is not None:
+            run = lambda: _lib.attention_kv(q, kk, vt, h, Mq, M, d ** -0.5, share_groups=G, q_count=qc)
         else:
-            Mq = M
-            med, best = timeit(lambda: _lib.attention(qk[:, :, :C], qk[:, :, C:], vt, h, M, d ** -0.5, 1), a.iters)
-        fl = 4.0 * B * Mq * M * C
-        print(f"attention B={B} Mq={Mq} Mk={M} h={h} d={d}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), "
-              f"best {best:.3f} ms ({fl / best / 1e9:.1f} TFLOP/s)")
+            run = lambda: _lib.attention(q, kk, vt, h, M, d ** -0.5, 1)
+        med, best = timeit(run, a.iters)
+        live = Mq * (a.bounded or 1.0)
+        fl = 4.0 * B * live * M * C
+        print(f"attention B={B} Mq={Mq} Mk={M} h={h} d={d} share={G} bounded={a.bounded}: median {med:.3f} ms ({fl / med / 1e9:.1f} "
+              f"TFLOP/s), best {best:.3f} ms ({fl / best / 1e9:.1f} TFLOP/s)   [VTM_ATT16={os.environ.get('VTM_ATT16', '')} "
+              f"NQ={os.environ.get('VTM_ATT16_NQ', '')} WAVES={os.environ.get('VTM_ATT16_WAVES', '')}]")
+        if a.check:                      # a few rows of every sample against fp32 torch (sa_forward's arithmetic)
+            out = run()
+            nrow = int(live)
+            rows = torch.cat([torch.arange(0, min(96, nrow)), torch.arange(max(0, nrow - 96), nrow)]).to(dev)
+            worst = 0.0
+            for b in range(B):
+                bq = b % (B // G)
+                for hh in range(h):
+                    sl = slice(hh * d, (hh + 1) * d)
+                    sc = (q[bq, rows][:, sl].float() @ kk[bq, :M, sl].float().T) * d ** -0.5
+                    ref = torch.softmax(sc, -1) @ vt[b, sl, :M].float().T
+                    worst = max(worst, float((out[b, rows][:, sl].float() - ref).abs().max()))
+            print(f"   check: max |out - fp32 reference| over {len(rows)} rows x {B} samples x {h} heads = {worst:.2e}")
     elif a.what == "sort":
         keys = torch.randint(0, 2 ** 62, (a.B, a.n), generator=g, device=dev, dtype=torch.int64)
         med, best = timeit(lambda: _lib.sort_desc(keys), a.iters)

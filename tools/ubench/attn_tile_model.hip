@@ -5,12 +5,49 @@
 // the per-tile barrier and the staging cost.
 //   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 tools/ubench/attn_tile_model.hip -o tools/ubench/attn_tile_model
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// Round 6, VERDICT r05 item 1b: an exponent path without v_exp_f32.  The score arrives from the MFMA as z = (x + 15) / 64
+// (scale and shift ride in the contraction's spare k-slots), ONE v_cvt_pknorm_u16_f32 per pair clamps, scales and packs it
+// to the fp16 BIT PATTERN [exponent = floor(x) + 15 | mantissa = frac(x)], i.e. Schraudolph's (1 + f) 2^floor(x); the rest
+// is packed fp16: g = 1 + f (v_and_or_b32), a cubic in g (3 v_pk_fma_f16) and the exponent put back --
+//   POLY 7: p = 2^floor(x) * P3(g),  P3 ~ 2^(g - 1)  (v_and_b32 + v_pk_mul_f16): 7 instructions per PAIR of scores,
+//            max relative error 1.3e-3, rms 4.3e-4 (exp + round-to-fp16: 4.8e-4 / 2.1e-4);
+//   POLY 6: p = t * C3(g),  C3 ~ 2^(g - 1) / g  (t itself as the fp16 value): 6 instructions, max 3.1e-3, rms 1.1e-3
+// against 2 v_exp_f32 + 1 v_cvt_pk_f16_f32 = 3 instructions but 2 of them quarter rate.
+template <int POLY>
+__device__ __forceinline__ uint32_t exp_pair_poly(float z0, float z1) {
+    const u16x2 u2 = __builtin_amdgcn_cvt_pknorm_u16(z0, z1);
+    const uint32_t t = __builtin_bit_cast(uint32_t, u2);
+    uint32_t gb;   // (t & 0x03ff03ff) | 0x3c003c00 in ONE instruction (the compiler emits v_and + v_or); one scalar operand per VOP3
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(gb) : "v"(t), "s"(0x03ff03ffu), "v"(0x3c003c00u));
+    const h16x2 g = __builtin_bit_cast(h16x2, gb);
+    if constexpr (POLY == 7) {
+        const h16x2 c3 = {(_Float16)0.07923143f, (_Float16)0.07923143f}, c2 = {(_Float16)-0.0130719f, (_Float16)-0.0130719f};
+        const h16x2 c1 = {(_Float16)0.48468515f, (_Float16)0.48468515f}, c0 = {(_Float16)0.44906588f, (_Float16)0.44906588f};
+        h16x2 acc = __builtin_elementwise_fma(g, c3, c2);
+        acc = __builtin_elementwise_fma(g, acc, c1);
+        acc = __builtin_elementwise_fma(g, acc, c0);
+        const h16x2 e = __builtin_bit_cast(h16x2, t & 0x7c007c00u);
+        return __builtin_bit_cast(uint32_t, (h16x2)(e * acc));
+    } else {
+        const h16x2 c3 = {(_Float16)-0.10246134f, (_Float16)-0.10246134f}, c2 = {(_Float16)0.69064004f, (_Float16)0.69064004f};
+        const h16x2 c1 = {(_Float16)-1.35417387f, (_Float16)-1.35417387f}, c0 = {(_Float16)1.76527665f, (_Float16)1.76527665f};
+        h16x2 acc = __builtin_elementwise_fma(g, c3, c2);
+        acc = __builtin_elementwise_fma(g, acc, c1);
+        acc = __builtin_elementwise_fma(g, acc, c0);
+        return __builtin_bit_cast(uint32_t, (h16x2)(__builtin_bit_cast(h16x2, t) * acc));
+    }
+}
 
 __device__ __forceinline__ uint32_t pmax3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t d;
@@ -20,6 +57,8 @@ __device__ __forceinline__ uint32_t pmax3(uint32_t a, uint32_t b, uint32_t c) {
 
 // MODE 0: the kernel's order (QK^T, exps, check, PV).  MODE 1: no exps (v_mov instead).  MODE 2: no MFMAs at all (VALU only).
 // MODE 3: the PV MFMAs only (the unused QK^T is eliminated).  MODE 4: as 0 with PV from 32-row blocks (8 x 32x32x16, no swaps).
+// MODE 6 / 7: as 0 with the packed-fp16 polynomial exponent (exp_pair_poly<7> / <6>) instead of v_exp_f32 + v_cvt_pk.
+// MODE 8: as 0 with HALF the pairs through exp_pair_poly<7> (is there a second issue port to win?  r01: no).
 template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void tile_model(float *out, int iters, float seed, unsigned long long *cyc) {
     const unsigned long long c_begin = clock64();   // s_memtime: shader-clock cycles
@@ -88,6 +127,17 @@ __global__ __launch_bounds__(NT) void tile_model(float *out, int iters, float se
                     else p = __builtin_amdgcn_exp2f(sv);
                     pf[st][e] = (_Float16)p;
                 }
+            if constexpr (MODE == 6 || MODE == 7 || MODE == 8) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    if (MODE == 8 && (st & 1)) continue;      // (half / half: steps 1 and 3 keep the v_exp path above)
+                    u32x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        w[j] = exp_pair_poly<(MODE == 7 ? 6 : 7)>(s[st >> 1][8 * (st & 1) + 2 * j], s[st >> 1][8 * (st & 1) + 2 * j + 1]);
+                    pf[st] = __builtin_bit_cast(h16x8, w);    // (the exps of this step above are dead code now)
+                }
+            }
             uint32_t pw[16];
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
@@ -175,7 +225,39 @@ void run(const char *name, int wgs_per_cu) {
     (void)hipFree(cyc);
 }
 
+// accuracy of exp_pair_poly on the hardware (v_cvt_pknorm's rounding included): x on a 2^-12 grid over [-14, 8)
+template <int POLY>
+__global__ void poly_accuracy(float *out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = -14.0f + (float)i * (22.0f / n);
+    const uint32_t w = exp_pair_poly<POLY>((x + 15.0f) / 64.0f, (x + 15.0f) / 64.0f);
+    const h16x2 p = __builtin_bit_cast(h16x2, w);
+    out[i] = (float)p[0] / exp2f(x) - 1.0f;
+}
+
+template <int POLY>
+void accuracy() {
+    const int n = 22 * 4096;
+    float *d, *h = (float *)malloc(sizeof(float) * n);
+    (void)hipMalloc(&d, sizeof(float) * n);
+    hipLaunchKernelGGL(poly_accuracy<POLY>, dim3((n + 255) / 256), dim3(256), 0, 0, d, n);
+    (void)hipMemcpy(h, d, sizeof(float) * n, hipMemcpyDeviceToHost);
+    double mx = 0, sq = 0, mean = 0;
+    for (int i = 0; i < n; ++i) {
+        mx = fabs(h[i]) > mx ? fabs(h[i]) : mx;
+        sq += (double)h[i] * h[i];
+        mean += h[i];
+    }
+    printf("polynomial exponent, %d instr / pair: relative error of p over x in [-14, 8): max %.2e  rms %.2e  mean %.2e"
+           "   (v_exp_f32 + round to fp16: max 4.8e-04 rms 2.1e-04)\n", POLY, mx, sqrt(sq / n), mean / n);
+    (void)hipFree(d);
+    free(h);
+}
+
 int main() {
+    accuracy<7>();
+    accuracy<6>();
     for (int w : {1, 2}) {
         run<0, 512>("kernel mix (QK^T, exp, check, PV16)", w);
         run<1, 512>("same without the exps (v_mov)", w);
@@ -183,6 +265,9 @@ int main() {
         run<3, 512>("PV MFMAs only (12 x 16x16x32)", w);
         run<4, 512>("PV from 32-row blocks (8 x 32x32x16, no swaps)", w);
         run<5, 512>("software-pipelined (QK^T of t+1 beside exps of t)", w);
+        run<6, 512>("polynomial exponent, 7 instr / pair (no v_exp)", w);
+        run<7, 512>("polynomial exponent, 6 instr / pair (no v_exp)", w);
+        run<8, 512>("half v_exp, half polynomial (7 instr / pair)", w);
     }
     run<0, 768>("kernel mix, 12-wave workgroup", 1);
     run<5, 768>("software-pipelined, 12-wave workgroup", 1);

@@ -18,6 +18,7 @@ from typing import Optional, Tuple
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2   # include/vidtome_hip.h VTM_ABI_VERSION (2: flags_out of the filtered matchers is 8 int32)
 LIB_PATH = os.environ.get("VIDTOME_HIP_LIB") or os.path.join(_HERE, "lib", "libvidtome_hip.so")
 
 VTM_F32, VTM_F16, VTM_BF16 = 0, 1, 2
@@ -109,7 +110,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(L, name)   # AttributeError here = the .so is stale w.r.t. the header
             fn.argtypes = argtypes
             fn.restype = restype
-        if L.vtm_version() != 1:
+        if L.vtm_version() != ABI_VERSION:
             raise RuntimeError("libvidtome_hip.so ABI version mismatch")
         if L.vtm_build_ablations() != 0 and os.environ.get("VIDTOME_ALLOW_ABLATED") != "1":
             # an experiment build (csrc/ablate.h) computes wrong results by construction: only tools/ may load one, knowingly
@@ -591,12 +592,16 @@ def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[to
 @_on_device
 def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, Mq: int, Mk: int, scale: float,
                  use_workspace: bool = True, q_count: Optional[torch.Tensor] = None,
-                 k_fold: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+                 k_fold: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, share_groups: int = 1) -> torch.Tensor:
     """Cross-attention core (patch.py:178-183): q (B, Mqp, C), k (B, Mkp, C) views contiguous along the last axis,
     vt (B, C, ldvt >= Mk) = v transposed.  Returns (B, Mqp, C).  ``q_count`` (B,) int32 on the device: only the first
     q_count[b] query rows of sample b are meaningful (compact_queries); the other rows of the result are undefined.
     ``k_fold`` = (k_count (B,) int32, k_bias (B, >= Mk) uint32 pairs) from fold_keys: k / vt hold a duplicate-free key
-    list, only the first k_count[b] entries are keys, each standing for 2^bias identical ones (head dims 8 and 40)."""
+    list, only the first k_count[b] entries are keys, each standing for 2^bias identical ones (head dims 8 and 40).
+    ``share_groups`` > 1 (plain launches only): the probabilities of the first B / share_groups samples serve every group
+    (pnp_utils.py:57-67)."""
+    if share_groups != 1 and (q_count is not None or k_fold is not None):
+        raise RuntimeError("attention_kv: shared probabilities go with the plain launch only")
     B, Mqp, C = q.shape
     Mkp = k.shape[1]
     d = C // heads
@@ -630,8 +635,8 @@ def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
                "vtm_attention_kv_bounded")
         return out
     _check(lib().vtm_attention_kv(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(), vt.stride(1),
-                                  out.data_ptr(), C, dtype_code(q), B, heads, Mq, Mqp, Mk, Mkp, d, float(scale), 1,
-                                  _ptr(ws), nb, _stream()), "vtm_attention_kv")
+                                  out.data_ptr(), C, dtype_code(q), B, heads, Mq, Mqp, Mk, Mkp, d, float(scale),
+                                  int(share_groups), _ptr(ws), nb, _stream()), "vtm_attention_kv")
     return out
 
 

@@ -26,108 +26,15 @@
 //   * d = 40 builds O^T from 16-row blocks (v_mfma_f32_16x16x32: 48 rows instead of 64, a quarter of the
 //     PV matrix work gone); P^T moves from the 32-query accumulator layout to the two 16-query B operands
 //     with v_permlane16_swap -- 8 swaps per tile, still no LDS round trip (PV16 below).
-#include "common.h"
+#include "attention_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
-
-// waves per workgroup by head dim (each wave owns 32 queries; all waves share the K / V^T tiles): more waves
-// amortise the tile staging, bounded by the register budget of the wider heads
-constexpr int waves_for(int D) { return D <= 48 ? 8 : D <= 96 ? 16 : 4; }
-constexpr int QW = 32;           // queries per wave
-constexpr int KV = 64;           // keys per tile
-constexpr int VT_STRIDE = KV + 8;  // 72 elements = 144 B: 16-byte aligned rows, conflict-free ds_read_b128 over 32 rows
-constexpr float DEFER_THR = 8.0f;  // log2 units
-
-// PV16: O^T is built from 16-row blocks (v_mfma_f32_16x16x32) instead of 32-row blocks when that needs fewer
-// matrix-pipe cycles: d = 40 -> 48 rows (the denominator row included) instead of 64, a quarter of the PV work.
-// P^T leaves the QK^T accumulators with one query per lane & 31; two v_permlane16_swap per register pair turn
-// the fragments of two 16-key steps into the B operands (query = lane & 15) of the two 16-query halves.
-constexpr bool pv16_for(int D) { return (D % 32) != 0 && (D + 16) / 16 * 16 < (D + 31) / 32 * 32; }
-constexpr int vrows_for(int D) { return pv16_for(D) ? (D + 16) / 16 * 16 : (D + 31) / 32 * 32; }   // V^T tile rows
-// per-thread record a key-split workgroup leaves for attention_combine_kernel: accumulators, running max
-// (one per accumulator group), denominator
-constexpr int acc_floats(int D) { return pv16_for(D) ? (D + 16) / 16 * 8 : (D + 31) / 32 * 16; }
-constexpr int max_floats(int D) { return pv16_for(D) ? 2 : 1; }
-constexpr int rec_floats(int D) { return acc_floats(D) + max_floats(D) + 1; }
-
-template <typename T> struct Frag;
-template <> struct Frag<__half> {
-    using vec = h16x8;
-    using elem = _Float16;
-    __device__ static f32x16 mfma(vec a, vec b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-    __device__ static f32x4 mfma16(vec a, vec b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-    }
-    static constexpr uint32_t BITS_256 = 0x5C00u;   // 256.0
-    __device__ static uint32_t pmax3(uint32_t a, uint32_t b, uint32_t c) {   // packed maximum of 3 x 2 values
-        uint32_t d;
-        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-        return d;
-    }
-    __device__ static void pack8(vec &dst, const float (&p)[8]) {
-        // round-to-nearest (v_cvt_pk_f16_f32): a truncating pack would bias the numerator against the fp32
-        // denominator of the head dims without a spare O^T row
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dst[i] = (_Float16)p[i];
-    }
-};
-template <> struct Frag<vtm_bf16> {
-    using vec = b16x8;
-    using elem = __bf16;
-    __device__ static f32x16 mfma(vec a, vec b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-    __device__ static f32x4 mfma16(vec a, vec b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    }
-    static constexpr uint32_t BITS_256 = 0x4380u;   // 256.0
-    __device__ static uint32_t pmax3(uint32_t a, uint32_t b, uint32_t c) {
-        // P >= 0: the bit patterns order like the values (inf and NaN on top), so an integer maximum will do
-        const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(u16x2, a),
-                                                                            __builtin_bit_cast(u16x2, b)),
-                                                  __builtin_bit_cast(u16x2, c));
-        return __builtin_bit_cast(uint32_t, m);
-    }
-    __device__ static void pack8(vec &dst, const float (&p)[8]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dst[i] = (__bf16)p[i];
-    }
-};
-
-// XCD-aware placement of the work items (query block, head, sample).  Workgroups are dispatched round-robin over the 8
-// XCDs in index order (observed, not a contract -- this is a speed choice, any placement gives the same result), so
-// position p runs on XCD p % 8.  All query blocks of one (sample, head) share its K / V^T stream: with `xcd_groups`
-// = (B * H) / 8 > 0 the (sample, head) pairs are dealt to the XCDs -- pair hb runs on XCD hb % 8 only -- so that a
-// K / V^T slice is fetched into ONE L2 instead of all eight (9x the algorithmic HBM-side traffic otherwise).
-__device__ __forceinline__ int64_t item_of(int64_t pos, int64_t nqb, int xcd_groups) {
-    if (xcd_groups == 0) return pos;
-    const int64_t xcd = pos & 7, slot = pos >> 3;
-    return (xcd + 8 * (slot / nqb)) * nqb + slot % nqb;
-}
-
-// zero the 16-bit elements j >= valid of a 16-byte piece (8 elements), on whole dwords so that the staging
-// registers stay plain 32-bit values (an element-wise view makes the compiler repack them after every load)
-__device__ __forceinline__ void mask_keys(uint4 &v, int valid) {
-    uint32_t *w = reinterpret_cast<uint32_t *>(&v);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t keep = (2 * j + 1 < valid) ? 0xffffffffu : (2 * j < valid) ? 0x0000ffffu : 0u;
-        w[j] &= keep;
-    }
-}
+using namespace vtm_att;
 
 // normalise and store one wave's O^T accumulators: row q = q0 + l31, channels dv*32 + (r & 3) + 8 (r >> 2) + 4 hi
 template <typename T, int D>
@@ -162,34 +69,6 @@ __device__ __forceinline__ void write_output(const f32x16 (&o)[(D + 31) / 32], f
                     *reinterpret_cast<uint2 *>(op + d0) = *reinterpret_cast<uint2 *>(w);
                 }
             }
-    }
-}
-
-// PV16 layout: o[dv][qh][e] = O^T row 16 dv + 4 (lane >> 4) + e of query q0 + 16 qh + (lane & 15)
-template <typename T, int D>
-__device__ __forceinline__ void write_output16(const f32x4 (&o)[(D + 16) / 16][2], T *__restrict__ out, int64_t ldo,
-                                               int64_t b, int64_t h, int64_t q0, int64_t M, int64_t Mp, int lane) {
-    using elem = typename Frag<T>::elem;
-    constexpr int DV16 = (D + 16) / 16;
-    constexpr int LB = D / 16, LG = (D % 16) / 4, LE = D % 4;   // where the denominator row D sits
-    const int l15 = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int qh = 0; qh < 2; ++qh) {
-        const float inv_l = 1.0f / __shfl(o[LB][qh][LE], 16 * LG + l15, 64);
-        const int64_t qi = q0 + 16 * qh + l15;
-        if (qi < M) {
-            T *op = out + (b * Mp + qi) * ldo + h * D;
-#pragma unroll
-            for (int dv = 0; dv < DV16; ++dv) {
-                const int d0 = dv * 16 + 4 * g;
-                if (d0 < D) {   // D % 4 == 0 -> the 4 channels are all valid
-                    elem w[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = (elem)(o[dv][qh][e] * inv_l);
-                    *reinterpret_cast<uint2 *>(op + d0) = *reinterpret_cast<uint2 *>(w);
-                }
-            }
-        }
     }
 }
 
@@ -755,13 +634,6 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
 // work items of that last round are therefore split along the key axis into `nsplit` shorter workgroups that fill
 // the chip -- in the SAME launch, behind the whole ones, so they start as the slots of the last whole round free
 // up -- and merged by attention_combine_kernel.
-struct TailPlan {
-    int64_t nqb, total, full;   // query blocks per (sample, head), all workgroups, workgroups in whole rounds
-    int nsplit;                 // splits of each remaining work item (1 = none)
-    size_t ws_bytes;
-    bool split_all;             // every item is split (launches with a device-side query bound)
-};
-
 // `bounded`: the launch carries a device-side query count (vtm_attention_kv_bounded: compacted live queries).  How many
 // of its workgroups do real work is not known when it is launched -- the cfg-2 top block launches 2 176 for ~1 800 live
 // ones, 3.5 rounds of 512 that cost 4 -- so the round structure cannot be planned.  It is made finer instead: EVERY
@@ -848,7 +720,8 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
                        p.split_all ? rem : (int64_t)0, k_count, k_bias, ldkb);
     // (few items: their accumulator groups are shared out, attention_combine_parts_kernel)
     bool parts = !pv16_for(D) && rem * 4 <= vtm::device_cus() && acc_floats(D) % 8 == 0;
-    if (getenv("VTM_DEBUG_COMBINE_PARTS")) parts = false;   // A/B hook
+    static const bool no_parts = getenv("VTM_DEBUG_COMBINE_PARTS") != nullptr;   // A/B hook, read once per process
+    if (no_parts) parts = false;
     if (p.nsplit > 1) {
         if constexpr (!pv16_for(D)) {
             if (parts)
@@ -861,6 +734,41 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
                                (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups, q_count);
     }
     return vtm::launch_status("vtm_attention");
+}
+
+// Which d = 40 launches go to the wide-tile kernel of attention16.hip, and in which shape (round 6).  VTM_ATT16=0 keeps
+// everything on attention_kernel; VTM_ATT16_NQ / VTM_ATT16_WAVES are A/B hooks for the plain (one value group) shape.  Read
+// once per process.  Both kernels compute the same sums in the same per-tile order for a query (the split plans differ),
+// so results agree to the tolerance of the key-split combine, not bit for bit.
+struct Policy16 {
+    bool on;
+    int nq, waves;
+};
+const Policy16 &policy16() {
+    static const Policy16 p = [] {
+        Policy16 v{true, 2, 8};
+        if (const char *e = getenv("VTM_ATT16")) v.on = atoi(e) != 0;
+        if (const char *e = getenv("VTM_ATT16_NQ")) v.nq = atoi(e) == 1 ? 1 : 2;
+        if (const char *e = getenv("VTM_ATT16_WAVES")) v.waves = atoi(e) == 4 ? 4 : 8;
+        if (v.nq == 1) v.waves = 8;
+        return v;
+    }();
+    return p;
+}
+// -> true and the shape when this launch is the wide kernel's
+bool shape16_for(int64_t d, int share_groups, bool fold, Shape16 *sh) {
+    const Policy16 &p = policy16();
+    if (!p.on || d != 40) return false;
+    if (share_groups == 1) {
+        if (p.nq == 1) return false;               // (one sub-tile, one group IS attention_kernel)
+        *sh = Shape16{p.nq, 1, p.waves};
+        return true;
+    }
+    if (!fold && (share_groups == 2 || share_groups == 3)) {   // shared probabilities: P once, one PV per sample
+        *sh = Shape16{1, share_groups, 8};
+        return true;
+    }
+    return false;
 }
 
 template <typename T>
@@ -884,10 +792,22 @@ int dispatch(int64_t d, const void *q, int64_t ldq, const void *k, int64_t ldk, 
 
 }  // namespace
 
+// (d = 40: the caller does not say how the launch will share its probabilities -- the largest plan any shape could choose)
+static size_t ws16_max(int64_t B, int64_t h, int64_t Mq, int64_t Mk, bool bounded) {
+    size_t n = 0;
+    Shape16 sh;
+    for (int sg = 1; sg <= 3; ++sg)
+        if (B % sg == 0 && shape16_for(40, sg, false, &sh)) {
+            const size_t w = ws_bytes16(sh, sh.ng > 1 ? B / sg : B, h, Mq, Mk, bounded && sg == 1);
+            n = w > n ? w : n;
+        }
+    return n;
+}
+
 VTM_EXPORT size_t vtm_attention_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64_t Mk, int64_t d) {
     if (B <= 0 || h <= 0 || Mq <= 0 || Mk <= 0) return 0;
     switch (d) {
-        case 40: return plan_tail<40>(B, h, Mq, Mk).ws_bytes;
+        case 40: return std::max(plan_tail<40>(B, h, Mq, Mk).ws_bytes, ws16_max(B, h, Mq, Mk, false));
         case 64: return plan_tail<64>(B, h, Mq, Mk).ws_bytes;
         case 80: return plan_tail<80>(B, h, Mq, Mk).ws_bytes;
         case 160: return plan_tail<160>(B, h, Mq, Mk).ws_bytes;
@@ -903,7 +823,7 @@ VTM_EXPORT size_t vtm_attention_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64
 VTM_EXPORT size_t vtm_attention_kv_bounded_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64_t Mk, int64_t d) {
     if (B <= 0 || h <= 0 || Mq <= 0 || Mk <= 0) return 0;
     switch (d) {
-        case 40: return plan_tail<40>(B, h, Mq, Mk, true).ws_bytes;
+        case 40: return std::max(plan_tail<40>(B, h, Mq, Mk, true).ws_bytes, ws16_max(B, h, Mq, Mk, true));
         case 64: return plan_tail<64>(B, h, Mq, Mk, true).ws_bytes;
         case 80: return plan_tail<80>(B, h, Mq, Mk, true).ws_bytes;
         case 160: return plan_tail<160>(B, h, Mq, Mk, true).ws_bytes;
@@ -929,6 +849,15 @@ static int attention_any(const void *q, int64_t ldq, const void *k, int64_t ldk,
     VTM_REQUIRE((Mkp * ldk + d) * 2 < (1ll << 31) && (d * ldvt + Mkp) * 2 < (1ll << 31),
                 "vtm_attention: a (sample, head) slice of K or V^T must stay below 2 GiB");
     hipStream_t s = vtm::as_stream(stream);
+    Shape16 sh;
+    if ((dtype == VTM_F16 || dtype == VTM_BF16) && shape16_for(d, share_groups, false, &sh)) {
+        // the value groups of one (source sample, head) share a buffer descriptor: the sample stride rides in the offset
+        if (sh.ng == 1 || (sh.ng * (B / share_groups) * h * d * ldvt) * 2 < (1ll << 31)) {
+            const Args16 a{q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws, ws_bytes,
+                           q_count, s, false, nullptr, nullptr, 0};
+            return attention16(a, sh);
+        }
+    }
     if (dtype == VTM_F16)
         return dispatch<__half>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws,
                                 ws_bytes, q_count, s);
@@ -968,6 +897,12 @@ VTM_EXPORT int vtm_attention_kv_folded(const void *q, int64_t ldq, const void *k
     VTM_REQUIRE((Mkp * ldk + d) * 2 < (1ll << 31) && (d * ldvt + Mkp) * 2 < (1ll << 31) && Mkp * 4 < (1ll << 31),
                 "vtm_attention_kv_folded: a (sample, head) slice of K or V^T must stay below 2 GiB");
     hipStream_t s = vtm::as_stream(stream);
+    Shape16 sh;
+    if ((dtype == VTM_F16 || dtype == VTM_BF16) && shape16_for(d, 1, true, &sh)) {
+        const Args16 a{q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, Mq, Mqp, Mk, Mkp, scale, 1, ws, ws_bytes,
+                       q_count, s, true, k_count, k_bias, ldkb};
+        return attention16(a, sh);
+    }
 #define VTM_FOLDED(T, D) launch<T, D, true>(q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, 1, ws, ws_bytes, q_count, s, \
                                             k_count, k_bias, ldkb)
     if (dtype == VTM_F16) return d == 40 ? VTM_FOLDED(__half, 40) : VTM_FOLDED(__half, 8);

@@ -523,9 +523,10 @@ template <typename T>
 int launch(const void *x0, int64_t P0, const void *x1, int64_t P1, int64_t B, int64_t K, const int32_t *rows,
            int64_t rows_ld, const int32_t *rows2, int64_t n, const void *W, const void *bias, int64_t N, void *out,
            int64_t ldo, int64_t obs, int transposed, hipStream_t s) {
+    static const bool force_tiled = getenv("VTM_LINEAR_TILED") != nullptr;   // A/B hook, read once per process
     // K = 320 with whole 160-channel halves and 16-byte-aligned output rows: the weight-stationary kernel
     if (K == WS_K && N % WS_TN == 0 && (ldo & 7) == 0 && (obs & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
-        vtm::cdiv(n, 32) * B * (N / WS_TN) < (1ll << 30) && !getenv("VTM_LINEAR_TILED")) {
+        vtm::cdiv(n, 32) * B * (N / WS_TN) < (1ll << 30) && !force_tiled) {
         return transposed ? launch_ws<T, true>(x0, P0, x1, P1, B, rows, rows_ld, rows2, n, W, bias, N, out, ldo, obs, s)
                           : launch_ws<T, false>(x0, P0, x1, P1, B, rows, rows_ld, rows2, n, W, bias, N, out, ldo, obs, s);
     }

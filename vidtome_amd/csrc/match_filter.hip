@@ -945,7 +945,11 @@ __global__ __launch_bounds__(256) void seed_kernel(const T *__restrict__ x0, int
         // C = 1280) so that it is provably <= the pair's filter score + EPS.
         const float s0 = (acc / na[b * Ns + i]) / nb[b * Nd + j];
         const float s = s0 - 1e-4f;
-        if (s == s && __builtin_fabsf(s) <= 1.5f && !dry) {  // (a row without a usable norm publishes nothing)
+        // (round 6) ... and nothing is published when the dot product itself left the normal fp32 range: norms near 2^-100 are
+        // still "usable", but the products of such rows underflow, acc arrives as 0 or as a denormal with no relative
+        // accuracy, and s0 = 0 would be published as a CERTIFIED bound above a row whose real scores are all negative
+        const bool acc_ok = __builtin_fabsf(acc) >= 0x1p-100f || (na[b * Ns + i] >= 0x1p-40f && nb[b * Nd + j] >= 0x1p-40f);
+        if (s == s && __builtin_fabsf(s) <= 1.5f && acc_ok && !dry) {  // (a row without a usable norm publishes nothing)
             atomicMax(&amax[align ? i : b * Ns + i], orderable(s));
             // ... and, kept apart from the filter's running maximum (which an overflowing row overwrites with +inf), a
             // CERTIFIED lower bound of the row's exact maximum for exact_rows_kernel's tile pruning: this pair's canonical
@@ -1480,6 +1484,32 @@ Layout make_layout(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
     return L;
 }
 
+// Tuning / A-B hooks of the host side, read from the environment ONCE per process (they were getenv calls on
+// every matcher call).  Every one of them is result-preserving: they move launch shapes and pruning depths, never what
+// `best` holds.  (A hook that changes results belongs behind a VTM_EXP_* build switch of ablate.h, where it sets a bit of
+// VTM_ABLATIONS and the Python binding refuses to load the library.)
+struct DebugEnv {
+    int kp5, kp, nsplit;              // -1 = unset
+    bool seed_dry, nsplit_r4, no_xprune;
+};
+const DebugEnv &debug_env() {
+    static const DebugEnv e = [] {
+        auto num = [](const char *name) {
+            const char *v = getenv(name);
+            return v ? atoi(v) : -1;
+        };
+        DebugEnv d;
+        d.kp5 = num("VTM_DEBUG_KP5");
+        d.kp = num("VTM_DEBUG_KP");
+        d.nsplit = num("VTM_DEBUG_NSPLIT");
+        d.seed_dry = getenv("VTM_DEBUG_SEED_DRY") != nullptr;
+        d.nsplit_r4 = getenv("VTM_DEBUG_NSPLIT_R4") != nullptr;
+        d.no_xprune = getenv("VTM_DEBUG_NOXPRUNE") != nullptr;
+        return d;
+    }();
+    return e;
+}
+
 }  // namespace
 
 VTM_EXPORT size_t vtm_match_filtered_ws_bytes(int64_t B, int64_t C, int64_t Ns, int64_t Nd, int align) {
@@ -1522,14 +1552,9 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
     // builds (their lo products are not covered by the hi rest norms)
     const int KT = (int)(L.C64 / FBK);
     int KP = (VTM_FILTER_PRODUCTS == 1 && KT >= 4) ? (2 * KT + 2) / 5 : 0;   // 40 % depth (profiles/r04_kp_sweep.txt)
-    if (const char *dbg5 = getenv("VTM_DEBUG_KP5")) {    // tuning hook for the C = 320 levels alone (KT = 5)
-        const int v = atoi(dbg5);
-        if (VTM_FILTER_PRODUCTS == 1 && KT == 5 && v >= 0 && v < KT) KP = v;
-    }
-    if (const char *dbg = getenv("VTM_DEBUG_KP")) {      // tuning hook: 0 = off, else the step after which blocks are tested
-        const int v = atoi(dbg);
-        if (VTM_FILTER_PRODUCTS == 1 && v >= 0 && v < KT) KP = v;
-    }
+    const DebugEnv &dbg = debug_env();   // tuning / A-B hooks, read ONCE per process (all of them leave the results unchanged)
+    if (VTM_FILTER_PRODUCTS == 1 && KT == 5 && dbg.kp5 >= 0 && dbg.kp5 < KT) KP = dbg.kp5;   // the C = 320 levels alone (KT = 5)
+    if (VTM_FILTER_PRODUCTS == 1 && dbg.kp >= 0 && dbg.kp < KT) KP = dbg.kp;                 // 0 = off, else the step after which blocks are tested
     const bool prune = KP > 0 && KP < KT;
     // (the per-tile values are written for every call: refine_kernel reads the "row without a usable norm" mark from them)
     float *rest_a = (float *)(w + L.rest_a), *rest_bt = (float *)(w + L.rest_bt);
@@ -1565,7 +1590,7 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
     }
 
     if (seed_N > 0) {   // starting maxima from same-position guesses (a kernel boundary behind prep_operand: norms, cleared amax)
-        const int dry = getenv("VTM_DEBUG_SEED_DRY") != nullptr;   // A/B hook: the seeds are computed and thrown away
+        const int dry = dbg.seed_dry;   // A/B hook: the seeds are computed and thrown away
         unsigned int *seedlb = (unsigned int *)(w + L.seedlb);
         const float lb_margin = (4.0f * (float)C + 32.0f) * 0x1p-24f + 1e-6f;   // see seed_kernel
         const dim3 grid((unsigned)vtm::cdiv(B * Ns * 8, 256)), block(256);
@@ -1601,7 +1626,7 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
             return patches_per_xcd * patch_tiles * (int)vtm::cdiv(nd_tiles, tps);
         };
         int nsplit;
-        if (getenv("VTM_DEBUG_NSPLIT_R4")) {
+        if (dbg.nsplit_r4) {
             // rounds 1-4: enough workgroups to fill the chip, >= 4 dst tiles each, at most 8 (every split contributes >= 1
             // candidate per row), 8 whenever the dst axis is long enough, 7 or 6 when that saves a round (A/B hook)
             int64_t want = vtm::cdiv(1536, (int64_t)ns_tiles * B);
@@ -1642,18 +1667,12 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
                 }
             }
         }
-        if (const char *dbg = getenv("VTM_DEBUG_NSPLIT")) {   // tuning hook (tools/sweep_nsplit.py)
-            const int v = atoi(dbg);
-            if (v >= 1 && v <= 16 && v <= nd_tiles) nsplit = v;
-        }
+        if (dbg.nsplit >= 1 && dbg.nsplit <= 16 && dbg.nsplit <= nd_tiles) nsplit = dbg.nsplit;   // tuning hook (tools/sweep_nsplit.py)
         const int tiles_per_split = (int)vtm::cdiv(nd_tiles, nsplit);
         nsplit = (int)vtm::cdiv(nd_tiles, tiles_per_split);
         const int64_t grid = (int64_t)8 * vtm::cdiv(ngroups, 8) * patch_tiles * nsplit;
-        int64_t c_run = L.C64;
-        if (const char *dbg = getenv("VTM_DEBUG_KSTEPS")) {   // timing hook (WRONG results): only the first v 64-channel steps
-            const int v = atoi(dbg);
-            if (v >= 1 && (int64_t)v * FBK < L.C64) c_run = (int64_t)v * FBK;
-        }
+        const int64_t c_run = L.C64;   // (rounds 4-5 had a timing hook here that cut the channel loop short -- WRONG results from a
+                                       // shipped library by an environment variable: removed in round 6)
         // scout + range plan (see filter_kernel): needs the pruning test, the seeds (without a starting maximum nothing is
         // dead) and dst frames of whole tiles -- one split per dst frame, so that a span is the live tiles of ONE frame
         const int map_words = (nd_tiles + 31) / 32;
@@ -1699,7 +1718,7 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
         xsplit = (int)vtm::cdiv(xd_tiles, xtps);
         const dim3 xgrid((unsigned)((XS == 128 ? 2 : 1) * vtm::device_cus()));
         // exact_rows_kernel's tile pruning: the rest norms prep_operand wrote for the filter's cut, in 32-channel steps
-        const int KX = getenv("VTM_DEBUG_NOXPRUNE") ? 0 : (int)(cut / XK);
+        const int KX = dbg.no_xprune ? 0 : (int)(cut / XK);
 #define VTM_XPRUNE_ARGS (const float *)rest_a, (const float *)rest_bt, KX, L.Ns_pad, L.Nd_pad / FBD, (const unsigned int *)(w + L.seedlb), \
                         flags + 6, src_order, dst_order
         switch (dtype) {

@@ -17,15 +17,13 @@ reference also makes on its generator (merge.py:57-58, patch.py:62).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, Optional, Tuple
 
 import torch
 
 from . import _lib
-
-
-import os
 
 # "filtered" (default) or "exact": both produce bit-identical packed results (tests/test_gpu_parity.py)
 MATCH_MODE = os.environ.get("VIDTOME_MATCH", "filtered")
@@ -83,14 +81,27 @@ class MatchPlanner:
     by itself costs a 40 us sort and saves 12-26 % of a top global call (more blocks die) but nothing at level 2.  So
     `order_alone` says what the level does while the plan is off: keep the ordering (global level) or go back to the reference's
     row order (level 2); and a level in which NOTHING died at the scout's test (uncorrelated tokens) drops the ordering too.
-    Results never depend on any of this."""
+    Results never depend on any of this.
 
-    HIGH, LOW, COOL = 0.09, 0.07, 256
+    Two pinned buffers, one per KIND of reading (round 6): the scout + range calls copy into `buf`, the one
+    one-launch call that is asked for the filter's own counters (the order probe) into `probe_buf` -- the 32-byte copy of
+    an earlier scout + range call that lands late can then never be read as the probe's answer.  `__del__` waits for the
+    copies still in flight before the pinned memory goes back to torch's host allocator."""
+
+    # COOL (round 6: 32, was 256): how long a level stays on the one-launch plan before the scout is tried again.  It bounds
+    # BOTH costs of being wrong (tests/test_gpu_parity.py::test_planner_cost_is_bounded_on_alternating_regimes): on data the plan
+    # never pays for, one exploring call (+40 % of ONE call) per COOL + 1 calls = +1.2 % of the level; on a clip that turns
+    # plan-friendly again, at most COOL calls at the one-launch price (a shot of 300 calls: < 3 % of the level against a
+    # per-call oracle; 256 lost 11 % there).  Fast alternation (every 2 - 8 calls) cannot be followed from the previous call's
+    # counters at all; the planner then costs at most the exploring calls against the better FIXED plan.
+    HIGH, LOW, COOL = 0.09, 0.07, 32
 
     def __init__(self, order_alone: bool = False):
         self.mode = _lib.MATCH_SCOUT_RANGE
         self.buf = torch.zeros(8, dtype=torch.int32).pin_memory()
         self.view = self.buf.numpy()
+        self.probe_buf = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.probe_view = self.probe_buf.numpy()
         self.cool = 0
         self.switches = 0
         self.order_alone = order_alone
@@ -120,13 +131,14 @@ class MatchPlanner:
                     # running maxima grow along the dst axis, the scout only has the seeds: a drifting smooth field leaves
                     # every block alive in the scout and 29 % in the filter) -- asked of the first one-launch call's counters
                     self.order_off, self.order_probe = False, self.order_alone
+                    self.probe_view[4] = 0
                 elif self.shallow_ban <= 0 and in_spans < self.LOW * tested:      # (some margin: a level at the edge of the
                     self.shallow = True                                           # plan is not the place for a cheaper scout)
             if self.shallow_ban > 0:
                 self.shallow_ban -= 1
         else:
-            if self.order_probe and int(self.view[4]) > 0:
-                self.order_off = int(self.view[5]) > 0.9 * int(self.view[4])
+            if self.order_probe and int(self.probe_view[4]) > 0:
+                self.order_off = int(self.probe_view[5]) > 0.9 * int(self.probe_view[4])
                 self.order_probe = False
             self.cool -= 1
             if self.cool <= 0:
@@ -135,7 +147,16 @@ class MatchPlanner:
         if self.mode == _lib.MATCH_SCOUT_RANGE:
             self.issued_shallow = self.shallow
             return self.mode, self.buf, True, (1 if self.shallow else 0)
-        return self.mode, (self.buf if self.order_probe else None), self.order_alone and not self.order_off, 0
+        return self.mode, (self.probe_buf if self.order_probe else None), self.order_alone and not self.order_off, 0
+
+    def __del__(self):
+        # an asynchronous counter copy may still be in flight towards the pinned buffers: wait for the device
+        # before they are released (garbage collection of a block, bench.py dropping a block's planners)
+        try:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+        except Exception:          # interpreter shutdown: the process' memory goes with it
+            pass
 
 
 # Levels 2 / global meet their rows in position order (vtm_position_order + vtm_match_filtered_ordered: same bits, fewer live
