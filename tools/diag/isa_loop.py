@@ -13,7 +13,7 @@ def short(l):
         return 'M' if '32x32' in op else 'm'
     for pre, ch in (('v_exp', 'E'), ('v_cvt_pk', 'c'), ('v_pk_max', 'x'), ('v_permlane', 'w'), ('ds_read', 'L'), ('ds_load', 'L'),
                     ('ds_write', 'W'), ('ds_store', 'W'), ('buffer_load', 'G'), ('global_load', 'G'), ('s_waitcnt', '|'),
-                    ('s_barrier', 'B'), ('s_cbranch', 'J'), ('s_branch', 'J'), ('s_nop', 'n')):
+                    ('s_barrier', 'B'), ('scratch_load', '<'), ('scratch_store', '>'), ('s_cbranch', 'J'), ('s_branch', 'J'), ('s_nop', 'n')):
         if op.startswith(pre):
             return ch
     if re.match(r'^\.?LBB', l):
@@ -28,7 +28,7 @@ def main():
     if not m:
         sys.exit("kernel not found")
     i = m.start()
-    body = s[i:s.index('s_endpgm', i)]
+    body = s[i:s.index('.Lfunc_end', i)]
     lines = [l.split(';')[0].strip() for l in body.split('\n')]
     lines = [l for l in lines if l and not l.startswith(('.s', '.p', '.t', '.g', '.w'))]
     labels = {l[:-1]: n for n, l in enumerate(lines) if re.match(r'^\.?LBB\d+_\d+:$', l)}

@@ -194,6 +194,155 @@ __global__ __launch_bounds__(NT) void tile_model(float *out, int iters, float se
     if (cyc && blockIdx.x == 0 && threadIdx.x == 0) *cyc = clock64() - c_begin;
 }
 
+// Round 6: the 64-queries-per-wave tile (two 32-query sub-tiles A, B sharing the K / V^T fragments) as a SKEWED in-wave
+// pipeline -- every matrix phase has independent VALU work of the same wave in its basic block:
+//   phase 1:  S_B = K Q_B^T (6 MFMA) + PV of B's PREVIOUS tile (12 MFMA)   beside   exps / pack / check / swaps of A
+//   phase 2:  PV of A (12 MFMA) + S_A of the NEXT tile (6 MFMA)            beside   exps / pack / check / swaps of B
+// SGB = 0: plain program order inside a phase (compiler's schedule); SGB = 1: one MFMA, then 5 (32x32) / 3 (16x16) VALU
+// (sched_group_barrier).  Per iteration = TWO tile-waves of the other modes.
+template <int SGB, int NT>
+__global__ __launch_bounds__(NT, 2) void tile_model2(float *out, int iters, float seed, unsigned long long *cyc) {
+    const unsigned long long c_begin = clock64();
+    h16x8 q[2][3], kf[2][3], vf[2][3];
+    for (int i = 0; i < 3; ++i)
+        for (int e = 0; e < 8; ++e)
+            for (int b = 0; b < 2; ++b) {
+                q[b][i][e] = (_Float16)(seed * 0.01f + 0.001f * (e + 3 * b));
+                kf[b][i][e] = (_Float16)(seed * 0.02f + 0.001f * (e + b));
+                vf[b][i][e] = (_Float16)(seed * 0.03f + 0.002f * (e + b));
+            }
+    f32x4 o[2][3][2];
+    for (int a = 0; a < 2; ++a)
+        for (int d = 0; d < 3; ++d)
+            for (int h = 0; h < 2; ++h)
+                for (int e = 0; e < 4; ++e) o[a][d][h][e] = 0.0f;
+    uint32_t flag = 0;
+    f32x16 sA[2], sB[2];
+    for (int kb = 0; kb < 2; ++kb)
+        for (int r = 0; r < 16; ++r) sA[kb][r] = seed, sB[kb][r] = seed;
+    h16x8 pB[2][2];     // swapped P^T operands of B's previous tile: [k-step][query half]
+    for (int ks = 0; ks < 2; ++ks)
+        for (int h = 0; h < 2; ++h) pB[ks][h] = q[0][ks];
+    auto softmax = [&](const f32x16 (&s)[2], h16x8 (&pout)[2][2]) {      // exps, pack, check, swaps
+        h16x8 pf[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[st][e] = (_Float16)__builtin_amdgcn_exp2f(s[st >> 1][8 * (st & 1) + e]);
+        uint32_t pw[16];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const u32x4 w = __builtin_bit_cast(u32x4, pf[st]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pw[4 * st + j] = w[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) pw[j] = pmax3(pw[3 * j], pw[3 * j + 1], pw[3 * j + 2]);
+        const uint32_t pr = pmax3(pmax3(pw[0], pw[1], pw[2]), pmax3(pw[3], pw[4], pw[15]), pw[15]);
+        flag |= (max(pr >> 16, pr & 0xffffu) > 0x5C00u) ? 1u : 0u;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 x = __builtin_bit_cast(u32x4, pf[2 * ks]), y = __builtin_bit_cast(u32x4, pf[2 * ks + 1]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const auto r = __builtin_amdgcn_permlane16_swap(x[w], y[w], false, false);
+                x[w] = r[0];
+                y[w] = r[1];
+            }
+            pout[ks][0] = __builtin_bit_cast(h16x8, x);
+            pout[ks][1] = __builtin_bit_cast(h16x8, y);
+        }
+    };
+    auto qk = [&](f32x16 (&s)[2], int sub) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], q[sub][ks], s[kb], 0, 0, 0);
+        }
+    };
+    auto pv = [&](int sub, const h16x8 (&p)[2][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int dv = 0; dv < 3; ++dv) {
+                o[sub][dv][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[ks][dv], p[ks][0], o[sub][dv][0], 0, 0, 0);
+                o[sub][dv][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[ks][dv], p[ks][1], o[sub][dv][1], 0, 0, 0);
+            }
+    };
+    auto interleave = [&]() {
+        if constexpr (SGB == 1) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+            }
+        }
+    };
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(kf[0][0]), "+v"(kf[1][0]));
+        h16x8 pA[2][2];
+        // ---- phase 1
+        __builtin_amdgcn_sched_barrier(0);
+        qk(sB, 1);
+        pv(1, pB);
+        softmax(sA, pA);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 2
+        asm volatile("" : "+v"(kf[0][1]), "+v"(kf[1][1]));     // (the next tile's K fragments)
+        pv(0, pA);
+        qk(sA, 0);
+        softmax(sB, pB);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float acc = (float)flag;
+    for (int a = 0; a < 2; ++a)
+        for (int d = 0; d < 3; ++d)
+            for (int h = 0; h < 2; ++h)
+                for (int e = 0; e < 4; ++e) acc += o[a][d][h][e];
+    for (int kb = 0; kb < 2; ++kb) acc += sA[kb][0] + sB[kb][0];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (cyc && blockIdx.x == 0 && threadIdx.x == 0) *cyc = clock64() - c_begin;
+}
+
+template <int SGB, int NT>
+void run2(const char *name, int wgs_per_cu) {
+    const int cus = 256, iters = 2000;
+    float *out;
+    (void)hipMalloc(&out, sizeof(float) * cus * wgs_per_cu * NT);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    unsigned long long *cyc;
+    (void)hipMalloc(&cyc, sizeof(*cyc));
+    hipLaunchKernelGGL((tile_model2<SGB, NT>), dim3(cus * wgs_per_cu), dim3(NT), 0, 0, out, 10, 1.0f, (unsigned long long *)nullptr);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((tile_model2<SGB, NT>), dim3(cus * wgs_per_cu), dim3(NT), 0, 0, out, iters, 1.0f, cyc);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const int wps = NT / 256 * wgs_per_cu;
+    const double ns = ms * 1e6 / ((double)iters * 2 * wps);   // per 32-query tile-wave, like the other modes
+    unsigned long long hc = 0;
+    (void)hipMemcpy(&hc, cyc, sizeof(hc), hipMemcpyDeviceToHost);
+    printf("%-48s %d waves/SIMD: %.3f ms -> %.1f ns per tile-wave per SIMD (= %.0f cycles @2.4 GHz; matrix pipe alone: 384)", name,
+           wps, ms, ns, ns * 2.4);
+    if (wps == 1) printf("  [measured: %.0f shader cycles per tile-wave, clock %.2f GHz]", (double)hc / iters / 2, (double)hc / (ms * 1e6));
+    printf("\n");
+    (void)hipFree(out);
+    (void)hipFree(cyc);
+}
+
 template <int MODE, int NT>
 void run(const char *name, int wgs_per_cu) {
     const int cus = 256, iters = 4000;
@@ -269,6 +418,10 @@ int main() {
         run<7, 512>("polynomial exponent, 6 instr / pair (no v_exp)", w);
         run<8, 512>("half v_exp, half polynomial (7 instr / pair)", w);
     }
+    run2<0, 256>("64 q / wave, skewed pipeline, compiler order", 1);
+    run2<1, 256>("64 q / wave, skewed pipeline, MFMA : VALU groups", 1);
+    run2<0, 512>("64 q / wave, skewed pipeline, compiler order", 1);
+    run2<1, 512>("64 q / wave, skewed pipeline, MFMA : VALU groups", 1);
     run<0, 768>("kernel mix, 12-wave workgroup", 1);
     run<5, 768>("software-pipelined, 12-wave workgroup", 1);
     run<0, 256>("kernel mix, 4-wave workgroup", 1);

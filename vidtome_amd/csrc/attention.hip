@@ -741,13 +741,14 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
 // once per process.  Both kernels compute the same sums in the same per-tile order for a query (the split plans differ),
 // so results agree to the tolerance of the key-split combine, not bit for bit.
 struct Policy16 {
-    bool on;
+    bool on, skew;
     int nq, waves;
 };
 const Policy16 &policy16() {
     static const Policy16 p = [] {
-        Policy16 v{true, 2, 8};
+        Policy16 v{true, true, 2, 8};
         if (const char *e = getenv("VTM_ATT16")) v.on = atoi(e) != 0;
+        if (const char *e = getenv("VTM_ATT16_SKEW")) v.skew = atoi(e) != 0;
         if (const char *e = getenv("VTM_ATT16_NQ")) v.nq = atoi(e) == 1 ? 1 : 2;
         if (const char *e = getenv("VTM_ATT16_WAVES")) v.waves = atoi(e) == 4 ? 4 : 8;
         if (v.nq == 1) v.waves = 8;
@@ -761,11 +762,11 @@ bool shape16_for(int64_t d, int share_groups, bool fold, Shape16 *sh) {
     if (!p.on || d != 40) return false;
     if (share_groups == 1) {
         if (p.nq == 1) return false;               // (one sub-tile, one group IS attention_kernel)
-        *sh = Shape16{p.nq, 1, p.waves};
+        *sh = Shape16{p.nq, 1, p.waves, p.skew};
         return true;
     }
     if (!fold && (share_groups == 2 || share_groups == 3)) {   // shared probabilities: P once, one PV per sample
-        *sh = Shape16{1, share_groups, 8};
+        *sh = Shape16{1, share_groups, 8, false};
         return true;
     }
     return false;

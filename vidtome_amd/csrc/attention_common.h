@@ -146,6 +146,7 @@ struct Args16 {
 };
 struct Shape16 {
     int nq, ng, waves;      // query sub-tiles per wave, value groups per wave, waves per workgroup
+    bool skew;              // nq = 2, ng = 1: the skewed in-wave pipeline (attention16s_kernel)
 };
 int wg_per_cu16(int nq, int ng, int waves);
 TailPlan plan_tail16(int64_t B_items, int64_t h, int64_t Mq, int64_t Mk, int64_t QB, int wg_per_cu, size_t item_rec_bytes,
