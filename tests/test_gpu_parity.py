@@ -1760,7 +1760,7 @@ def test_fold_keys_vs_numpy(L, shape):
 
 
 @pytest.mark.parametrize("dtype,d", [(torch.float16, 40), (torch.bfloat16, 40), (torch.float16, 8)])
-def test_attention_folded_keys_equal_the_duplicated_ones(L, oracle, dtype, d):
+def test_attention_folded_keys_equal_the_duplicated_ones(L, oracle, dtype, d, monkeypatch):
     """vtm_attention_kv_folded: m identical keys weigh like one key with + log2(m) on its score -- the folded launch (device-side
     key count, bias pair in the spare k-slots) against the oracle's attention over the sequence WITH the copies, and against
     the unfolded kernel on the same sequence; with and without a device-side query count, ragged last tile, split tails."""
@@ -1818,9 +1818,18 @@ def test_attention_folded_keys_equal_the_duplicated_ones(L, oracle, dtype, d):
     oq = L.attention_kv(qd, kf.to(DEV), vf.to(DEV).transpose(1, 2).contiguous(), h, Mq, Mu, scale, q_count=q_count,
                         k_fold=(k_count, bias.to(DEV)))
     of = L.attention_kv(qd, kf.to(DEV), vf.to(DEV).transpose(1, 2).contiguous(), h, Mq, Mu, scale, k_fold=(k_count, bias.to(DEV)))
+    # (round 6: a query-bounded d = 40 launch is planned on the device -- this small one is key-split to fill the chip, so
+    # the two launches sum the keys in different orders; with the bounded workspace withheld both take the same plan)
+    sc = max(1.0, float(of.float().abs().max()))
     for b in range(B):
         n = int(q_count[b])
-        assert torch.equal(oq[b, :n], of[b, :n])
+        assert (oq[b, :n].float() - of[b, :n].float()).abs().max() < tol * sc, b
+    monkeypatch.setattr(L, "SPLIT_ALL_BOUNDED", False)
+    oq0 = L.attention_kv(qd, kf.to(DEV), vf.to(DEV).transpose(1, 2).contiguous(), h, Mq, Mu, scale, q_count=q_count,
+                         k_fold=(k_count, bias.to(DEV)))
+    for b in range(B):
+        n = int(q_count[b])
+        assert torch.equal(oq0[b, :n], of[b, :n])
 
 
 def test_attention_folded_keys_under_the_split_plans(L):
@@ -2411,9 +2420,11 @@ def test_compact_queries_vs_torch(L, B, Ml, U, Nd):
         assert int(tmap[b].max()) < n
 
 
-def test_attention_bounded_equals_unbounded_prefix(L):
-    """vtm_attention_kv_bounded: rows below the per-sample count equal the plain launch's rows bit for bit (same
-    workgroups, same order); the launch covers counts inside the first block, mid-sequence and the full length."""
+def test_attention_bounded_equals_unbounded_prefix(L, monkeypatch):
+    """vtm_attention_kv_bounded: rows below the per-sample count equal the plain launch's rows -- bit for bit when both take
+    the same launch plan (the bounded workspace withheld), within the tolerance of another summation order when the
+    bounded launch is planned on the device from the counts (round 6: a geometric key-split tail); the launch covers counts
+    inside the first block, mid-sequence and the full length."""
     B, h, d, Mq, Mk = 3, 8, 40, 8448, 9000
     C = h * d
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -2422,6 +2433,11 @@ def test_attention_bounded_equals_unbounded_prefix(L):
     vt = torch.randn(B, C, (Mk + 7) // 8 * 8, generator=g, device=DEV, dtype=torch.float16)
     full = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5)
     count = torch.tensor([100, 5000, Mq], dtype=torch.int32, device=DEV)
+    got = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5, q_count=count)
+    scale = float(full.float().abs().max())
+    for b, n in enumerate(count.tolist()):
+        assert (got[b, :n].float() - full[b, :n].float()).abs().max() < 2e-3 * scale, b
+    monkeypatch.setattr(L, "SPLIT_ALL_BOUNDED", False)
     got = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5, q_count=count)
     for b, n in enumerate(count.tolist()):
         assert torch.equal(got[b, :n], full[b, :n]), b

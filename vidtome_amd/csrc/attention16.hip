@@ -18,6 +18,7 @@
 // Reference: the `self.attn1(...)` call at vidtome/patch.py:157-162 = `sa_forward`, utils/pnp_utils.py:47-95.
 #include "attention_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -29,15 +30,91 @@ using namespace vtm_att;
 // attention.hip (24 accumulators at d = 40, one running max per 16-query half, one unused denominator slot)
 template <int D> constexpr int rec16() { return (D + 16) / 16 * 8 + 2 + 1; }
 
+// ---- device-side launch plan for QUERY-BOUNDED launches (vtm_attention_kv_bounded: compacted live queries) ----
+// How many query blocks are live is a device value (q_count), so the host cannot cut the launch into whole rounds plus a
+// key-split tail the way plan_tail16 does for a known length; rounds 4-5 split EVERY item in two instead (finer rounds).
+// Measured in round 6 (profiles/r06_d_attention16_ab.txt): 912 live items on 256 slots are 3.56 rounds of work and took the
+// time of 4 (4.81 ms against 4.31).  One thread now plans on the device, in front of the launch, from the counts -- a
+// GEOMETRIC tail: workgroups are dispatched in index order as slots free up, so pieces that shrink towards the end of the
+// grid pack like longest-first list scheduling and the idle tail is one SMALLEST piece long:
+//   L live items (the longest sample's blocks x heads x samples), S slots;
+//   tier 0: the items of the whole rounds, L - L % S of them, one workgroup each;
+//   then, while items remain: the next tier takes S / n of them (or what is left), n = the smallest power of two >= 2 with
+//   S / n <= remaining (at most MAX_SPLIT), each split n ways along the key axis -- S pieces, one short round.
+// 912 items on 256 slots: 768 whole, 128 in halves, 16 in sixteenths = 3 + 0.5 + 1/16 rounds -- the work there is.  The
+// launch itself is sized for the host-known upper bound; workgroups the plan has no role for leave at once.
+constexpr int PLAN_TIERS = 8;
+constexpr int PLAN_MAX_SPLIT = 16;
+struct DevTier {
+    int wg0, item0, items, nsplit, rec0;   // first workgroup, first item, items, pieces per item, first partial record
+};
+struct DevPlan {
+    int nqb, ntiers, split_items, pad;     // live query blocks per (sample, head); tiers in use; items behind tier 0
+    DevTier tier[PLAN_TIERS];
+};
+// upper bounds of a plan on S slots: workgroups behind the whole items / partial records, items that are split
+constexpr int64_t plan_tail_wgs(int slots) { return (int64_t)(PLAN_TIERS - 1) * slots; }
+constexpr int64_t plan_split_items(int slots) { return slots; }
+
+__global__ void attention16_plan_kernel(const int32_t *__restrict__ q_count, int B, int H, int QB, int slots, int ntiles,
+                                        DevPlan *__restrict__ plan) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int nqb = 1;
+    for (int b = 0; b < B; ++b) {
+        const int n = (q_count[b] + QB - 1) / QB;
+        nqb = n > nqb ? n : nqb;
+    }
+    const int L = nqb * H * B, S = slots;
+    int max_ns = ntiles / 8;                     // a piece keeps >= 8 key tiles
+    max_ns = max_ns > PLAN_MAX_SPLIT ? PLAN_MAX_SPLIT : max_ns < 1 ? 1 : max_ns;
+    DevPlan p;
+    p.nqb = nqb;
+    p.pad = 0;
+    int nt = 0, wg = 0, item = 0, rec = 0;
+    const int whole = max_ns < 2 ? L : L - L % S;
+    p.tier[nt++] = DevTier{0, 0, whole, 1, 0};
+    wg = item = whole;
+    while (item < L && nt < PLAN_TIERS) {
+        const int rem = L - item;
+        int n = 2;
+        while (n < max_ns && S / n > rem) n *= 2;
+        if (n > max_ns) n = max_ns;
+        int take = S / n < rem ? S / n : rem;
+        if (nt == PLAN_TIERS - 1) take = rem;    // (never with S = 256: 2, 4, 8, 16, 16 ...: the last tier takes what is left)
+        p.tier[nt++] = DevTier{wg, item, take, n, rec};
+        wg += take * n;
+        rec += take * n;
+        item += take;
+    }
+    p.ntiers = nt;
+    p.split_items = L - whole;
+    for (int i = nt; i < PLAN_TIERS; ++i) p.tier[i] = DevTier{wg, item, 0, 1, rec};
+    *plan = p;
+}
+
 template <typename T, int D, int NQ, int NG, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attention16_combine_kernel(
     const float *__restrict__ partial, T *__restrict__ out, int64_t ldo, int64_t H, int64_t M, int64_t Mp, int64_t nqb,
-    int64_t id0, int nsplit, int xcd_groups, const int32_t *__restrict__ q_count, int64_t src_batch) {
+    int64_t id0, int nsplit, int xcd_groups, const int32_t *__restrict__ q_count, int64_t src_batch,
+    const DevPlan *__restrict__ dev_plan) {
     constexpr int NT = WAVES * 64, QB = WAVES * QW * NQ, NV = NQ * NG;
     constexpr int NA = (D + 16) / 16 * 8, REC = rec16<D>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int v = blockIdx.y, sub = v / NG, g = v % NG;
-    const int64_t lin = item_of(id0 + blockIdx.x, nqb, xcd_groups);
+    int64_t rec0 = (int64_t)blockIdx.x * nsplit;   // first partial record of this item
+    int64_t pos = id0 + blockIdx.x;
+    if (dev_plan != nullptr) {        // (the launch is sized for the most items a plan can split)
+        if ((int)blockIdx.x >= dev_plan->split_items) return;
+        nqb = dev_plan->nqb;
+        xcd_groups = nqb >= 32 ? xcd_groups : 0;
+        pos = dev_plan->tier[0].items + blockIdx.x;
+        int ti = 1;
+        while (ti + 1 < dev_plan->ntiers && pos >= dev_plan->tier[ti + 1].item0) ++ti;
+        const DevTier tr = dev_plan->tier[ti];
+        nsplit = tr.nsplit;
+        rec0 = tr.rec0 + (pos - tr.item0) * tr.nsplit;
+    }
+    const int64_t lin = item_of(pos, nqb, xcd_groups);
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t q0 = (lin % nqb) * QB + (wave * NQ + sub) * QW;
     if (q_count != nullptr && (lin % nqb) * QB >= (int64_t)q_count[b]) return;   // its partial records were never written
@@ -45,7 +122,7 @@ __global__ __launch_bounds__(WAVES * 64) void attention16_combine_kernel(
 #pragma unroll
     for (int r = 0; r < NA; ++r) acc[r] = 0.0f;
     for (int sp = 0; sp < nsplit; ++sp) {
-        const float *pp = partial + (((int64_t)blockIdx.x * nsplit + sp) * NV + v) * REC * NT + tid;
+        const float *pp = partial + ((rec0 + sp) * NV + v) * REC * NT + tid;
         float fa[2], fb[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -466,13 +543,29 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention16s_kernel(
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
     int64_t M, int64_t Mp, int64_t Mk_arg, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t nwhole,
     int nsplit_tail, float *__restrict__ partial_base, int xcd_groups, const int32_t *__restrict__ q_count,
-    int64_t split_major_items, const int32_t *__restrict__ k_count, const uint32_t *__restrict__ k_bias, int64_t ldkb) {
+    int64_t split_major_items, const int32_t *__restrict__ k_count, const uint32_t *__restrict__ k_bias, int64_t ldkb,
+    const DevPlan *__restrict__ dev_plan) {
     using F = Frag<T>;
     using vec = typename F::vec;
     using elem = typename F::elem;
     static_assert(pv16_for(D) && (D % 16) != 0, "the 16-row O^T path: a head dim with a spare k-slot and a spare O^T row");
     static_assert(!FOLD || (D % 8 == 0 && D % 16 == 8), "key folding needs the spare k-slots of a d % 16 == 8 head");
     constexpr int NQ = 2, KR = 3, VR = 2;
+    int64_t tier_item0 = nwhole, tier_wg0 = nwhole, tier_rec0 = 0;
+    if (dev_plan != nullptr) {        // query-bounded launch: the roles come from attention16_plan_kernel (wave-uniform loads)
+        nqb = dev_plan->nqb;
+        xcd_groups = nqb >= 32 ? xcd_groups : 0;
+        int ti = 0;
+        while (ti + 1 < dev_plan->ntiers && (int)blockIdx.x >= dev_plan->tier[ti + 1].wg0) ++ti;
+        const DevTier tr = dev_plan->tier[ti];
+        if ((int64_t)blockIdx.x >= (int64_t)tr.wg0 + (int64_t)tr.items * tr.nsplit) return;   // behind the last tier
+        nwhole = dev_plan->tier[0].items;
+        nsplit_tail = tr.nsplit;
+        split_major_items = tr.items;       // (inside a tier: all first pieces, then all second pieces ...)
+        tier_item0 = tr.item0;
+        tier_wg0 = tr.wg0;
+        tier_rec0 = tr.rec0;
+    }
     constexpr int NT = WAVES * 64, QB = WAVES * QW * NQ, NV = NQ;
     constexpr int DK = (D + 15) / 16, DV16 = (D + 16) / 16, VROWS = vrows_for(D);
     constexpr int BIAS_HI = (D % 16) / 8, BIAS_E = D % 8;
@@ -491,12 +584,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention16s_kernel(
     const int l31 = lane & 31, hi = lane >> 5;
     const int l15 = lane & 15, g16 = lane >> 4;
     const bool tail_wg = (int64_t)blockIdx.x >= nwhole;
-    const int64_t tail_id = (int64_t)blockIdx.x - nwhole;
+    const int64_t tail_id = (int64_t)blockIdx.x - tier_wg0;      // (host plan: one tier behind the whole items)
     const int nsplit = tail_wg ? nsplit_tail : 1;
     const int64_t tail_item = split_major_items ? tail_id % split_major_items : tail_id / nsplit;
     const int split = !tail_wg ? 0 : split_major_items ? (int)(tail_id / split_major_items) : (int)(tail_id % nsplit);
-    const int64_t lin = item_of(tail_wg ? nwhole + tail_item : (int64_t)blockIdx.x, nqb, xcd_groups);
-    float *partial = tail_wg ? partial_base + (tail_item * nsplit + split) * NV * REC * NT : nullptr;
+    const int64_t lin = item_of(tail_wg ? tier_item0 + tail_item : (int64_t)blockIdx.x, nqb, xcd_groups);
+    float *partial = tail_wg ? partial_base + (tier_rec0 + tail_item * nsplit + split) * NV * REC * NT : nullptr;
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t bq = b % src_batch;
     const int64_t qblock0 = (lin % nqb) * QB;
@@ -894,6 +987,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention16s_kernel(
         write_output16<T, D>(o16[sub], out, ldo, b, h, qblock0 + (wave * NQ + sub) * QW, M, Mp, lane);
 }
 
+// workspace of a device-planned launch: the plan (one cache line) + the records of the largest tail a plan can have
+constexpr size_t DEVPLAN_HEADER = 256;
+static_assert(sizeof(DevPlan) <= 256, "the plan lives in the workspace header");
+size_t devplan_ws_bytes(int slots, size_t rec_bytes) { return DEVPLAN_HEADER + (size_t)plan_tail_wgs(slots) * rec_bytes; }
+bool devplan_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("VTM_ATT16_DEVPLAN");      // A/B hook, read once per process
+        return e == nullptr || atoi(e) != 0;
+    }();
+    return on;
+}
+
 template <typename T, int D, bool FOLD, int NQ, int NG, int WAVES, bool SKEW>
 int launch16(const Args16 &a) {
     static_assert(!SKEW || (NQ == 2 && NG == 1), "the skewed pipeline is the two-sub-tile, one-group shape");
@@ -908,26 +1013,56 @@ int launch16(const Args16 &a) {
     const int64_t src_batch = a.B / a.share_groups;
     const int64_t B_items = NG > 1 ? src_batch : a.B;
     const size_t rec_bytes = (size_t)NV * rec16<D>() * NT * sizeof(float);
-    TailPlan p = plan_tail16(B_items, a.h, a.M, a.Mk, QB, wg_per_cu16(NQ, NG, WAVES), rec_bytes, a.q_count != nullptr);
-    if (p.split_all && (!a.ws || a.ws_bytes < p.ws_bytes))
-        p = plan_tail16(B_items, a.h, a.M, a.Mk, QB, wg_per_cu16(NQ, NG, WAVES), rec_bytes, false);
+    const float scale_log2e = a.scale * 1.4426950408889634f;
+    const int wg_cu = wg_per_cu16(NQ, NG, WAVES);
+    const int64_t nqb_max = vtm::cdiv(a.M, QB);
+    const int xcd_pairs = (B_items * a.h) % 8 == 0 ? (int)(B_items * a.h / 8) : 0;
+    if constexpr (SKEW) {
+        // query-bounded: planned on the device (attention16_plan_kernel) when the workspace holds the plan and its records
+        const int slots = vtm::device_cus() * wg_cu;
+        const size_t need = devplan_ws_bytes(slots, rec_bytes);
+        if (a.q_count != nullptr && a.ws != nullptr && a.ws_bytes >= need && devplan_enabled()) {
+            DevPlan *plan = reinterpret_cast<DevPlan *>(a.ws);
+            float *records = reinterpret_cast<float *>(static_cast<char *>(a.ws) + DEVPLAN_HEADER);
+            const int ntiles = (int)vtm::cdiv(a.Mk, KV);
+            hipLaunchKernelGGL(attention16_plan_kernel, dim3(1), dim3(64), 0, a.s, a.q_count, (int)B_items, (int)a.h, QB, slots,
+                               ntiles, plan);
+            const int64_t total = nqb_max * a.h * B_items, tail_max = plan_tail_wgs(slots);
+            VTM_REQUIRE(total + tail_max < (1ll << 31) / 16, "vtm_attention: grid too large");
+            hipLaunchKernelGGL(kernel, dim3((unsigned)(total + tail_max)), dim3(NT), lds, a.s, (const T *)a.q, a.ldq,
+                               (const T *)a.k, a.ldk, (const T *)a.vt, a.ldvt, (T *)a.out, a.ldo, a.h, a.M, a.Mp, a.Mk, a.Mkp,
+                               scale_log2e, src_batch, nqb_max, total, 1, records, xcd_pairs, a.q_count, (int64_t)0, a.k_count,
+                               a.k_bias, a.ldkb, (const DevPlan *)plan);
+            hipLaunchKernelGGL((attention16_combine_kernel<T, D, NQ, NG, WAVES>), dim3((unsigned)plan_split_items(slots), (unsigned)NV), dim3(NT),
+                               0, a.s, (const float *)records, (T *)a.out, a.ldo, a.h, a.M, a.Mp, nqb_max, total, 1, xcd_pairs,
+                               a.q_count, src_batch, (const DevPlan *)plan);
+            return vtm::launch_status("vtm_attention");
+        }
+    }
+    TailPlan p = plan_tail16(B_items, a.h, a.M, a.Mk, QB, wg_cu, rec_bytes, a.q_count != nullptr);
+    if (p.split_all && (!a.ws || a.ws_bytes < p.ws_bytes)) p = plan_tail16(B_items, a.h, a.M, a.Mk, QB, wg_cu, rec_bytes, false);
     if (p.nsplit > 1 && (!a.ws || a.ws_bytes < p.ws_bytes)) {
         p.nsplit = 1;
         p.full = p.total;
         p.split_all = false;
     }
-    const float scale_log2e = a.scale * 1.4426950408889634f;
     VTM_REQUIRE(p.total < (1ll << 31) / 16, "vtm_attention: grid too large");
     const int64_t rem = p.total - p.full;
-    const int xcd_groups = ((B_items * a.h) % 8 == 0 && p.nqb >= 32) ? (int)(B_items * a.h / 8) : 0;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(p.full + rem * p.nsplit)), dim3(NT), lds,
-                       a.s, (const T *)a.q, a.ldq, (const T *)a.k, a.ldk, (const T *)a.vt, a.ldvt, (T *)a.out, a.ldo, a.h, a.M,
-                       a.Mp, a.Mk, a.Mkp, scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)a.ws, xcd_groups, a.q_count,
-                       p.split_all ? rem : (int64_t)0, a.k_count, a.k_bias, a.ldkb);
+    const int xcd_groups = p.nqb >= 32 ? xcd_pairs : 0;
+    if constexpr (SKEW)
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(p.full + rem * p.nsplit)), dim3(NT), lds,
+                           a.s, (const T *)a.q, a.ldq, (const T *)a.k, a.ldk, (const T *)a.vt, a.ldvt, (T *)a.out, a.ldo, a.h, a.M,
+                           a.Mp, a.Mk, a.Mkp, scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)a.ws, xcd_groups, a.q_count,
+                           p.split_all ? rem : (int64_t)0, a.k_count, a.k_bias, a.ldkb, (const DevPlan *)nullptr);
+    else
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(p.full + rem * p.nsplit)), dim3(NT), lds,
+                           a.s, (const T *)a.q, a.ldq, (const T *)a.k, a.ldk, (const T *)a.vt, a.ldvt, (T *)a.out, a.ldo, a.h, a.M,
+                           a.Mp, a.Mk, a.Mkp, scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)a.ws, xcd_groups, a.q_count,
+                           p.split_all ? rem : (int64_t)0, a.k_count, a.k_bias, a.ldkb);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((attention16_combine_kernel<T, D, NQ, NG, WAVES>), dim3((unsigned)rem, (unsigned)NV), dim3(NT), 0, a.s,
                            (const float *)a.ws, (T *)a.out, a.ldo, a.h, a.M, a.Mp, p.nqb, p.full, p.nsplit, xcd_groups,
-                           a.q_count, src_batch);
+                           a.q_count, src_batch, (const DevPlan *)nullptr);
     return vtm::launch_status("vtm_attention");
 }
 
@@ -996,7 +1131,10 @@ TailPlan plan_tail16(int64_t B_items, int64_t h, int64_t Mq, int64_t Mk, int64_t
 size_t ws_bytes16(const Shape16 &sh, int64_t B_items, int64_t h, int64_t Mq, int64_t Mk, bool bounded) {
     const int NT = sh.waves * 64;
     const size_t rec = (size_t)sh.nq * sh.ng * rec16<40>() * NT * sizeof(float);
-    return plan_tail16(B_items, h, Mq, Mk, (int64_t)sh.waves * QW * sh.nq, wg_per_cu16(sh.nq, sh.ng, sh.waves), rec, bounded).ws_bytes;
+    const int wg_cu = wg_per_cu16(sh.nq, sh.ng, sh.waves);
+    size_t n = plan_tail16(B_items, h, Mq, Mk, (int64_t)sh.waves * QW * sh.nq, wg_cu, rec, bounded).ws_bytes;
+    if (bounded && sh.skew && devplan_enabled()) n = std::max(n, devplan_ws_bytes(vtm::device_cus() * wg_cu, rec));
+    return n;
 }
 
 int attention16(const Args16 &a, const Shape16 &sh) {
