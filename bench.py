@@ -177,7 +177,7 @@ def self_launch(args) -> int:
 
 class BoxSampler(threading.Thread):
     """Shader clock and package power of the GPU this rank runs on, sampled from sysfs (amdgpu hwmon) during the
-    timed region: the dominant kernels are power-limited, so the number belongs next to the
+    timed region: the dominant kernels are power-limited (profiles/HISTORY.md section 10), so the number belongs next to the
     roofline fraction -- measured on THIS box, in THIS run."""
 
     def __init__(self, device_index: int, period_s: float = 0.05):
@@ -828,7 +828,7 @@ def main():
             box_note = (f"this run: package power {watts:.0f} W mean, shader clock {sclk / 1e3:.2f} GHz mean over the timed region "
                         f"(bench.box) -- the fp16 MFMA roof at that clock is {roof_at_clock:.0f} TFLOP/s; with non-toggling "
                         f"operands the same launch reaches 1 130-1 166 TFLOP/s at 2.4 GHz = the floor of its instruction mix "
-                        f"(profiles/r02_ubench.txt, DESIGN.md section 10)")
+                        f"(profiles/r02_ubench.txt, DESIGN.md section 8)")
         else:
             box_note = "no clock / power sample available on this box (sysfs hwmon not readable)"
         # every launch kind of the path, HIP-event time per step on the event passes; what is left of the step is dispatch

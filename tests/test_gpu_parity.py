@@ -2369,7 +2369,7 @@ def _block_rows_vs_oracle(oracle, blk, plan, hidden, out, fsize, share=1, n_rows
     `out_ulp` (cfg-4's 18 432-key chunks, where a few rows have a sharply peaked softmax): all but 1e-4 of the sampled
     elements within 1e-3 and every one within 2e-3 -- tools/diag/cfg4_err.py shows 2 of 164 000 elements at 1.3e-3 of the
     scale (p99.9 = 3.7e-4), identically for an fp16 and an fp32 model: the fp16 rounding of q / k of a row whose largest
-    logit is tens of log2 units, not the projections."""
+    logit is tens of log2 units, not the projections (profiles/HISTORY.md section 10.6)."""
     from vidtome_amd.utils import join_frame
     a = blk.attn1
     f32 = lambda t: t.detach().float().cpu().numpy()

@@ -1,5 +1,5 @@
 // Ablation switches of the hand-scheduled kernels (filter_kernel in match_filter.hip, the projection GEMMs in linear.hip),
-// in ONE place.  They exist for the "where does the time go" measurements quoted in DESIGN.md section 9: each one removes a
+// in ONE place.  They exist for the "where does the time go" measurements quoted in profiles/HISTORY.md section 9: each one removes a
 // part of a loop (loads, barriers, stores ...) and EVERY ONE OF THEM PRODUCES WRONG RESULTS.  The shipped library is built
 // with none of them defined: every macro below then expands to its "shipped" argument and nothing else, the kernels'
 // sources carry no #ifdef, and vtm_build_ablations() (api.hip) returns 0 -- tests/test_host.py checks exactly that on
