@@ -766,7 +766,7 @@ bool shape16_for(int64_t d, int share_groups, bool fold, Shape16 *sh) {
         return true;
     }
     if (!fold && (share_groups == 2 || share_groups == 3)) {   // shared probabilities: P once, one PV per sample
-        *sh = Shape16{1, share_groups, 8, false};
+        *sh = Shape16{1, share_groups, 8, p.skew};   // (skew: attention16g.hip, else attention16_kernel<NQ = 1, NG>)
         return true;
     }
     return false;
