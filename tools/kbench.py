@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--share", type=int, default=1, help="attn: share_groups (B must be a multiple)")
     ap.add_argument("--bounded", type=float, default=0.0, help="attn: device-side query count = this fraction of Mq")
     ap.add_argument("--check", action="store_true", help="attn: compare a few rows with an fp32 torch reference")
+    ap.add_argument("--power", type=float, default=0.0, help="attn: seconds of back-to-back launches under the sysfs power sampler "
+                    "(prints W, MHz and joules per launch)")
     ap.add_argument("--data", default="random", help="attn: random | zeros | const (operand values); match: n01 | corr01 | "
                     "corr05 | flat25 | dup | zero | all (token regime; random = n01 in fp16 straight from the device generator)")
     a = ap.parse_args()
@@ -151,6 +153,28 @@ def main():
         print(f"attention B={B} Mq={Mq} Mk={M} h={h} d={d} share={G} bounded={a.bounded}: median {med:.3f} ms ({fl / med / 1e9:.1f} "
               f"TFLOP/s), best {best:.3f} ms ({fl / best / 1e9:.1f} TFLOP/s)   [VTM_ATT16={os.environ.get('VTM_ATT16', '')} "
               f"NQ={os.environ.get('VTM_ATT16_NQ', '')} WAVES={os.environ.get('VTM_ATT16_WAVES', '')}]")
+        if a.power:                      # ms AND joules: back-to-back launches for ~a.power seconds under the sysfs sampler of bench.py
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bench import BoxSampler
+            n = max(10, int(a.power * 1e3 / med))
+            run()
+            torch.cuda.synchronize()
+            smp = BoxSampler(0, 0.02)
+            smp.start()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            box = smp.stop()
+            ms = e0.elapsed_time(e1) / n
+            if box and box.get("power_w"):
+                w, f = box["power_w"]["mean"], box["sclk_mhz"]["mean"]
+                print(f"   power: {n} back-to-back launches, {ms:.3f} ms each at {w:.0f} W package power, {f:.0f} MHz mean -> "
+                      f"{w * ms * 1e-3:.3f} J per launch ({w * ms * 1e-3 / (fl * 1e-12):.3f} J per TFLOP)")
+            else:
+                print(f"   power: {n} back-to-back launches, {ms:.3f} ms each (no sysfs power sample on this box)")
         if a.check:                      # a few rows of every sample against fp32 torch (sa_forward's arithmetic)
             out = run()
             nrow = int(live)
