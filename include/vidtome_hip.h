@@ -111,9 +111,12 @@ int vtm_match(const float *a, const float *b, int64_t B, int64_t Ns, int64_t Nd,
  * usable norm was seen, [2] = number of rows recomputed by the escape because their candidate list overflowed or their own
  * norm was unusable, [3] = number of (row, dst) pairs the refine pass evaluated, [4] = 32 x 32 score blocks the filter's
  * partial-sum pruning tested, [5] = blocks still alive after the test (the others skipped their remaining MFMAs; both 0
- * when the rows are too short to prune), [6] = work items the escape launch handed out dynamically (internal), [7] = 0
+ * when the rows are too short to prune), [6] = internal (the escape launch's work counter while it runs: unspecified), [7] = 0
  * (vtm_match_filtered_plan: blocks inside the spans of the second launch).  The block counters are only collected when flags_out
- * is given.  Derivation of the window: vidtome_amd/csrc/match_filter.hip.
+ * is given.  flags_out may be device memory or host memory (ABI version 2): memory a kernel can store to -- device, pinned /
+ * registered host -- is written by the call's last launch itself, pageable host memory by a 32-byte asynchronous copy behind the
+ * call; either way the values are there once the stream has passed the call.  Derivation of the window:
+ * vidtome_amd/csrc/match_filter.hip.
  *
  * vtm_match_filtered_seeded -- the same result, usually faster on video tokens: before the filter starts every src row gets
  * a starting maximum from ONE guessed pair, the dst row at the same token position (one more small launch).  seed_N =

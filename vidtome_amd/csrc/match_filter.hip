@@ -1176,7 +1176,11 @@ __global__ __launch_bounds__(256, XS == 128 ? 2 : 1) void exact_rows_kernel(
     const int *__restrict__ ovf_cnt, const int *__restrict__ ovf_rows, unsigned long long *__restrict__ best, int nsplit,
     int tiles_per_split, const float *__restrict__ rest_a, const float *__restrict__ rest_bt, int KX, int64_t Ns_pad,
     int64_t rest_tiles, const unsigned int *__restrict__ seed_lb, int *__restrict__ work,
-    const int32_t *__restrict__ src_order, const int32_t *__restrict__ dst_order) {
+    const int32_t *__restrict__ src_order, const int32_t *__restrict__ dst_order, int32_t *__restrict__ flags_pub) {
+    // (round 6) the call's counters for the host -- final since refine_kernel finished, except the work counter [6] this launch
+    // hands out -- are published from here when `flags_out` is device-accessible memory (device or pinned host): the last
+    // launch of the call does it instead of a 32-byte copy of its own (one dispatch less per matcher call)
+    if (flags_pub != nullptr && blockIdx.x == 0 && threadIdx.x < 8) flags_pub[threadIdx.x] = flags[threadIdx.x];
     __shared__ __attribute__((aligned(16))) float sD[8 * XPD * 4];
     // position-ordered call: the ORIGINAL index of every dst row of the tile being scored (double-buffered like the row
     // pointers: the next tile's are staged behind the current tile's last step) -- a lane's running argmax is kept and
@@ -1703,6 +1707,7 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
                                (unsigned int *)nullptr, map_words);
         }
     }
+    bool flags_direct = false;
     {
         const dim3 grid((unsigned)vtm::cdiv(rows_out, RROWS)), block(256);
         unsigned long long *bp = reinterpret_cast<unsigned long long *>(best);
@@ -1719,8 +1724,20 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
         const dim3 xgrid((unsigned)((XS == 128 ? 2 : 1) * vtm::device_cus()));
         // exact_rows_kernel's tile pruning: the rest norms prep_operand wrote for the filter's cut, in 32-channel steps
         const int KX = dbg.no_xprune ? 0 : (int)(cut / XK);
+        // where the counters go: written by exact_rows_kernel itself when the destination is memory a kernel can store to
+        // (device, or host memory the runtime has pinned / registered), copied behind the call otherwise (pageable host memory)
+        int32_t *flags_pub = nullptr;
+        if (flags_out) {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, flags_out) == hipSuccess &&
+                (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeManaged))
+                flags_pub = attr.type == hipMemoryTypeHost && attr.devicePointer ? (int32_t *)attr.devicePointer : flags_out;
+            else
+                (void)hipGetLastError();          // (an unregistered pointer is an "error" of the query, not of the call)
+        }
+        flags_direct = flags_pub != nullptr;
 #define VTM_XPRUNE_ARGS (const float *)rest_a, (const float *)rest_bt, KX, L.Ns_pad, L.Nd_pad / FBD, (const unsigned int *)(w + L.seedlb), \
-                        flags + 6, src_order, dst_order
+                        flags + 6, src_order, dst_order, flags_pub
         switch (dtype) {
             case VTM_F32:
                 hipLaunchKernelGGL(refine_kernel<float>, grid, block, 0, s, (const float *)x0, P0, (const float *)x1, P1,
@@ -1744,8 +1761,8 @@ static int match_filtered_impl(const void *x0, int64_t P0, const void *x1, int64
     }
     if (int rc = vtm::launch_status("vtm_match_filtered")) return rc;
 
-    if (flags_out) {
-        // (device or pinned host memory: the copy direction is taken from the pointers)
+    if (flags_out && !flags_direct) {
+        // (pageable host memory: the copy direction is taken from the pointers)
         const hipError_t e = hipMemcpyAsync(flags_out, flags, 8 * sizeof(int), hipMemcpyDefault, s);
         if (e != hipSuccess) return vtm::fail(VTM_ELAUNCH, "vtm_match_filtered: copy: %s", hipGetErrorString(e));
     }
