@@ -36,42 +36,6 @@ namespace {
 
 using namespace vtm_att;
 
-// normalise and store one wave's O^T accumulators: row q = q0 + l31, channels dv*32 + (r & 3) + 8 (r >> 2) + 4 hi
-template <typename T, int D>
-__device__ __forceinline__ void write_output(const f32x16 (&o)[(D + 31) / 32], float l_run, T *__restrict__ out,
-                                             int64_t ldo, int64_t b, int64_t h, int64_t q0, int64_t M, int64_t Mp,
-                                             int l31, int hi) {
-    using elem = typename Frag<T>::elem;
-    constexpr int DV = (D + 31) / 32;
-    constexpr bool SPARE = (D % 32) != 0;
-    float l_tot;
-    if constexpr (SPARE) {
-        // denominator row D of O^T: block D/32, in-block row D%32 = (r&3) + 8(r>>2) + 4hi
-        constexpr int LB = D / 32, LR = D % 32;
-        constexpr int LHI = (LR >> 2) & 1, LREG = (LR & 3) + 4 * (LR >> 3);
-        l_tot = __shfl(o[LB][LREG], l31 + 32 * LHI, 64);
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    }
-    const float inv_l = 1.0f / l_tot;
-    const int64_t qi = q0 + l31;
-    if (qi < M) {
-        T *op = out + (b * Mp + qi) * ldo + h * D;
-#pragma unroll
-        for (int dv = 0; dv < DV; ++dv)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = dv * 32 + 8 * g + 4 * hi;
-                if (d0 < D) {  // D % 8 == 0 and d0 % 4 == 0 -> the 4 channels are all valid
-                    elem w[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = (elem)(o[dv][g * 4 + e] * inv_l);
-                    *reinterpret_cast<uint2 *>(op + d0) = *reinterpret_cast<uint2 *>(w);
-                }
-            }
-    }
-}
-
 // merges the `nsplit` partial states of a query block (same thread <-> register mapping as attention_kernel)
 template <typename T, int D>
 __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
@@ -809,8 +773,8 @@ VTM_EXPORT size_t vtm_attention_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64
     if (B <= 0 || h <= 0 || Mq <= 0 || Mk <= 0) return 0;
     switch (d) {
         case 40: return std::max(plan_tail<40>(B, h, Mq, Mk).ws_bytes, ws16_max(B, h, Mq, Mk, false));
-        case 64: return plan_tail<64>(B, h, Mq, Mk).ws_bytes;
-        case 80: return plan_tail<80>(B, h, Mq, Mk).ws_bytes;
+        case 64: return std::max(plan_tail<64>(B, h, Mq, Mk).ws_bytes, shape32g_for(64, 1, Mk) ? ws_bytes32g(64, B, h, Mq, Mk, false) : (size_t)0);
+        case 80: return std::max(plan_tail<80>(B, h, Mq, Mk).ws_bytes, shape32g_for(80, 1, Mk) ? ws_bytes32g(80, B, h, Mq, Mk, false) : (size_t)0);
         case 160: return plan_tail<160>(B, h, Mq, Mk).ws_bytes;
         case 8: return plan_tail<8>(B, h, Mq, Mk).ws_bytes;
         case 16: return plan_tail<16>(B, h, Mq, Mk).ws_bytes;
@@ -825,8 +789,8 @@ VTM_EXPORT size_t vtm_attention_kv_bounded_ws_bytes(int64_t B, int64_t h, int64_
     if (B <= 0 || h <= 0 || Mq <= 0 || Mk <= 0) return 0;
     switch (d) {
         case 40: return std::max(plan_tail<40>(B, h, Mq, Mk, true).ws_bytes, ws16_max(B, h, Mq, Mk, true));
-        case 64: return plan_tail<64>(B, h, Mq, Mk, true).ws_bytes;
-        case 80: return plan_tail<80>(B, h, Mq, Mk, true).ws_bytes;
+        case 64: return std::max(plan_tail<64>(B, h, Mq, Mk, true).ws_bytes, shape32g_for(64, 1, Mk) ? ws_bytes32g(64, B, h, Mq, Mk, true) : (size_t)0);
+        case 80: return std::max(plan_tail<80>(B, h, Mq, Mk, true).ws_bytes, shape32g_for(80, 1, Mk) ? ws_bytes32g(80, B, h, Mq, Mk, true) : (size_t)0);
         case 160: return plan_tail<160>(B, h, Mq, Mk, true).ws_bytes;
         case 8: return plan_tail<8>(B, h, Mq, Mk, true).ws_bytes;
         case 16: return plan_tail<16>(B, h, Mq, Mk, true).ws_bytes;
@@ -858,6 +822,11 @@ static int attention_any(const void *q, int64_t ldq, const void *k, int64_t ldk,
                            q_count, s, false, nullptr, nullptr, 0};
             return attention16(a, sh);
         }
+    }
+    if ((dtype == VTM_F16 || dtype == VTM_BF16) && shape32g_for(d, share_groups, Mk)) {
+        const Args16 a{q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws, ws_bytes,
+                       q_count, s, false, nullptr, nullptr, 0};
+        return attention32g(a, d);
     }
     if (dtype == VTM_F16)
         return dispatch<__half>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws,

@@ -102,6 +102,42 @@ __device__ __forceinline__ void mask_keys(uint4 &v, int valid) {
     }
 }
 
+// normalise and store one wave's O^T accumulators: row q = q0 + l31, channels dv*32 + (r & 3) + 8 (r >> 2) + 4 hi
+template <typename T, int D>
+__device__ __forceinline__ void write_output(const f32x16 (&o)[(D + 31) / 32], float l_run, T *__restrict__ out,
+                                             int64_t ldo, int64_t b, int64_t h, int64_t q0, int64_t M, int64_t Mp,
+                                             int l31, int hi) {
+    using elem = typename Frag<T>::elem;
+    constexpr int DV = (D + 31) / 32;
+    constexpr bool SPARE = (D % 32) != 0;
+    float l_tot;
+    if constexpr (SPARE) {
+        // denominator row D of O^T: block D/32, in-block row D%32 = (r&3) + 8(r>>2) + 4hi
+        constexpr int LB = D / 32, LR = D % 32;
+        constexpr int LHI = (LR >> 2) & 1, LREG = (LR & 3) + 4 * (LR >> 3);
+        l_tot = __shfl(o[LB][LREG], l31 + 32 * LHI, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
+    const float inv_l = 1.0f / l_tot;
+    const int64_t qi = q0 + l31;
+    if (qi < M) {
+        T *op = out + (b * Mp + qi) * ldo + h * D;
+#pragma unroll
+        for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dv * 32 + 8 * g + 4 * hi;
+                if (d0 < D) {  // D % 8 == 0 and d0 % 4 == 0 -> the 4 channels are all valid
+                    elem w[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (elem)(o[dv][g * 4 + e] * inv_l);
+                    *reinterpret_cast<uint2 *>(op + d0) = *reinterpret_cast<uint2 *>(w);
+                }
+            }
+    }
+}
+
 // PV16 layout: o[dv][qh][e] = O^T row 16 dv + 4 (lane >> 4) + e of query q0 + 16 qh + (lane & 15)
 template <typename T, int D>
 __device__ __forceinline__ void write_output16(const f32x4 (&o)[(D + 16) / 16][2], T *__restrict__ out, int64_t ldo,
@@ -156,5 +192,9 @@ int attention16(const Args16 &a, const Shape16 &sh);
 // attention16g.hip: shared probabilities (ng = 2, 3 value groups), one-tile skew
 size_t ws_bytes16g(int ng, int64_t src_batch, int64_t h, int64_t Mq, int64_t Mk);
 int attention16g(const Args16 &a, int ng);
+// attention32g.hip: d = 64 / 80 self-attention, one-tile skew
+bool shape32g_for(int64_t d, int share_groups, int64_t Mk);
+size_t ws_bytes32g(int64_t d, int64_t B, int64_t h, int64_t Mq, int64_t Mk, bool bounded);
+int attention32g(const Args16 &a, int64_t d);
 
 }  // namespace vtm_att
