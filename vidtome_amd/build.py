@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvidtome_hip.so")
-SOURCES = ["api.hip", "normalize.hip", "match.hip", "match_filter.hip", "sort.hip", "order.hip", "plan.hip", "gather.hip", "attention.hip", "attention16.hip", "attention16g.hip", "attention32g.hip", "ddim.hip", "layernorm.hip", "geglu.hip", "linear.hip", "ff.hip"]
+SOURCES = ["api.hip", "normalize.hip", "match.hip", "match_filter.hip", "sort.hip", "order.hip", "plan.hip", "gather.hip", "attention.hip", "attention16.hip", "attention16g.hip", "ddim.hip", "layernorm.hip", "geglu.hip", "linear.hip", "ff.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",

@@ -26,7 +26,7 @@
 //   * d = 40 builds O^T from 16-row blocks (v_mfma_f32_16x16x32: 48 rows instead of 64, a quarter of the
 //     PV matrix work gone); P^T moves from the 32-query accumulator layout to the two 16-query B operands
 //     with v_permlane16_swap -- 8 swaps per tile, still no LDS round trip (PV16 below).
-#include "attention_common.h"
+#include "attention16_parts.h"   // (the device-side launch plan of query-bounded launches: DevPlan, attention16_plan_kernel)
 
 #include <algorithm>
 #include <cstdlib>
@@ -34,19 +34,30 @@
 
 namespace {
 
-using namespace vtm_att;
-
 // merges the `nsplit` partial states of a query block (same thread <-> register mapping as attention_kernel)
 template <typename T, int D>
 __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
     const float *__restrict__ partial, T *__restrict__ out, int64_t ldo, int64_t H, int64_t M, int64_t Mp, int64_t nqb,
-    int64_t id0, int nsplit, int xcd_groups, const int32_t *__restrict__ q_count) {
+    int64_t id0, int nsplit, int xcd_groups, const int32_t *__restrict__ q_count, const DevPlan *__restrict__ dev_plan) {
     constexpr int WAVES = waves_for(D), NT = WAVES * 64, QB = WAVES * QW, DV = (D + 31) / 32;
     constexpr bool PV16 = pv16_for(D);
     constexpr int NA = acc_floats(D), NM = max_floats(D), REC = rec_floats(D);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int64_t lin = item_of(id0 + blockIdx.x, nqb, xcd_groups);
+    int64_t rec0 = (int64_t)blockIdx.x * nsplit;   // first partial record of this item
+    int64_t pos = id0 + blockIdx.x;
+    if (dev_plan != nullptr) {        // device-planned launch (attention16_parts.h): the launch is sized for the most items a plan can split
+        if ((int)blockIdx.x >= dev_plan->split_items) return;
+        nqb = dev_plan->nqb;
+        xcd_groups = nqb >= 64 ? xcd_groups : 0;
+        pos = dev_plan->tier[0].items + blockIdx.x;
+        int ti = 1;
+        while (ti + 1 < dev_plan->ntiers && pos >= dev_plan->tier[ti + 1].item0) ++ti;
+        const DevTier tr = dev_plan->tier[ti];
+        nsplit = tr.nsplit;
+        rec0 = tr.rec0 + (pos - tr.item0) * tr.nsplit;
+    }
+    const int64_t lin = item_of(pos, nqb, xcd_groups);
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
     if (q_count != nullptr && (lin % nqb) * QB >= (int64_t)q_count[b]) return;   // its partial records were never written
@@ -56,7 +67,7 @@ __global__ __launch_bounds__(waves_for(D) * 64) void attention_combine_kernel(
 #pragma unroll
     for (int j = 0; j < NM; ++j) m[j] = -INFINITY;
     for (int sp = 0; sp < nsplit; ++sp) {
-        const float *pp = partial + ((int64_t)blockIdx.x * nsplit + sp) * REC * NT + tid;
+        const float *pp = partial + (rec0 + sp) * REC * NT + tid;
         float fa[NM], fb[NM];
 #pragma unroll
         for (int j = 0; j < NM; ++j) {
@@ -150,7 +161,8 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
     int64_t M, int64_t Mp, int64_t Mk_arg, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t nwhole,
     int nsplit_tail, float *__restrict__ partial_base, int xcd_groups, const int32_t *__restrict__ q_count,
-    int64_t split_major_items, const int32_t *__restrict__ k_count, const uint32_t *__restrict__ k_bias, int64_t ldkb) {
+    int64_t split_major_items, const int32_t *__restrict__ k_count, const uint32_t *__restrict__ k_bias, int64_t ldkb,
+    const DevPlan *__restrict__ dev_plan) {
     // M / Mp: queries per sample and their row stride; Mk / Mkp: keys per sample and the row stride of k
     // (self-attention passes the same values; cross-attention, patch.py:178-183, has Mk = 77).
     // Work decomposition: work item = (query block, head, sample), query blocks fastest.  Workgroups [0, nwhole) take
@@ -194,16 +206,33 @@ __global__ __launch_bounds__(waves_for(D) * 64, (D <= 48 ? 4 : D <= 96 ? 4 : 1))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int l15 = lane & 15, g16 = lane >> 4;   // PV16 operand coordinates
+    // (round 6) query-bounded launches: the roles come from the plan one thread made on the device from the live counts --
+    // whole items first, then tiers of items split 2, 4, 8, 16 ways (attention16_parts.h); workgroups behind the plan leave
+    int64_t tier_item0 = nwhole, tier_wg0 = nwhole, tier_rec0 = 0;
+    if (dev_plan != nullptr) {
+        nqb = dev_plan->nqb;
+        xcd_groups = nqb >= 64 ? xcd_groups : 0;
+        int ti = 0;
+        while (ti + 1 < dev_plan->ntiers && (int)blockIdx.x >= dev_plan->tier[ti + 1].wg0) ++ti;
+        const DevTier tr = dev_plan->tier[ti];
+        if ((int64_t)blockIdx.x >= (int64_t)tr.wg0 + (int64_t)tr.items * tr.nsplit) return;
+        nwhole = dev_plan->tier[0].items;
+        nsplit_tail = tr.nsplit;
+        split_major_items = tr.items;       // (inside a tier: all first pieces, then all second pieces ...)
+        tier_item0 = tr.item0;
+        tier_wg0 = tr.wg0;
+        tier_rec0 = tr.rec0;
+    }
     const bool tail_wg = (int64_t)blockIdx.x >= nwhole;
-    const int64_t tail_id = (int64_t)blockIdx.x - nwhole;
+    const int64_t tail_id = (int64_t)blockIdx.x - tier_wg0;      // (host plan: one tier behind the whole items)
     const int nsplit = tail_wg ? nsplit_tail : 1;
     // split-minor (a partly filled last round: the splits of an item sit next to each other) or split-MAJOR (launches
     // with a device-side query bound split EVERY item, see launch(): all first halves, then all second halves, so that
     // workgroup p and its item still share p % 8 = the XCD the item's (sample, head) pair is pinned to)
     const int64_t tail_item = split_major_items ? tail_id % split_major_items : tail_id / nsplit;
     const int split = !tail_wg ? 0 : split_major_items ? (int)(tail_id / split_major_items) : (int)(tail_id % nsplit);
-    const int64_t lin = item_of(tail_wg ? nwhole + tail_item : (int64_t)blockIdx.x, nqb, xcd_groups);
-    float *partial = tail_wg ? partial_base + (tail_item * nsplit + split) * rec_floats(D) * (waves_for(D) * 64) : nullptr;
+    const int64_t lin = item_of(tail_wg ? tier_item0 + tail_item : (int64_t)blockIdx.x, nqb, xcd_groups);
+    float *partial = tail_wg ? partial_base + (tier_rec0 + tail_item * nsplit + split) * rec_floats(D) * (waves_for(D) * 64) : nullptr;
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;
     const int64_t bq = b % src_batch;  // PnP injection: q/k of the source sample (pnp_utils.py:57-67)
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
@@ -639,6 +668,21 @@ TailPlan plan_tail(int64_t B, int64_t h, int64_t Mq, int64_t Mk, bool bounded = 
     return p;
 }
 
+bool devplan_on() {
+    static const bool on = [] {
+        const char *e = getenv("VTM_ATT_DEVPLAN");      // A/B hook, read once per process
+        return e == nullptr || atoi(e) != 0;
+    }();
+    return on;
+}
+// workspace of a device-planned query-bounded launch of attention_kernel<D>
+template <int D>
+size_t devplan_ws(int64_t Mk) {
+    if (!devplan_on() || vtm::cdiv(Mk, KV) < 16) return 0;
+    const int slots = vtm::device_cus() * (D <= 48 ? 2 : 1);
+    return 256 + (size_t)plan_tail_wgs(slots) * rec_floats(D) * (waves_for(D) * 64) * sizeof(float);
+}
+
 template <typename T, int D, bool FOLD = false>
 int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt, void *out,
            int64_t ldo, int64_t B, int64_t h, int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale, int share_groups,
@@ -658,6 +702,34 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
         }
     }
     constexpr int WAVES = waves_for(D);
+    const float scale_log2e_ = scale * 1.4426950408889634f;
+    // (round 6) a query-bounded launch is planned ON THE DEVICE from the live counts when the workspace holds the plan and
+    // the records of the largest tail a plan can have (vtm_attention_kv_bounded_ws_bytes): whole items, then tiers split
+    // 2 .. 16 ways -- rounds 4-5 split every item in two (VTM_ATT_DEVPLAN=0 keeps that plan)
+    if (q_count != nullptr && ws != nullptr && devplan_on()) {
+        const int slots = vtm::device_cus() * (D <= 48 ? 2 : 1);
+        const size_t rec_bytes = (size_t)rec_floats(D) * (WAVES * 64) * sizeof(float);
+        constexpr int QB = WAVES * QW;
+        // (launches of at least two rounds: the oversized grid and the two small launches of a plan cost 50-70 us, which a
+        // one-round launch does not get back -- profiles/r06_k_devplan_attention_kernel.txt)
+        if (ws_bytes >= 256 + (size_t)plan_tail_wgs(slots) * rec_bytes && vtm::cdiv(M, QB) * h * B >= 2 * slots) {
+            DevPlan *plan = reinterpret_cast<DevPlan *>(ws);
+            float *records = reinterpret_cast<float *>(static_cast<char *>(ws) + 256);
+            const int64_t nqb_max = vtm::cdiv(M, QB), total = nqb_max * h * B, tail_max = plan_tail_wgs(slots);
+            VTM_REQUIRE(total + tail_max < (1ll << 31) / 16, "vtm_attention: grid too large");
+            const int xcd_pairs = (B * h) % 8 == 0 ? (int)(B * h / 8) : 0;
+            hipLaunchKernelGGL(attention16_plan_kernel, dim3(1), dim3(64), 0, s, q_count, (int)B, (int)h, QB, slots,
+                               (int)vtm::cdiv(Mk, KV), plan);
+            hipLaunchKernelGGL((attention_kernel<T, D, FOLD>), dim3((unsigned)(total + tail_max)), dim3(WAVES * 64), lds, s,
+                               (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
+                               scale_log2e_, B / share_groups, nqb_max, total, 1, records, xcd_pairs, q_count, (int64_t)0, k_count,
+                               k_bias, ldkb, (const DevPlan *)plan);
+            hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)plan_split_items(slots)), dim3(WAVES * 64), 0, s,
+                               (const float *)records, (T *)out, ldo, h, M, Mp, nqb_max, total, 1, xcd_pairs, q_count,
+                               (const DevPlan *)plan);
+            return vtm::launch_status("vtm_attention");
+        }
+    }
     TailPlan p = plan_tail<D>(B, h, M, Mk, q_count != nullptr);
     if (p.split_all && (!ws || ws_bytes < p.ws_bytes)) p = plan_tail<D>(B, h, M, Mk);   // not enough workspace: the plain plan
     if (p.nsplit > 1 && (!ws || ws_bytes < p.ws_bytes)) {   // no workspace: plain single launch
@@ -681,7 +753,7 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
     hipLaunchKernelGGL((attention_kernel<T, D, FOLD>), dim3((unsigned)(p.full + rem * p.nsplit)), dim3(WAVES * 64), lds, s,
                        (const T *)q, ldq, (const T *)k, ldk, (const T *)vt, ldvt, (T *)out, ldo, h, M, Mp, Mk, Mkp,
                        scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)ws, xcd_groups, q_count,
-                       p.split_all ? rem : (int64_t)0, k_count, k_bias, ldkb);
+                       p.split_all ? rem : (int64_t)0, k_count, k_bias, ldkb, (const DevPlan *)nullptr);
     // (few items: their accumulator groups are shared out, attention_combine_parts_kernel)
     bool parts = !pv16_for(D) && rem * 4 <= vtm::device_cus() && acc_floats(D) % 8 == 0;
     static const bool no_parts = getenv("VTM_DEBUG_COMBINE_PARTS") != nullptr;   // A/B hook, read once per process
@@ -695,7 +767,8 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
         }
         if (!parts)
             hipLaunchKernelGGL((attention_combine_kernel<T, D>), dim3((unsigned)rem), dim3(WAVES * 64), 0, s,
-                               (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups, q_count);
+                               (const float *)ws, (T *)out, ldo, h, M, Mp, p.nqb, p.full, p.nsplit, xcd_groups, q_count,
+                               (const DevPlan *)nullptr);
     }
     return vtm::launch_status("vtm_attention");
 }
@@ -773,8 +846,8 @@ VTM_EXPORT size_t vtm_attention_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64
     if (B <= 0 || h <= 0 || Mq <= 0 || Mk <= 0) return 0;
     switch (d) {
         case 40: return std::max(plan_tail<40>(B, h, Mq, Mk).ws_bytes, ws16_max(B, h, Mq, Mk, false));
-        case 64: return std::max(plan_tail<64>(B, h, Mq, Mk).ws_bytes, shape32g_for(64, 1, Mk) ? ws_bytes32g(64, B, h, Mq, Mk, false) : (size_t)0);
-        case 80: return std::max(plan_tail<80>(B, h, Mq, Mk).ws_bytes, shape32g_for(80, 1, Mk) ? ws_bytes32g(80, B, h, Mq, Mk, false) : (size_t)0);
+        case 64: return plan_tail<64>(B, h, Mq, Mk).ws_bytes;
+        case 80: return plan_tail<80>(B, h, Mq, Mk).ws_bytes;
         case 160: return plan_tail<160>(B, h, Mq, Mk).ws_bytes;
         case 8: return plan_tail<8>(B, h, Mq, Mk).ws_bytes;
         case 16: return plan_tail<16>(B, h, Mq, Mk).ws_bytes;
@@ -788,15 +861,15 @@ VTM_EXPORT size_t vtm_attention_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64
 VTM_EXPORT size_t vtm_attention_kv_bounded_ws_bytes(int64_t B, int64_t h, int64_t Mq, int64_t Mk, int64_t d) {
     if (B <= 0 || h <= 0 || Mq <= 0 || Mk <= 0) return 0;
     switch (d) {
-        case 40: return std::max(plan_tail<40>(B, h, Mq, Mk, true).ws_bytes, ws16_max(B, h, Mq, Mk, true));
-        case 64: return std::max(plan_tail<64>(B, h, Mq, Mk, true).ws_bytes, shape32g_for(64, 1, Mk) ? ws_bytes32g(64, B, h, Mq, Mk, true) : (size_t)0);
-        case 80: return std::max(plan_tail<80>(B, h, Mq, Mk, true).ws_bytes, shape32g_for(80, 1, Mk) ? ws_bytes32g(80, B, h, Mq, Mk, true) : (size_t)0);
-        case 160: return plan_tail<160>(B, h, Mq, Mk, true).ws_bytes;
-        case 8: return plan_tail<8>(B, h, Mq, Mk, true).ws_bytes;
-        case 16: return plan_tail<16>(B, h, Mq, Mk, true).ws_bytes;
-        case 32: return plan_tail<32>(B, h, Mq, Mk, true).ws_bytes;
-        case 96: return plan_tail<96>(B, h, Mq, Mk, true).ws_bytes;
-        case 128: return plan_tail<128>(B, h, Mq, Mk, true).ws_bytes;
+        case 40: return std::max(std::max(plan_tail<40>(B, h, Mq, Mk, true).ws_bytes, devplan_ws<40>(Mk)), ws16_max(B, h, Mq, Mk, true));
+        case 64: return std::max(plan_tail<64>(B, h, Mq, Mk, true).ws_bytes, devplan_ws<64>(Mk));
+        case 80: return std::max(plan_tail<80>(B, h, Mq, Mk, true).ws_bytes, devplan_ws<80>(Mk));
+        case 160: return std::max(plan_tail<160>(B, h, Mq, Mk, true).ws_bytes, devplan_ws<160>(Mk));
+        case 8: return std::max(plan_tail<8>(B, h, Mq, Mk, true).ws_bytes, devplan_ws<8>(Mk));
+        case 16: return std::max(plan_tail<16>(B, h, Mq, Mk, true).ws_bytes, devplan_ws<16>(Mk));
+        case 32: return std::max(plan_tail<32>(B, h, Mq, Mk, true).ws_bytes, devplan_ws<32>(Mk));
+        case 96: return std::max(plan_tail<96>(B, h, Mq, Mk, true).ws_bytes, devplan_ws<96>(Mk));
+        case 128: return std::max(plan_tail<128>(B, h, Mq, Mk, true).ws_bytes, devplan_ws<128>(Mk));
     }
     return 0;
 }
@@ -822,11 +895,6 @@ static int attention_any(const void *q, int64_t ldq, const void *k, int64_t ldk,
                            q_count, s, false, nullptr, nullptr, 0};
             return attention16(a, sh);
         }
-    }
-    if ((dtype == VTM_F16 || dtype == VTM_BF16) && shape32g_for(d, share_groups, Mk)) {
-        const Args16 a{q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws, ws_bytes,
-                       q_count, s, false, nullptr, nullptr, 0};
-        return attention32g(a, d);
     }
     if (dtype == VTM_F16)
         return dispatch<__half>(d, q, ldq, k, ldk, vt, ldvt, out, ldo, B, h, Mq, Mqp, Mk, Mkp, scale, share_groups, ws,

@@ -901,7 +901,8 @@ int launch16(const Args16 &a) {
         // query-bounded: planned on the device (attention16_plan_kernel) when the workspace holds the plan and its records
         const int slots = vtm::device_cus() * wg_cu;
         const size_t need = devplan_ws_bytes(slots, rec_bytes);
-        if (a.q_count != nullptr && a.ws != nullptr && a.ws_bytes >= need && devplan_enabled()) {
+        if (a.q_count != nullptr && a.ws != nullptr && a.ws_bytes >= need && devplan_enabled() &&
+            nqb_max * a.h * B_items >= 2 * slots) {      // (at least two rounds: a plan costs 50-70 us of small launches)
             DevPlan *plan = reinterpret_cast<DevPlan *>(a.ws);
             float *records = reinterpret_cast<float *>(static_cast<char *>(a.ws) + DEVPLAN_HEADER);
             const int ntiles = (int)vtm::cdiv(a.Mk, KV);

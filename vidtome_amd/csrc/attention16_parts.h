@@ -19,7 +19,8 @@ template <int D> constexpr int rec16() { return (D + 16) / 16 * 8 + 2 + 1; }
 // GEOMETRIC tail: workgroups are dispatched in index order as slots free up, so pieces that shrink towards the end of the
 // grid pack like longest-first list scheduling and the idle tail is one SMALLEST piece long:
 //   L live items (the longest sample's blocks x heads x samples), S slots;
-//   tier 0: the items of the whole rounds, L - L % S of them, one workgroup each;
+//   tier 0: the items of the whole rounds, L - L % S of them, one workgroup each (a last round >= 0.8 full, or the only round of a
+//   launch that fills more than half of the chip, counts as whole);
 //   then, while items remain: the next tier takes S / n of them (or what is left), n = the smallest power of two >= 2 with
 //   S / n <= remaining (at most MAX_SPLIT), each split n ways along the key axis -- S pieces, one short round.
 // 912 items on 256 slots: 768 whole, 128 in halves, 16 in sixteenths = 3 + 0.5 + 1/16 rounds -- the work there is.  The
@@ -52,7 +53,10 @@ __global__ void attention16_plan_kernel(const int32_t *__restrict__ q_count, int
     p.nqb = nqb;
     p.pad = 0;
     int nt = 0, wg = 0, item = 0, rec = 0;
-    const int whole = max_ns < 2 ? L : L - L % S;
+    // what runs whole: the full rounds; ALSO a last round that is at least 0.8 full, or the one round of a launch that fills
+    // more than half of the chip (splitting those moves more partial records than the idle slots are worth)
+    int whole = L - L % S;
+    if (max_ns < 2 || (L % S) * 5 >= S * 4 || (L < S && L * 2 > S)) whole = L;
     p.tier[nt++] = DevTier{0, 0, whole, 1, 0};
     wg = item = whole;
     while (item < L && nt < PLAN_TIERS) {

@@ -192,9 +192,6 @@ int attention16(const Args16 &a, const Shape16 &sh);
 // attention16g.hip: shared probabilities (ng = 2, 3 value groups), one-tile skew
 size_t ws_bytes16g(int ng, int64_t src_batch, int64_t h, int64_t Mq, int64_t Mk);
 int attention16g(const Args16 &a, int ng);
-// attention32g.hip: d = 64 / 80 self-attention, one-tile skew
-bool shape32g_for(int64_t d, int share_groups, int64_t Mk);
-size_t ws_bytes32g(int64_t d, int64_t B, int64_t h, int64_t Mq, int64_t Mk, bool bounded);
-int attention32g(const Args16 &a, int64_t d);
+
 
 }  // namespace vtm_att
