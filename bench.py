@@ -463,12 +463,15 @@ def pmc_traffic():
     x 52 224 keys).  NOT measured in this run: read from the committed rocprofv3 PMC passes under profiles/
     (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, separate --pmc runs of tools/kbench.py on the same shape).
     Returns (bytes or None, source string)."""
-    for fname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json",
+                  "r01_pmc_traffic.json"):
         d, src = _profile_json(fname)
         if not d:
             continue
         for key in sorted(d, reverse=True):
-            if key.startswith("attention_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224") and "hbm_bytes_per_launch" in d[key]:
+            # (round 6: the bench's d = 40 launches are attention16s_kernel; older profiles hold attention_kernel's)
+            if key.split("<")[0] in ("attention16s_kernel", "attention_kernel") and "<half,40> B=2 h=8 Mq=34816 Mk=52224" in key \
+                    and "hbm_bytes_per_launch" in d[key]:
                 return int(d[key]["hbm_bytes_per_launch"]), f"profiles/{src}: {key} (rocprofv3 --pmc, not this run)"
     return None, None
 
@@ -477,7 +480,7 @@ def pmc_gather_path():
     """Counter-derived HBM rates of the gather-path kernels at working sets beyond the 256 MB Infinity Cache
     (profiles/r02_pmc_traffic.json, section "gather_path"); None when the profile is absent."""
     d = src = None
-    for fname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for fname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         d, src = _profile_json(fname)
         if d and "gather_path" in d:
             break
@@ -889,8 +892,9 @@ def main():
             # dominant single kernel of the step: the merged-token self-attention (MFMA-bound)
             # `achieved` counts EXECUTED flops (4 B Mq Mk C per launch): with a global level the block only computes the
             # attention rows unmerge() reads, so the reference-algorithmic 4 B M^2 C would overstate the kernel
-            "roofline": {"kernel": "attention_kernel<half,d> (flash attention over merged tokens, "
-                                   "v_mfma_f32_32x32x16_f16; executed flops)",
+            "roofline": {"kernel": "attention16s_kernel<half,40> / attention16g_kernel (d = 40: 64-query wave tile, skewed in-wave "
+                                   "pipeline; shared probabilities computed once) + attention_kernel<half,d> (d = 80, 64, 160): flash "
+                                   "attention over merged tokens, v_mfma_f32_32x32x16_f16 / 16x16x32; executed flops",
                          "bound": "mfma", "achieved": round(att_tf, 1), "peak": FP16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(att_tf / FP16_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,

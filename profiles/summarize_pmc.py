@@ -35,7 +35,8 @@ sq = {"_how": "rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_
 traffic = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python "
                    "tools/kbench.py ... (tools/gpu_session.sh); KiB; hbm_read_bytes = 2 * FETCH_SIZE * 1024 (gfx950), WRITE_SIZE matched the "
                    "written bytes exactly in the three gather-path kernels (calibration)"}
-for nm, kern, label, alg in (("attn", "attention_kernel", "attention_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224", 2 * (34816 + 52224) * 320 * 2 * 2),
+# (round 6: the d = 40 launch of the bench is attention16s_kernel -- csrc/attention16.hip -- since VTM_ATT16 defaults to on)
+for nm, kern, label, alg in (("attn", "attention16s_kernel", "attention16s_kernel<half,40> B=2 h=8 Mq=34816 Mk=52224", 2 * (34816 + 52224) * 320 * 2 * 2),
                              ("match", "filter_kernel", "filter_kernel top_l1 (B=2 Ns=49152 Nd=16384 C=320)", 83886080),
                              # round 3: the GEGLU projection of the cfg-2 top site (131 072 tokens, C = 320 -> 2 x 1280, gated
                              # activation in the epilogue): panels in (84 MB + 1.6 MB of weights), panels out (336 MB)
