@@ -2443,6 +2443,31 @@ def test_attention_bounded_equals_unbounded_prefix(L, monkeypatch):
         assert torch.equal(got[b, :n], full[b, :n]), b
 
 
+@pytest.mark.parametrize("d,h", [(40, 8), (64, 5), (80, 8)])
+def test_attention_device_planned_tail_every_live_fraction(L, d, h):
+    """Round 6: a query-bounded launch of two or more rounds of workgroups is planned on the device from the live counts
+    (attention16_plan_kernel: whole items, then tiers split 2 / 4 / 8 / 16 ways along the key axis; csrc/attention16_parts.h) --
+    by attention16s_kernel at d = 40 and by attention_kernel at every other head dim.  Whatever the counts make of the plan
+    (no tail, one tier, several, a launch that no longer fills the chip; different counts per sample), every row below its
+    sample's count must equal the plain launch's row within the tolerance of another summation order.  vidtome/patch.py:157-162
+    on the rows merge.py:439-460 reads."""
+    B, Mk = 2, 2100                                     # 33 key tiles: pieces of >= 8 tiles, up to 4-way splits
+    Mq = 32768 if d != 64 else 53248                    # x B x h >= 2 x 256 slots of 512-query items in every instantiation
+    C = h * d
+    g = torch.Generator(device=DEV).manual_seed(13)
+    q = torch.randn(B, Mq, C, generator=g, device=DEV, dtype=torch.float16)
+    k = torch.randn(B, (Mk + 7) // 8 * 8, C, generator=g, device=DEV, dtype=torch.float16)
+    vt = torch.randn(B, C, (Mk + 7) // 8 * 8, generator=g, device=DEV, dtype=torch.float16)
+    full = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5)
+    scale = float(full.float().abs().max())
+    for f0, f1 in ((1.0, 1.0), (0.97, 0.9), (0.83, 0.83), (0.56, 0.7), (0.5, 0.25), (0.26, 0.3), (0.05, 0.02), (0.001, 0.6)):
+        count = torch.tensor([max(1, int(Mq * f0)), max(1, int(Mq * f1))], dtype=torch.int32, device=DEV)
+        got = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5, q_count=count)
+        for b, n in enumerate(count.tolist()):
+            assert torch.isfinite(got[b, :n]).all(), (d, f0, f1, b)
+            assert (got[b, :n].float() - full[b, :n].float()).abs().max() < 2e-3 * scale, (d, f0, f1, b)
+
+
 def test_attention_bounded_split_all_vs_plain(L, monkeypatch):
     """A query-bounded launch that fills at least two rounds of the chip splits EVERY work item in two along the key axis
     (split-major order, partial records merged by attention_combine_kernel): its rows below the per-sample count must
