@@ -774,7 +774,8 @@ int launch(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *v
 }
 
 // Which d = 40 launches go to the wide-tile kernel of attention16.hip, and in which shape (round 6).  VTM_ATT16=0 keeps
-// everything on attention_kernel; VTM_ATT16_NQ / VTM_ATT16_WAVES are A/B hooks for the plain (one value group) shape.  Read
+// everything on attention_kernel; VTM_ATT16_NQ=1 does the same for the plain (one value group) shape only, VTM_ATT16_SKEW=0
+// selects the un-skewed kernels (4-wave workgroups were measured 18 % slower -- register spills -- and are not built).  Read
 // once per process.  Both kernels compute the same sums in the same per-tile order for a query (the split plans differ),
 // so results agree to the tolerance of the key-split combine, not bit for bit.
 struct Policy16 {
@@ -787,7 +788,6 @@ const Policy16 &policy16() {
         if (const char *e = getenv("VTM_ATT16")) v.on = atoi(e) != 0;
         if (const char *e = getenv("VTM_ATT16_SKEW")) v.skew = atoi(e) != 0;
         if (const char *e = getenv("VTM_ATT16_NQ")) v.nq = atoi(e) == 1 ? 1 : 2;
-        if (const char *e = getenv("VTM_ATT16_WAVES")) v.waves = atoi(e) == 4 ? 4 : 8;
         if (v.nq == 1) v.waves = 8;
         return v;
     }();

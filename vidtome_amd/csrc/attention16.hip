@@ -954,12 +954,8 @@ int dispatch16(const Args16 &a, const Shape16 &sh) {
         return launch16<T, 40, FOLD_, NQ_, NG_, W_, SK_>(a)
     VTM_A16(false, 2, 1, 8, true);
     VTM_A16(true, 2, 1, 8, true);
-    VTM_A16(false, 2, 1, 4, true);
-    VTM_A16(true, 2, 1, 4, true);
     VTM_A16(false, 2, 1, 8, false);
     VTM_A16(true, 2, 1, 8, false);
-    VTM_A16(false, 2, 1, 4, false);
-    VTM_A16(true, 2, 1, 4, false);
     VTM_A16(false, 1, 3, 8, false);
     VTM_A16(false, 1, 2, 8, false);
 #undef VTM_A16
