@@ -2466,6 +2466,22 @@ def test_attention_device_planned_tail_every_live_fraction(L, d, h):
         for b, n in enumerate(count.tolist()):
             assert torch.isfinite(got[b, :n]).all(), (d, f0, f1, b)
             assert (got[b, :n].float() - full[b, :n].float()).abs().max() < 2e-3 * scale, (d, f0, f1, b)
+        # the plan the launch ran on sits in the first 256 bytes of the call's workspace (csrc/attention16_parts.h: DevPlan =
+        # {nqb, ntiers, split_items, pad, 8 x {wg0, item0, items, nsplit, rec0}}): its invariants, whatever the counts
+        ws = L._workspace("attention", 256, q.device)
+        plan = ws[:176].view(torch.int32).cpu().tolist()
+        nqb, ntiers, split_items = plan[0], plan[1], plan[2]
+        tiers = [plan[4 + 5 * i: 9 + 5 * i] for i in range(8)]
+        QB, slots = 512, 256
+        assert nqb == max(-(-int(c) // QB) for c in count.tolist()), (d, f0, f1, plan)
+        items_total = nqb * h * B
+        assert 1 <= ntiers <= 8 and sum(t[2] for t in tiers[:ntiers]) == items_total, (d, f0, f1, plan)
+        assert tiers[0][:2] == [0, 0] and tiers[0][3] == 1 and split_items == items_total - tiers[0][2], (d, f0, f1, plan)
+        wg, item, rec = tiers[0][2], tiers[0][2], 0
+        for t in tiers[1:ntiers]:
+            assert t[0] == wg and t[1] == item and t[4] == rec and 2 <= t[3] <= 4 and t[2] > 0, (d, f0, f1, plan)   # 33 key tiles: <= 4 pieces
+            wg, item, rec = wg + t[2] * t[3], item + t[2], rec + t[2] * t[3]
+        assert rec <= 7 * slots and split_items <= slots, (d, f0, f1, plan)
 
 
 def test_attention_bounded_split_all_vs_plain(L, monkeypatch):
