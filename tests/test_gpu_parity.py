@@ -489,6 +489,36 @@ def test_match_position_ordered_equals_exact(L):
                     assert torch.equal(got, ex), (regime, mode)
 
 
+@pytest.mark.parametrize("scale", [1e-25, 2e-21, 3e-20, 1e15])
+def test_match_filtered_seeds_of_tiny_tokens_with_all_negative_scores(L, scale):
+    """the seed of a row is (a . b) / |a| / |b| in fp32.  With fp32 tokens around 2e-21 the norms (~2^-65) are
+    still "usable" (>= 2^-100) but the dot product of two rows (~1e-39) is a denormal with no relative accuracy, or 0 -- and 0 would be published as a CERTIFIED running maximum above a row whose real scores are all negative, after
+    which the filter's window and the escape's tile pruning discard the true argmax.  Round 6 publishes a seed only when the dot
+    product itself is a normal number (or both norms are >= 2^-40).  Here every cosine is about -0.98 (all tokens = +-(one common
+    vector + noise)), the same-position seeds included: filtered (seeded, both launch plans) == exact, bit for bit; the other
+    scales check that ordinary small / large magnitudes keep their seeds working."""
+    g = torch.Generator().manual_seed(44)
+    B, F, N, C, fs = 2, 4, 512, 320, 3
+    common = torch.randn(B, 1, 1, C, generator=g)
+    x = common + 0.1 * torch.randn(B, F, N, C, generator=g)
+    x[:, fs:] = -x[:, fs:]                                   # the dst frame: every src . dst is negative
+    x = (x * scale).reshape(B, F * N, C).float().to(DEV)
+    Ns, Nd = fs * N, (F - fs) * N
+    ra = torch.arange(Ns, dtype=torch.int32, device=DEV).expand(B, Ns).contiguous()
+    rb = torch.arange(Ns, Ns + Nd, dtype=torch.int32, device=DEV).expand(B, Nd).contiguous()
+    a_op, _ = L.normalize_gather(x, None, ra)
+    b_op, _ = L.normalize_gather(x, None, rb)
+    exact = L.match(a_op, b_op, Ns, Nd, False)
+    nm, _ = L.decode_best(exact)
+    if scale > 1e-24:        # (1e-25: every x^2 underflows, every norm is 0 and every score NaN -- in the reference too; 2e-21: the
+        # squares and the dot products are denormals, norms ~2^-65: the case the guard is for)
+        assert float(nm.max()) < -0.5, float(nm.max())      # the premise: all maxima are negative
+    for mode in (L.MATCH_ONE_LAUNCH, L.MATCH_SCOUT_RANGE):
+        got = L.match_filtered(x, None, ra, rb, False, seed=(N, F * N, None, None), mode=mode)
+        assert torch.equal(got, exact), (scale, mode)
+    assert torch.equal(L.match_filtered(x, None, ra, rb, False), exact)
+
+
 def test_match_planner_steers_by_the_previous_calls_counters(L):
     """merge.MatchPlanner: a scout + range call copies its counters into the planner's pinned buffer (no synchronisation in
     the product path; the test synchronises to look); uncorrelated tokens (every wave tile alive) send the block's first level
