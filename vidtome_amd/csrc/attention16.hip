@@ -873,7 +873,7 @@ static_assert(sizeof(DevPlan) <= 256, "the plan lives in the workspace header");
 size_t devplan_ws_bytes(int slots, size_t rec_bytes) { return DEVPLAN_HEADER + (size_t)plan_tail_wgs(slots) * rec_bytes; }
 bool devplan_enabled() {
     static const bool on = [] {
-        const char *e = getenv("VTM_ATT16_DEVPLAN");      // A/B hook, read once per process
+        const char *e = getenv("VTM_ATT_DEVPLAN");        // A/B hook, read once per process (attention.hip reads the same name)
         return e == nullptr || atoi(e) != 0;
     }();
     return on;
