@@ -152,7 +152,7 @@ def main():
         fl = 4.0 * B * live * M * C
         print(f"attention B={B} Mq={Mq} Mk={M} h={h} d={d} share={G} bounded={a.bounded}: median {med:.3f} ms ({fl / med / 1e9:.1f} "
               f"TFLOP/s), best {best:.3f} ms ({fl / best / 1e9:.1f} TFLOP/s)   [VTM_ATT16={os.environ.get('VTM_ATT16', '')} "
-              f"SKEW={os.environ.get('VTM_ATT16_SKEW', '')} DEVPLAN={os.environ.get('VTM_ATT_DEVPLAN', '')}{os.environ.get('VTM_ATT_DEVPLAN', '')}]")
+              f"SKEW={os.environ.get('VTM_ATT16_SKEW', '')} DEVPLAN={os.environ.get('VTM_ATT_DEVPLAN', '')}]")
         if a.power:                      # ms AND joules: back-to-back launches for ~a.power seconds under the sysfs sampler of bench.py
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             from bench import BoxSampler
