@@ -132,6 +132,11 @@ def parse():
                     help="N = 1 headline run: secondary workloads appended to the line as `workloads` (each in a child process "
                          "of this script): all | none | comma list of cfg3,cfg5,full_block")
     ap.add_argument("--workload-steps", type=int, default=10, help="timed passes per secondary workload")
+    ap.add_argument("--no-inflight-line", dest="inflight_line", action="store_false",
+                    help="N = 1: skip the secondary `two_in_flight` region (two chunks on two HIP streams)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="N = 1 A/B: run the HEADLINE region with this many chunks in flight (the line then says so in "
+                         "config.parallelism; the default line keeps `value` on one stream)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
                     help="cfg2 = the headline configuration; cfg3 / cfg5 = secondary lines (BASELINE.json configs[2] / [4])")
     ap.add_argument("--exchange-modes", default="all",
@@ -680,7 +685,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_region(regime, steps, warmup, xmode, with_box):
+    def run_region(regime, steps, warmup, xmode, with_box, inflight=1):
         """One measured region: a fresh chunk stream of `regime`, anchors populated, `warmup` untimed and `steps` timed passes
         between two fences (barrier + synchronize), HIP events on every `every`-th pass, one extra untimed pass for the
         matcher's device-side counters.  Returns everything the line is built from."""
@@ -714,7 +719,7 @@ def main():
                                   chunks_per_step=args.chunks_per_step, same_chunk=args.same_chunk, rank=rank,
                                   reseed=ex is None, regime=regime, gen_device=dev,
                                   sets=None if ex is None else {(p_ * world + rank) % K for p_ in range(total_passes)},
-                                  cond=cond)
+                                  cond=cond, inflight=inflight if ex is None else 1)
         passes = [0]
 
         def step():
@@ -794,7 +799,7 @@ def main():
                 "pruned_block_fraction": cnt.get("pruned_block_fraction"),
                 "executed_mfma_fraction": cnt.get("executed_mfma_fraction")}
 
-    head = run_region(args.data, args.steps, args.warmup, mode, True)
+    head = run_region(args.data, args.steps, args.warmup, mode, True, inflight=max(1, args.inflight) if world == 1 else 1)
     mt, dt, box = head["mt"], head["dt"], head["box"]
     timed_passes, total_passes, event_pass_ms = head["timed_passes"], head["total_passes"], head["event_pass_ms"]
     aflops, ams, an = mt.summary("attention")
@@ -840,13 +845,15 @@ def main():
         comp_sum = sum(comp.values())
         side = comp_sum - comp.get("attention", 0.0) - comp.get("matching", 0.0) - comp.get("position_order", 0.0)
 
-        par = f"chunk-parallel x{world}"
+        par = f"chunk-parallel x{world}" + (f", {args.inflight} chunks in flight on {args.inflight} HIP streams (NOT the default line)"
+                                            if world == 1 and args.inflight > 1 else "")
         if mode is not None:
             par += {"neighbour": ", anchor tokens = the previous rank's local merged tokens, point-to-point over RCCL/xGMI "
                                  "per merging block",
                     "allgather": ", RCCL all-gather of the composed merge maps per merging block, tokens point-to-point",
                     "ring": ", exact serial anchor chain (ring hand-off over RCCL/xGMI)"}[mode]
-        headline = args.workload == "cfg2" and FRAMES == 16 and not args.full_block and not args.local_only
+        headline = args.workload == "cfg2" and FRAMES == 16 and not args.full_block and not args.local_only and \
+            not (world == 1 and args.inflight > 1)
         line = {
             "metric": "denoising steps/sec, 16-frame 512x512 SD-1.5 chunk, ratio=0.5" +
                       (" -- FULL transformer blocks (secondary measurement, not the headline)" if args.full_block else "") +
@@ -1001,6 +1008,23 @@ def main():
             worst = min(named, key=named.get)
             line["value_worst_named"] = {"value": named[worst], "unit": "steps/s", "regime": worst, "both": named}
 
+    # ---- N = 1: two chunks in flight on two HIP streams (round 6) ----
+    # Same chunk stream, same anchor chain, same results (tests/test_gpu_parity.py::test_two_chunks_in_flight_equal_one_stream):
+    # chunk c runs on stream c % 2, on the device chunk c + 1 waits block by block for chunk c's anchors (patch.mark_anchors_ready /
+    # await_anchors).  The dispatch gaps and the ~400 small launches of one chunk then run beside the other chunk's big kernels.
+    # `value` stays the ONE-stream number (like for like with rounds 1-5); this is what a video of several chunks per denoising
+    # step gets on one GPU.
+    if world == 1 and mode is None and rank == 0 and args.inflight_line and args.workload == "cfg2" and not args.local_only:
+        try:
+            r2 = run_region(args.data, args.steps, args.warmup + 2, None, False, inflight=2)
+            c2 = compact(r2)
+            line["two_in_flight"] = {"steps_per_s": c2["steps_per_s"], "ms_per_chunk_step": c2["ms_per_step"], "steps": c2["steps"],
+                                     "streams": 2, "vs_value": round(c2["steps_per_s"] / line["value"], 4),
+                                     "note": "chunk c on HIP stream c % 2; anchors handed over by device-side events; results "
+                                             "bit-identical to the one-stream run; `value` is NOT this number"}
+        except Exception as e:                       # a secondary line must never take the headline with it
+            line["two_in_flight"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # ---- N = 1 headline run: the other single-GPU BASELINE configurations, driver-timed ----
     if world == 1 and mode is None and rank == 0 and args.workloads != "none" and args.workload == "cfg2" \
             and not args.full_block and not args.local_only and FRAMES == 16:
@@ -1014,7 +1038,7 @@ def main():
             if w not in ("cfg3", "cfg5", "full_block"):
                 raise SystemExit(f"bench.py: unknown secondary workload {w!r}")
             cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.workload_steps), "--warmup", "3",
-                   "--no-cpu-baseline", "--regimes", "none", "--workloads", "none", "--data", args.data] + \
+                   "--no-cpu-baseline", "--regimes", "none", "--workloads", "none", "--no-inflight-line", "--data", args.data] + \
                   (["--full-block"] if w == "full_block" else ["--workload", w])
             t0 = time.perf_counter()
             try:

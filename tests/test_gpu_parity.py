@@ -2574,6 +2574,42 @@ def test_live_queries_equal_full_attention(L, F, global_rand):
             assert (a - b).abs().max() <= 2e-3 * max(1.0, float(b.abs().max()))
 
 
+def test_two_chunks_in_flight_equal_one_stream(L):
+    """Round 6: consecutive chunks may run on different HIP streams (bench.py `two_in_flight`; sites.ClipStream(inflight=2)).  The
+    anchors chunk k + 1 takes from chunk k (patch.py:60-82) are handed over by a device-side event the producer records behind
+    them (patch.mark_anchors_ready / await_anchors); everything else a chunk touches is its own (workspaces are keyed by
+    stream).  Six steady-state chunks of a top, a mid and an un-merged site through one stream and through two: block outputs
+    and the anchors left behind bit-identical, generators in the same state."""
+    import vidtome_amd
+    from vidtome_amd import sites as S
+    B, F, latent = 2, 8, (32, 32)
+    sl = [S.Site("up3.0", 1, 320, 8), S.Site("up2.0", 2, 640, 8), S.Site("up1.0", 4, 1280, 8)]
+    res = {}
+    for inflight in (1, 2):
+        unet = S.SiteUNet(sl, seed=5).to(device=DEV, dtype=torch.float16)
+        vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B)
+        unet.set_size(latent)
+        torch.manual_seed(123)
+        stream = S.ClipStream(unet, sl, B, F, latent, torch.float16, torch.device(DEV, 0), n_sets=3, chunks_per_step=4,
+                              regime="corr01", inflight=inflight)
+        stream.populate()
+        torch.cuda.synchronize()
+        outs = [stream.step(c) for c in range(6)]                 # (no synchronisation between the chunks)
+        torch.cuda.synchronize()
+        res[inflight] = ([[o.float().cpu() for o in oc] for oc in outs],
+                         [b.global_tokens.float().cpu() for b in unet.blocks if getattr(b, "global_tokens", None) is not None],
+                         [b.generator.get_state() for b in unet.blocks if hasattr(b, "generator")])
+        vidtome_amd.remove_patch(unet)
+    for oa, ob in zip(res[1][0], res[2][0]):
+        for a, b in zip(oa, ob):
+            assert torch.equal(a, b)
+    assert len(res[1][1]) == len(res[2][1]) > 0
+    for a, b in zip(res[1][1], res[2][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[1][2], res[2][2]):
+        assert torch.equal(a, b)
+
+
 def test_projection_paths_agree(L):
     """The patched segment with its projections fed through the composed merge map (vtm_linear_rows), as panel GEMMs
     (vtm_gather_panels / vtm_layernorm_panels + vtm_linear_panels) and in the default mix of the two ("auto": rows at

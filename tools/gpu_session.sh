@@ -10,12 +10,12 @@ cd $R
 python -m pytest tests -m gpu -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests.log
 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-for rep in 2 3; do python bench.py --no-cpu-baseline --regimes none --workloads none > $O/bench_run$rep.json 2>> $O/bench.err; done
-python bench.py --no-cpu-baseline --regimes none --workloads none --full-block > $O/bench_full_block.json 2>> $O/bench.err; echo "bench full rc=$?"
-for wlk in cfg3 cfg5; do python bench.py --no-cpu-baseline --regimes none --workloads none --workload $wlk > $O/bench_$wlk.json 2>> $O/bench.err; done
+for rep in 2 3; do python bench.py --no-cpu-baseline --regimes none --workloads none --no-inflight-line > $O/bench_run$rep.json 2>> $O/bench.err; done
+python bench.py --no-cpu-baseline --regimes none --workloads none --no-inflight-line --full-block > $O/bench_full_block.json 2>> $O/bench.err; echo "bench full rc=$?"
+for wlk in cfg3 cfg5; do python bench.py --no-cpu-baseline --regimes none --workloads none --no-inflight-line --workload $wlk > $O/bench_$wlk.json 2>> $O/bench.err; done
 # the secondary options still run (N = 1 exchange modes in place, cfg-4's 8-frame chunk, local-only, rounds 1-2's regime)
 for opt in "--exchange neighbour" "--exchange ring" "--exchange allgather" "--frames 8" "--local-only" "--same-chunk" "--data corr05"; do
-  python bench.py --no-cpu-baseline --regimes none --workloads none --steps 8 $opt 2>> $O/bench.err | python -c "
+  python bench.py --no-cpu-baseline --regimes none --workloads none --no-inflight-line --steps 8 $opt 2>> $O/bench.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('option $opt:', d['ms_per_step'], 'ms per step,', d['value'], 'steps/s')" ; done > $O/bench_options.txt 2>&1; cat $O/bench_options.txt
 python - <<PY
@@ -28,7 +28,7 @@ for n in ("bench","bench_run2","bench_run3","bench_full_block","bench_cfg3","ben
     except Exception as e: print(n, "failed", e)
 PY
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py --steps 7 --warmup 1 --no-cpu-baseline --regimes none --workloads none > $O/prof.log 2>&1; echo "prof rc=$?"
+rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py --steps 7 --warmup 1 --no-cpu-baseline --regimes none --workloads none --no-inflight-line > $O/prof.log 2>&1; echo "prof rc=$?"
 grep '"metric"' $O/prof.log > $O/bench_profiled.json
 python $R/profiles/summarize_rocpd.py $O/prof/k_results.db > $O/kernel_stats.txt 2>&1; rm -f $O/prof/k_results.db
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc -o sq_attn --output-format csv -- python $R/tools/kbench.py attn --Mq 34816 --M 52224 --d 40 --iters 3 > $O/pmc_sq_attn.log 2>&1

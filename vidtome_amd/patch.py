@@ -123,6 +123,39 @@ def tag_content_ids(tokens: torch.Tensor, ids: torch.Tensor) -> None:
     tokens._vtm_cid = (ids, tokens._version, tokens.data_ptr(), tuple(tokens.shape))
 
 
+def mark_anchors_ready(tokens: Optional[torch.Tensor]) -> None:
+    """(round 6) Consecutive chunks may run on DIFFERENT HIP streams (two chunks in flight hide each other's dispatch gaps and
+    small launches: bench.py `two_in_flight`, +15 % chunk-steps/s on one GPU).  The anchors are the one thing chunk k + 1 takes
+    from chunk k (patch.py:60-82), so the producer leaves an event behind every anchor tensor it stores -- recorded on its
+    stream after the last kernel that writes the anchors, their token positions or their content ids."""
+    if tokens is not None and tokens.is_cuda:
+        s = torch.cuda.current_stream(tokens.device)
+        ev = torch.cuda.Event()
+        ev.record(s)
+        tokens._vtm_ready = (ev, s.cuda_stream)
+
+
+def await_anchors(tokens: Optional[torch.Tensor]) -> None:
+    """... and a consumer on another stream waits for that event ON THE DEVICE (no host synchronisation) and tells torch's
+    caching allocator that the tensors are in use on its stream too (`record_stream`: the producer's reference may be dropped
+    -- the next anchor update replaces `module.global_tokens` -- while this stream's kernels still read the old rows)."""
+    ready = getattr(tokens, "_vtm_ready", None) if tokens is not None else None
+    if ready is None or not tokens.is_cuda:
+        return
+    ev, sid = ready
+    cur = torch.cuda.current_stream(tokens.device)
+    if cur.cuda_stream == sid:
+        return
+    cur.wait_event(ev)
+    tokens.record_stream(cur)
+    pos = getattr(tokens, "_vtm_pos", None)
+    if pos is not None and pos.is_cuda:
+        pos.record_stream(cur)
+    tag = getattr(tokens, "_vtm_cid", None)
+    if tag is not None and len(tag) == 4 and tag[0].is_cuda:
+        tag[0].record_stream(cur)
+
+
 def content_ids(tokens: torch.Tensor, device, dtype) -> Optional[torch.Tensor]:
     """The ids `tag_content_ids` attached, or None when the tag is missing or stale."""
     tag = getattr(tokens, "_vtm_cid", None)
@@ -231,6 +264,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 gt = exchange.anchors_for(xkey, lambda: xj if cur is None else _lib.gather_rows(xj, None, cur), xj, cur)
             else:
                 gt = getattr(module, "global_tokens", None)
+                await_anchors(gt)              # (a predecessor chunk on another stream: device-side wait, see mark_anchors_ready)
             # token positions of the anchors (the matcher's seeds) ride on the tensor THIS function stored (an attribute of the
             # tensor object: they live and die with it); anchors that came from anywhere else (the user, an exchange) have none
             gt_pos = getattr(gt, "_vtm_pos", None) if gt is not None else None
@@ -293,6 +327,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
                 module.global_tokens = merged[:, :Ml] if merged.shape[1] != Ml else merged
                 if _lib.SEED_MATCHER:      # (cur None: a single-frame chunk, the local tokens are the chunk's rows themselves)
                     module.global_tokens._vtm_pos = _lib.anchor_pos(cur, B, Ml, L, tsize, None, xj.device)
+            mark_anchors_ready(getattr(module, "global_tokens", None))
             if exchange is not None:
                 exchange.publish(xkey, module.global_tokens)
 

@@ -268,8 +268,13 @@ class ClipStream:
 
     def __init__(self, unet: "SiteUNet", site_list: List[Site], batch: int, frames: int, latent_hw: Tuple[int, int], dtype,
                  device, n_sets: int = 3, chunks_per_step: int = 8, same_chunk: bool = False, rank: int = 0,
-                 reseed: bool = True, sets=None, cond: torch.Tensor = None, regime: str = None, gen_device=None):
+                 reseed: bool = True, sets=None, cond: torch.Tensor = None, regime: str = None, gen_device=None,
+                 inflight: int = 1):
         self.unet, self.site_list = unet, site_list
+        # `inflight` chunks at a time: chunk c is issued on HIP stream c % inflight (the host issues whole chunks in order; on the
+        # device chunk c + 1 waits block by block for chunk c's anchors -- patch.mark_anchors_ready / await_anchors), so the
+        # dispatch gaps and the small launches of one chunk run beside the big kernels of the other.  Same results as one stream.
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(inflight)] if inflight > 1 else None
         self.cond = cond                      # not None: full-block passes (run_block_pass)
         self.K = 1 if same_chunk else max(2, n_sets)
         self.same_chunk = same_chunk
@@ -314,7 +319,10 @@ class ClipStream:
                 b.global_tokens = a
         self.steady += 1
         with torch.no_grad():
-            return self._run(self.sets[j])
+            if self.streams is None:
+                return self._run(self.sets[j])
+            with torch.cuda.stream(self.streams[chunk % len(self.streams)]):
+                return self._run(self.sets[j])
 
     def _run(self, hiddens):
         return run_segment_pass(self.unet, hiddens) if self.cond is None else run_block_pass(self.unet, hiddens, self.cond)
