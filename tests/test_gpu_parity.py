@@ -2610,6 +2610,54 @@ def test_two_chunks_in_flight_equal_one_stream(L):
         assert torch.equal(a, b)
 
 
+def test_run_step_with_streams_equals_the_sequential_loop(L):
+    """scheduler.run_step(..., streams=[s0, s1]) (round 6): the chunks of a denoising step issued on alternating HIP streams, in
+    the reference's order (generate.py:215-219), COLD caches included (the first chunks build the packed weights and the
+    workspaces the next chunk's stream reads).  Chunk lengths as the reference draws them (a random first chunk, 1 .. 4
+    frames: single-frame chunks have no local level).  Outputs of every chunk, the anchors and the generator states equal the
+    sequential loop's bit for bit; the anchors are reset after the step either way (generate.py:233-236)."""
+    import vidtome_amd
+    from vidtome_amd import scheduler as sch
+    from vidtome_amd import sites as S
+    B, latent, n_frames = 2, (32, 32), 14
+    sl = [S.Site("up3.0", 1, 320, 8), S.Site("up2.0", 2, 640, 8)]
+    res = {}
+    for use_streams in (False, True):
+        unet = S.SiteUNet(sl, seed=6).to(device=DEV, dtype=torch.float16)
+        vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B)
+        unet.set_size(latent)
+        np.random.seed(3)
+        torch.manual_seed(3)
+        sc = sch.ChunkScheduler(chunk_size=4, merge_global=True, chunk_ord="seq")
+        outs, anchors = {}, {}
+
+        def process(chunk):
+            F, f0 = len(chunk), int(chunk[0])
+            hs = [S.synthetic_hidden(s_, B, F, latent, torch.float16, DEV, seed=500 + f0 + 31 * i, clip_seed=9 + i, regime="corr01")
+                  for i, s_ in enumerate(sl)]
+            with torch.no_grad():
+                outs[f0] = S.run_segment_pass(unet, hs)
+            anchors[f0] = [b.global_tokens for b in unet.blocks]
+
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()] if use_streams else None
+        for _ in range(2):                                       # two denoising steps: the second meets warm caches
+            chunks = sch.run_step(unet, sc, n_frames, process, streams=streams)
+            assert all(getattr(b, "global_tokens", None) is None for b in unet.blocks)
+        torch.cuda.synchronize()
+        res[use_streams] = ({k: [o.float().cpu() for o in v] for k, v in outs.items()},
+                            {k: [a.float().cpu() for a in v] for k, v in anchors.items()},
+                            [b.generator.get_state() for b in unet.blocks], [len(c) for c in chunks])
+        vidtome_amd.remove_patch(unet)
+    assert res[False][3] == res[True][3] and res[False][0].keys() == res[True][0].keys()
+    for k in res[False][0]:
+        for a, b in zip(res[False][0][k], res[True][0][k]):
+            assert torch.equal(a, b), k
+        for a, b in zip(res[False][1][k], res[True][1][k]):
+            assert torch.equal(a, b), k
+    for a, b in zip(res[False][2], res[True][2]):
+        assert torch.equal(a, b)
+
+
 def test_projection_paths_agree(L):
     """The patched segment with its projections fed through the composed merge map (vtm_linear_rows), as panel GEMMs
     (vtm_gather_panels / vtm_layernorm_panels + vtm_linear_panels) and in the default mix of the two ("auto": rows at

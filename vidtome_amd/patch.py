@@ -386,6 +386,25 @@ def _pnp_share_groups(attn: torch.nn.Module) -> int:
     return 1
 
 
+def _built_here(device):
+    """(event, stream id) behind a cached device tensor that was just built on the current stream: a chunk on ANOTHER stream may
+    be the next to use it (scheduler.run_step(streams=...): the first two chunks of a run meet the caches empty) ..."""
+    if not torch.cuda.is_available() or torch.device(device).type != "cuda":
+        return None
+    st = torch.cuda.current_stream(device)
+    ev = torch.cuda.Event()
+    ev.record(st)
+    return ev, st.cuda_stream
+
+
+def _built_before(mark, device) -> None:
+    """... and waits for the build on the device before its own kernels read the tensor (same stream: nothing to do)."""
+    if mark is not None:
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream != mark[1]:
+            cur.wait_event(mark[0])
+
+
 def _fused_weights(attn: torch.nn.Module, dtype, device):
     """[Wq; Wk] stacked once per module (one projection GEMM for q and k), cached on the module."""
     cache = attn.__dict__.get("_vtm_wcache")
@@ -398,8 +417,9 @@ def _fused_weights(attn: torch.nn.Module, dtype, device):
             zq = attn.to_q.bias if attn.to_q.bias is not None else torch.zeros_like(attn.to_q.weight[:, 0])
             zk = attn.to_k.bias if attn.to_k.bias is not None else torch.zeros_like(attn.to_k.weight[:, 0])
             bqk = torch.cat([zq, zk]).to(device=device, dtype=dtype)
-        cache = (key, wqk, bqk)
+        cache = (key, wqk, bqk, _built_here(device))
         attn.__dict__["_vtm_wcache"] = cache
+    _built_before(cache[3], device)
     return cache[1], cache[2]
 
 
@@ -815,8 +835,11 @@ def _packed(module: torch.nn.Module, key: str, build):
     params = [p for p in module.parameters()]
     tag = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
     hit = cache.get(key)
+    dev = params[0].device if params else None
     if hit is None or hit[0] != tag:
-        hit = cache[key] = (tag, build())
+        hit = cache[key] = (tag, build(), _built_here(dev) if dev is not None else None)
+    if dev is not None:
+        _built_before(hit[2], dev)
     return hit[1]
 
 
