@@ -316,7 +316,7 @@ class KernelTimer:
         # attention_kv(q, k, vt, heads, Mq, Mk, scale): 4 * B * Mq * Mk * C executed flops
         # (with a device-side query bound the executed rows are the per-sample counts, rounded up to whole query blocks
         # of 256 (d <= 48) / 512 (d <= 96) / 128 queries: read back AFTER the timed region)
-        def kv_flops(q, k, vt, heads, Mq, Mk, scale, use_workspace=True, q_count=None, k_fold=None):
+        def kv_flops(q, k, vt, heads, Mq, Mk, scale, use_workspace=True, q_count=None, k_fold=None, share_groups=1):
             self.ref_flops += 4.0 * q.shape[0] * (Mk * Mk if Mq > 256 and Mk > Mq else Mq * Mk) * q.shape[2]
             if q_count is None and k_fold is None:
                 return 4.0 * q.shape[0] * Mq * Mk * q.shape[2]

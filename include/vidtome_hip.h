@@ -347,6 +347,14 @@ int vtm_attention_kv_bounded(const void *q, int64_t ldq, const void *k, int64_t 
                              void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
                              int64_t Mk, int64_t Mkp, int64_t d, float scale, const int32_t *q_count, void *ws,
                              size_t ws_bytes, vtm_stream_t stream);
+/* ... and with shared probabilities (pnp_utils.py:57-67, 75-90) on top: the probabilities of sample b come from q / k of sample
+ * b % (B / share_groups), v stays per sample, and every sample of a group has the SAME live rows (align_batch: one index set
+ * for the batch, merge.py:73-76), so q_count[b % (B / share_groups)] bounds them all.  q_count has B entries; the first
+ * B / share_groups are read.  Workspace: vtm_attention_ws_bytes. */
+int vtm_attention_kv_shared_bounded(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+                                    void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
+                                    int64_t Mk, int64_t Mkp, int64_t d, float scale, int share_groups,
+                                    const int32_t *q_count, void *ws, size_t ws_bytes, vtm_stream_t stream);
 /* workspace of a vtm_attention_kv_bounded launch: with a device-side query count the launch cannot plan its rounds, so every
  * work item is split in two along the key axis (one partial record per workgroup, merged by a second kernel); with less
  * workspace than this the launch falls back to the plain plan of vtm_attention_ws_bytes */

@@ -2514,6 +2514,41 @@ def test_attention_device_planned_tail_every_live_fraction(L, d, h):
         assert rec <= 7 * slots and split_items <= slots, (d, f0, f1, plan)
 
 
+@pytest.mark.parametrize("d,h,groups", [(40, 8, 3), (40, 8, 2), (80, 8, 3), (64, 5, 3)])
+def test_attention_shared_probabilities_with_a_query_bound(L, d, h, groups):
+    """vtm_attention_kv_shared_bounded (round 6): the PnP shared-probability launch (pnp_utils.py:57-67, 75-90: q / k of the
+    source sample, v per sample) on compacted live queries -- under align_batch every sample of a group has the same live
+    rows, so one count bounds the group (merge.py:439-460 reads nothing else).  Rows below the count equal the plain shared
+    launch (attention16g at d = 40: the probabilities once per group; attention_kernel elsewhere: the device-planned tail)
+    and, directly, softmax(q_src k_src^T) v_b in fp32; every count from a full launch down to one block."""
+    B, Mq, Mk = groups, 19456, 2100
+    C = h * d
+    g = torch.Generator(device=DEV).manual_seed(17)
+    q = torch.randn(B, Mq, C, generator=g, device=DEV, dtype=torch.float16)
+    k = torch.randn(B, (Mk + 7) // 8 * 8, C, generator=g, device=DEV, dtype=torch.float16)
+    vt = torch.randn(B, C, (Mk + 7) // 8 * 8, generator=g, device=DEV, dtype=torch.float16)
+    full = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5, share_groups=groups)
+    scale = float(full.float().abs().max())
+    # fp32 statement of a few rows: probabilities of the SOURCE sample (sample 0), values of sample b
+    rows = torch.tensor([0, 1, 255, 256, 4097, 12345, Mq - 1], device=DEV)
+    for hd in (0, h - 1):
+        qs = q[0, rows, hd * d:(hd + 1) * d].float()
+        ks = k[0, :Mk, hd * d:(hd + 1) * d].float()
+        p = torch.softmax(qs @ ks.t() * d ** -0.5, dim=-1)
+        for b in range(B):
+            ref = p @ vt[b, hd * d:(hd + 1) * d, :Mk].float().t()
+            assert (full[b, rows, hd * d:(hd + 1) * d].float() - ref).abs().max() < 2e-3 * scale, (d, b, hd)
+    for frac in (1.0, 0.93, 0.78, 0.5, 0.27, 0.01):
+        n = max(1, int(Mq * frac))
+        count = torch.full((B,), n, dtype=torch.int32, device=DEV)
+        got = L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5, q_count=count, share_groups=groups)
+        assert torch.isfinite(got[:, :n]).all(), (d, frac)
+        assert (got[:, :n].float() - full[:, :n].float()).abs().max() < 2e-3 * scale, (d, frac)
+    with pytest.raises(RuntimeError):          # folded keys do not go with shared probabilities
+        L.attention_kv(q, k, vt, h, Mq, Mk, d ** -0.5, share_groups=groups,
+                       k_fold=(torch.full((B,), Mk, dtype=torch.int32, device=DEV), torch.zeros(B, Mk, dtype=torch.int32, device=DEV)))
+
+
 def test_attention_bounded_split_all_vs_plain(L, monkeypatch):
     """A query-bounded launch that fills at least two rounds of the chip splits EVERY work item in two along the key axis
     (split-major order, partial records merged by attention_combine_kernel): its rows below the per-sample count must
@@ -2753,6 +2788,82 @@ def test_cfg3_pnp_batch3_aligned_full_size(L, oracle):
         y2 = vpatch.self_attention(blk.attn1, x2)
     assert torch.allclose(y2[0], y2[1]) and torch.allclose(y2[0], y2[2]) and torch.allclose(y[0], y2[0])
     vidtome_amd.remove_patch(unet)
+
+
+def test_pnp_shared_probabilities_take_the_live_query_rows(L, oracle):
+    """Round 6: with align_batch the levels' indices -- hence the live query rows of a global level whose local chunk is
+    the src side (merge.py:439-460: only the local tokens' outputs are ever read) -- are the same rows in every sample, so
+    the PnP shared-probability attention (pnp_utils.py:57-67, 75-90: q / k of the source sample, v per sample) computes
+    the live rows only, like the un-shared path (cfg-3 attention 46.5 -> 35.8 ms).  `global_rand=0` puts the local chunk
+    on the src side of every global level.  Checked: the shared launch really ran on a compacted query list; block outputs
+    equal the full-layout run (VIDTOME_LIVE_QUERIES=0) to 1e-3 of the output scale and the oracle's shared-probability
+    rows at sampled positions; without align_batch the full layout is kept."""
+    import vidtome_amd
+    from vidtome_amd import _lib
+    from vidtome_amd import patch as vpatch
+    from vidtome_amd import sites as S
+    B, F, latent = 3, 8, (32, 32)
+    sl = [s for s in S.sd15_sites() if s.name in ("up3.0", "up2.0")]
+    res = {}
+    keep_live, orig_kv = vpatch.LIVE_QUERIES, _lib.attention_kv
+    try:
+        for aligned, live in ((True, True), (True, False), (False, True)):
+            vpatch.LIVE_QUERIES = live
+            unet = S.SiteUNet(sl, seed=4).to(device=DEV, dtype=torch.float16)
+            for blk in unet.blocks:      # what pnp.register_attention_control sets on the decoder blocks
+                blk.attn1.injection_schedule, blk.attn1.t, blk.attn1.vtm_num_inputs = [981], 981, B
+            vidtome_amd.apply_patch(unet, local_merge_ratio=0.5, merge_global=True, global_merge_ratio=0.5, batch_size=B,
+                                    align_batch=aligned, global_rand=0.0)
+            unet.set_size(latent)
+            torch.manual_seed(7)
+            shared_kv = []
+
+            def spy(q, k, vt, heads, Mq, Mk, scale, *a, **kw):
+                if kw.get("share_groups", 1) != 1:
+                    shared_kv.append((Mq, Mk))
+                return orig_kv(q, k, vt, heads, Mq, Mk, scale, *a, **kw)
+
+            _lib.attention_kv = spy
+            passes = []
+            for c in range(2):           # chunk 0 leaves the anchors, chunk 1 merges with them
+                hiddens = [S.synthetic_hidden(s_, B, F, latent, torch.float16, DEV, seed=90 + 10 * c + i, clip_seed=3 + i, regime="corr01")
+                           for i, s_ in enumerate(sl)]
+                seen, orig_cm = {}, vpatch.compute_merge
+
+                def rec(module, x, info, **kw):
+                    r = orig_cm(module, x, info, **kw)
+                    seen[id(module)] = r[0].plan
+                    return r
+
+                vpatch.compute_merge = rec
+                try:
+                    with torch.no_grad():
+                        outs = S.run_segment_pass(unet, hiddens)
+                finally:
+                    vpatch.compute_merge = orig_cm
+                plans = [seen[id(blk)] for blk in unet.blocks]
+                assert all(bool(torch.isfinite(o).all()) for o in outs)
+                assert all((p.global_level is not None) == (c == 1) for p in plans)
+                passes.append((hiddens, outs, plans))
+            _lib.attention_kv = orig_kv
+            torch.cuda.synchronize()
+            res[(aligned, live)] = (passes, list(shared_kv))
+            if aligned and live:
+                hiddens, outs, plans = passes[1]
+                for i in range(len(sl)):
+                    assert plans[i].q_rows is not None and plans[i].aligned
+                    assert torch.equal(plans[i].q_rows[0], plans[i].q_rows[1]) and torch.equal(plans[i].q_rows[0], plans[i].q_rows[2])
+                    _block_rows_vs_oracle(oracle, unet.blocks[i], plans[i], hiddens[i], outs[i], F, share=B, seed=i)
+            vidtome_amd.remove_patch(unet)
+    finally:
+        vpatch.LIVE_QUERIES, _lib.attention_kv = keep_live, orig_kv
+    # the shared launches of chunk 1 ran on the local rows only (Mq = the local merged tokens < Mk), one per site
+    assert len(res[(True, True)][1]) == len(sl) and all(mq < mk for mq, mk in res[(True, True)][1])
+    assert res[(True, False)][1] == [] and res[(False, True)][1] == []
+    for (_, oa, _), (_, ob, _) in zip(res[(True, True)][0], res[(True, False)][0]):
+        for a, b in zip(oa, ob):
+            scale = float(b.float().abs().max())
+            assert float((a.float() - b.float()).abs().max()) <= 1e-3 * scale
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -70,6 +70,8 @@ _SIGNATURES = {
                           _f32, _int, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_attention_kv_bounded": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                   _f32, _vp, _vp, ctypes.c_size_t, _vp], _int),
+    "vtm_attention_kv_shared_bounded": ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                         _f32, _int, _vp, _vp, ctypes.c_size_t, _vp], _int),
     "vtm_attention_kv_bounded_ws_bytes": ([_i64, _i64, _i64, _i64, _i64], ctypes.c_size_t),
     "vtm_anchor_maps": ([_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp], _int),
     "vtm_transpose_cols": ([_vp, _i64, _int, _i64, _i64, _i64, _vp, _i64, _vp], _int),
@@ -598,10 +600,10 @@ def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
     q_count[b] query rows of sample b are meaningful (compact_queries); the other rows of the result are undefined.
     ``k_fold`` = (k_count (B,) int32, k_bias (B, >= Mk) uint32 pairs) from fold_keys: k / vt hold a duplicate-free key
     list, only the first k_count[b] entries are keys, each standing for 2^bias identical ones (head dims 8 and 40).
-    ``share_groups`` > 1 (plain launches only): the probabilities of the first B / share_groups samples serve every group
-    (pnp_utils.py:57-67)."""
-    if share_groups != 1 and (q_count is not None or k_fold is not None):
-        raise RuntimeError("attention_kv: shared probabilities go with the plain launch only")
+    ``share_groups`` > 1: the probabilities of the first B / share_groups samples serve every group (pnp_utils.py:57-67);
+    with ``q_count`` the caller vouches that every sample of a group has the same live rows (align_batch) -- no key folding."""
+    if share_groups != 1 and k_fold is not None:
+        raise RuntimeError("attention_kv: shared probabilities do not go with folded keys")
     B, Mqp, C = q.shape
     Mkp = k.shape[1]
     d = C // heads
@@ -612,12 +614,18 @@ def attention_kv(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
     out = torch.zeros((B, Mqp, C), dtype=q.dtype, device=q.device) if Mqp != Mq else \
         torch.empty((B, Mqp, C), dtype=q.dtype, device=q.device)
     ws, nb = _attention_ws(B, heads, Mq, Mk, d, q.device) if use_workspace else (None, 0)
-    if q_count is not None and use_workspace and SPLIT_ALL_BOUNDED:
-        nb2 = int(lib().vtm_attention_kv_bounded_ws_bytes(B, heads, Mq, Mk, d))
-        if nb2 > 0:
-            ws, nb = _workspace("attention", nb2, q.device), nb2
     if q_count is not None and (q_count.dtype != torch.int32 or q_count.numel() != B or not q_count.is_cuda):
         raise RuntimeError("attention_kv: q_count must be a (B,) int32 device tensor")
+    if q_count is not None and use_workspace and SPLIT_ALL_BOUNDED:
+        nb2 = int(lib().vtm_attention_kv_bounded_ws_bytes(B, heads, Mq, Mk, d))
+        if nb2 > nb:
+            ws, nb = _workspace("attention", nb2, q.device), nb2
+    if share_groups != 1 and q_count is not None:
+        _check(lib().vtm_attention_kv_shared_bounded(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), vt.data_ptr(),
+                                                     vt.stride(1), out.data_ptr(), C, dtype_code(q), B, heads, Mq, Mqp, Mk, Mkp,
+                                                     d, float(scale), int(share_groups), _ptr(q_count), _ptr(ws), nb, _stream()),
+               "vtm_attention_kv_shared_bounded")
+        return out
     if k_fold is not None:
         k_count, k_bias = k_fold
         if k_count.dtype != torch.int32 or k_count.numel() != B or k_bias.dtype != torch.int32 or k_bias.dim() != 2 \

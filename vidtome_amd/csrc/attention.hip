@@ -922,6 +922,18 @@ VTM_EXPORT int vtm_attention_kv_bounded(const void *q, int64_t ldq, const void *
                          q_count, stream);
 }
 
+VTM_EXPORT int vtm_attention_kv_shared_bounded(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
+                                               void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
+                                               int64_t Mk, int64_t Mkp, int64_t d, float scale, int share_groups,
+                                               const int32_t *q_count, void *ws, size_t ws_bytes, vtm_stream_t stream) {
+    VTM_REQUIRE(q_count, "vtm_attention_kv_shared_bounded: null q_count");
+    VTM_REQUIRE(share_groups >= 1 && B % share_groups == 0, "vtm_attention_kv_shared_bounded: B %% share_groups != 0");
+    // (d = 40, 2 or 3 groups: attention16g computes the probabilities once per group and reads the source sample's count;
+    // other shapes: attention_kernel recomputes them per sample and reads every sample's own -- equal -- count)
+    return attention_any(q, ldq, k, ldk, vt, ldvt, out, ldo, dtype, B, h, Mq, Mqp, Mk, Mkp, d, scale, share_groups, ws, ws_bytes,
+                         q_count, stream);
+}
+
 VTM_EXPORT int vtm_attention_kv_folded(const void *q, int64_t ldq, const void *k, int64_t ldk, const void *vt, int64_t ldvt,
                                        void *out, int64_t ldo, int dtype, int64_t B, int64_t h, int64_t Mq, int64_t Mqp,
                                        int64_t Mk, int64_t Mkp, int64_t d, float scale, const int32_t *q_count,

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention16g_kernel(
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
     int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t nwhole,
-    int nsplit_tail, float *__restrict__ partial_base, int xcd_groups) {
+    int nsplit_tail, float *__restrict__ partial_base, int xcd_groups, const int32_t *__restrict__ q_count) {
     using F = Frag<T>;
     using vec = typename F::vec;
     using elem = typename F::elem;
@@ -58,6 +58,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention16g_kernel(
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;   // b: a SOURCE sample; the groups are the samples b + g * src_batch
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
     const int64_t C = H * D;
+    // a device-side query bound (compacted live queries, the same rows in every sample of the group): blocks beyond the source
+    // sample's count leave at once, the key-split pieces of such a block too (the combine kernel skips their records)
+    if (q_count != nullptr && (lin % nqb) * QB >= (int64_t)q_count[b]) return;
 
     for (int i = tid; i < KR * KV * (K_STRIDE - D); i += NT) {
         const int row = i / (K_STRIDE - D), c = D + i % (K_STRIDE - D);
@@ -430,11 +433,11 @@ int launch16g(const Args16 &a) {
     const int xcd_groups = ((src_batch * a.h) % 8 == 0 && p.nqb >= 32) ? (int)(src_batch * a.h / 8) : 0;
     hipLaunchKernelGGL((attention16g_kernel<T, D, NG, WAVES>), dim3((unsigned)(p.full + rem * p.nsplit)), dim3(NT), lds, a.s,
                        (const T *)a.q, a.ldq, (const T *)a.k, a.ldk, (const T *)a.vt, a.ldvt, (T *)a.out, a.ldo, a.h, a.M, a.Mp,
-                       a.Mk, a.Mkp, scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)a.ws, xcd_groups);
+                       a.Mk, a.Mkp, scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)a.ws, xcd_groups, a.q_count);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((attention16_combine_kernel<T, D, 1, NG, WAVES>), dim3((unsigned)rem, (unsigned)NV), dim3(NT), 0, a.s,
                            (const float *)a.ws, (T *)a.out, a.ldo, a.h, a.M, a.Mp, p.nqb, p.full, p.nsplit, xcd_groups,
-                           (const int32_t *)nullptr, src_batch, (const DevPlan *)nullptr);
+                           a.q_count, src_batch, (const DevPlan *)nullptr);
     return vtm::launch_status("vtm_attention");
 }
 

@@ -53,7 +53,7 @@ class MergePlan:
     """What ``compute_merge`` produces for one block call: composed maps + the merged tokens."""
 
     __slots__ = ("fsize", "L", "M", "gather_map", "_inv", "_inv_parts", "_merged", "levels", "global_level", "local_chunk",
-                 "x_joined", "anchors_in", "q_rows", "inv_q", "q_count", "pad_to", "fold_args", "_key_fold")
+                 "x_joined", "anchors_in", "q_rows", "inv_q", "q_count", "pad_to", "fold_args", "_key_fold", "aligned")
 
     def __init__(self):
         self.levels = []
@@ -74,6 +74,7 @@ class MergePlan:
         self.q_rows = None
         self.inv_q = None
         self.q_count = None
+        self.aligned = False            # align_batch: every sample shares the levels' indices (so also q_rows / inv_q)
         # The anchors' exact duplicates (patch.py:80 copies an anchor row to every local token that merged into it) are
         # duplicate KEYS of the next block: (merged-position -> pool row map, L, content id per anchor row, number of ids)
         # when the anchors carry ids, folded on first use by the attention path that can take a per-key multiplicity
@@ -228,6 +229,7 @@ def compute_merge(module: torch.nn.Module, x: torch.Tensor, tome_info: Dict[str,
 
     plan = MergePlan()
     plan.fsize = fsize
+    plan.aligned = bool(args["align_batch"])
     # chunk-parallel runs (chunk_parallel.py): the exchange replays the draws of the chunks other ranks process
     # and posts the receive of the predecessor's anchor tokens before this block's own first draw
     exchange = getattr(module, "_vtm_exchange", None)
@@ -536,8 +538,7 @@ def self_attention_panels(attn: torch.nn.Module, x0: torch.Tensor, x1: Optional[
     heads = attn.heads
     scale = getattr(attn, "scale", None) or (C // heads) ** -0.5
     share = _pnp_share_groups(attn)
-    if q_rows is not None and share != 1:
-        raise RuntimeError("q_rows cannot be combined with the PnP shared-probability mode")
+    # (q_rows under PnP sharing: the caller vouches that every sample of a group has the same rows -- align_batch)
     Mpad = _lib.panel_rows(M)
     xp = _lib.gather_panels(x0, x1, rows, None, M)                       # (C / 8, B * Mpad, 8)
     wq, bq = _panel_weight(attn.to_q)
@@ -557,7 +558,7 @@ def self_attention_panels(attn: torch.nn.Module, x0: torch.Tensor, x1: Optional[
         Mqpad = _lib.panel_rows(Mq)
         qp = _lib.gather_panels(x0, x1, rows, q_rows, Mq)
         q_op = _lib.linear_panels(qp, B * Mqpad, wq, C, bq).view(B, Mqpad, C)
-        o = _lib.attention_kv(q_op, k_op, vt, heads, Mq, M, scale, q_count=q_count)
+        o = _lib.attention_kv(q_op, k_op, vt, heads, Mq, M, scale, q_count=q_count, share_groups=share)
     wo, bo = _panel_weight(_out_linear(attn))
     op = _lib.to_panels(o.view(B * Mqpad, C))
     return _lib.linear_panels(op, B * Mqpad, wo, C, bo).view(B, Mqpad, C)
@@ -640,8 +641,7 @@ def self_attention_rows(attn: torch.nn.Module, x0: torch.Tensor, x1: Optional[to
     heads = attn.heads
     scale = getattr(attn, "scale", None) or (C // heads) ** -0.5
     share = _pnp_share_groups(attn)
-    if q_rows is not None and share != 1:
-        raise RuntimeError("q_rows cannot be combined with the PnP shared-probability mode")
+    # (q_rows under PnP sharing: the caller vouches that every sample of a group has the same rows -- align_batch)
     dt = x0.dtype
     wqk, bqk = _fused_weights(attn, dt, x0.device)
     bv = getattr(attn.to_v, "bias", None)
@@ -668,7 +668,7 @@ def self_attention_rows(attn: torch.nn.Module, x0: torch.Tensor, x1: Optional[to
         Mq = q_rows.shape[1]
         k_op = _lib.linear_rows(x0, x1, rows, None, M, wqk[C:], None if bqk is None else bqk[C:])
         q_op = _lib.linear_rows(x0, x1, rows, q_rows, Mq, wqk[:C], None if bqk is None else bqk[:C])
-        o = _lib.attention_kv(q_op, k_op, vt, heads, Mq, M, scale, q_count=q_count)
+        o = _lib.attention_kv(q_op, k_op, vt, heads, Mq, M, scale, q_count=q_count, share_groups=share)
     to_out = _out_linear(attn)
     return _lib.linear_rows(o, None, None, None, Mq, _weight(to_out, dt), None if to_out.bias is None else to_out.bias.to(dt))
 
@@ -691,8 +691,7 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
     heads = attn.heads
     scale = getattr(attn, "scale", None) or (C // heads) ** -0.5
     share = _pnp_share_groups(attn)
-    if q_rows is not None and share != 1:
-        raise RuntimeError("q_rows cannot be combined with the PnP shared-probability mode")
+    # (q_rows under PnP sharing: the caller vouches that every sample of a group has the same rows -- align_batch)
     if x.shape[1] % 8:
         # keep the transposed V (B, C, Mp) 16-byte aligned per row
         pad = 8 - x.shape[1] % 8
@@ -729,7 +728,7 @@ def self_attention(attn: torch.nn.Module, x: torch.Tensor, M: Optional[int] = No
     if q_rows is None:
         o = _lib.attention(q_op, k_op, vt, heads, M, scale, share)
     else:
-        o = _lib.attention_kv(q_op, k_op, vt, heads, q_rows.shape[1], M, scale, q_count=q_count)
+        o = _lib.attention_kv(q_op, k_op, vt, heads, q_rows.shape[1], M, scale, q_count=q_count, share_groups=share)
         # (q_count: rows past the count are undefined; the output projection is row-wise, so they stay confined to
         # rows unmerge() never reads)
     to_out = _out_linear(attn)
@@ -932,9 +931,10 @@ def patched_self_attention_segment(block: torch.nn.Module, hidden_states: torch.
                                   encoder_hidden_states=encoder_hidden_states if block.only_cross_attention else None,
                                   attention_mask=attention_mask, **cross_attention_kwargs)
     else:
-        # (PnP injection reads the source sample's q for every group: it keeps the full, aligned layout)
+        # (PnP injection reads the source sample's q for every group: the live rows must be the same rows in every sample,
+        # which align_batch guarantees -- the levels' indices are computed once on the batch-folded tokens, merge.py:73-76)
         live = (plan is not None and plan.q_rows is not None and gate_msa is None and LIVE_QUERIES
-                and _pnp_share_groups(block.attn1) == 1)
+                and (_pnp_share_groups(block.attn1) == 1 or plan.aligned))
         q_rows = plan.q_rows if live else None
         q_count = plan.q_count if live else None
         if by_rows or by_panels:
