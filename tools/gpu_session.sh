@@ -31,6 +31,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py --steps 7 --warmup 1 --no-cpu-baseline --regimes none --workloads none --no-inflight-line > $O/prof.log 2>&1; echo "prof rc=$?"
 grep '"metric"' $O/prof.log > $O/bench_profiled.json
 python $R/profiles/summarize_rocpd.py $O/prof/k_results.db > $O/kernel_stats.txt 2>&1; rm -f $O/prof/k_results.db
+rocprofv3 --kernel-trace --stats -d $O/prof3 -o k -- python $R/bench.py --workload cfg3 --steps 7 --warmup 1 --no-cpu-baseline --regimes none --workloads none --no-inflight-line > $O/prof3.log 2>&1; echo "prof cfg3 rc=$?"
+python $R/profiles/summarize_rocpd.py $O/prof3/k_results.db > $O/kernel_stats_cfg3.txt 2>&1; rm -rf $O/prof3
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc -o sq_attn --output-format csv -- python $R/tools/kbench.py attn --Mq 34816 --M 52224 --d 40 --iters 3 > $O/pmc_sq_attn.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc -o sq_match --output-format csv -- python $R/tools/kbench.py match --shape top_l1 --data corr01 --iters 3 > $O/pmc_sq_match.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc -o sq_ff --output-format csv -- python $R/tools/kbench.py ff --n 131072 --C 320 --iters 3 > $O/pmc_sq_ff.log 2>&1
