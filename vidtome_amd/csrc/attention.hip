@@ -836,7 +836,7 @@ static size_t ws16_max(int64_t B, int64_t h, int64_t Mq, int64_t Mk, bool bounde
     Shape16 sh;
     for (int sg = 1; sg <= 3; ++sg)
         if (B % sg == 0 && shape16_for(40, sg, false, &sh)) {
-            const size_t w = ws_bytes16(sh, sh.ng > 1 ? B / sg : B, h, Mq, Mk, bounded && sg == 1);
+            const size_t w = ws_bytes16(sh, sh.ng > 1 ? B / sg : B, h, Mq, Mk, bounded);
             n = w > n ? w : n;
         }
     return n;

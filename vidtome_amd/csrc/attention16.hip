@@ -867,17 +867,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention16s_kernel(
         write_output16<T, D>(o16[sub], out, ldo, b, h, qblock0 + (wave * NQ + sub) * QW, M, Mp, lane);
 }
 
-// workspace of a device-planned launch: the plan (one cache line) + the records of the largest tail a plan can have
-constexpr size_t DEVPLAN_HEADER = 256;
-static_assert(sizeof(DevPlan) <= 256, "the plan lives in the workspace header");
-size_t devplan_ws_bytes(int slots, size_t rec_bytes) { return DEVPLAN_HEADER + (size_t)plan_tail_wgs(slots) * rec_bytes; }
-bool devplan_enabled() {
-    static const bool on = [] {
-        const char *e = getenv("VTM_ATT_DEVPLAN");        // A/B hook, read once per process (attention.hip reads the same name)
-        return e == nullptr || atoi(e) != 0;
-    }();
-    return on;
-}
 
 template <typename T, int D, bool FOLD, int NQ, int NG, int WAVES, bool SKEW>
 int launch16(const Args16 &a) {
@@ -1009,7 +998,7 @@ size_t ws_bytes16(const Shape16 &sh, int64_t B_items, int64_t h, int64_t Mq, int
     const int NT = sh.waves * 64;
     const size_t rec = (size_t)sh.nq * sh.ng * rec16<40>() * NT * sizeof(float);
     const int wg_cu = wg_per_cu16(sh.nq, sh.ng, sh.waves);
-    if (sh.ng > 1 && sh.skew) return ws_bytes16g(sh.ng, B_items, h, Mq, Mk);
+    if (sh.ng > 1 && sh.skew) return ws_bytes16g(sh.ng, B_items, h, Mq, Mk, bounded);
     size_t n = plan_tail16(B_items, h, Mq, Mk, (int64_t)sh.waves * QW * sh.nq, wg_cu, rec, bounded).ws_bytes;
     if (bounded && sh.skew && devplan_enabled()) n = std::max(n, devplan_ws_bytes(vtm::device_cus() * wg_cu, rec));
     return n;

@@ -1,6 +1,7 @@
 // Internal pieces shared by the two wide-tile d = 40 translation units (attention16.hip, attention16g.hip): the partial record of a
 // key-split workgroup, the device-side launch plan of query-bounded launches and the kernel that combines the records.
 #pragma once
+#include <cstdlib>
 #include "attention_common.h"
 
 namespace {
@@ -127,6 +128,18 @@ __global__ __launch_bounds__(WAVES * 64) void attention16_combine_kernel(
 #pragma unroll
     for (int r = 0; r < NA; ++r) o[r >> 3][(r >> 2) & 1][r & 3] = acc[r];
     write_output16<T, D>(o, out, ldo, b + g * src_batch, h, q0, M, Mp, lane);
+}
+
+// workspace of a device-planned launch: the plan (one cache line) + the records of the largest tail a plan can have
+constexpr size_t DEVPLAN_HEADER = 256;
+static_assert(sizeof(DevPlan) <= 256, "the plan lives in the workspace header");
+inline size_t devplan_ws_bytes(int slots, size_t rec_bytes) { return DEVPLAN_HEADER + (size_t)plan_tail_wgs(slots) * rec_bytes; }
+inline bool devplan_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("VTM_ATT_DEVPLAN");        // A/B hook, read once per process and translation unit
+        return e == nullptr || atoi(e) != 0;
+    }();
+    return on;
 }
 
 }  // namespace

@@ -15,6 +15,7 @@
 // attention16_kernel / attention_kernel's PV16 path.
 #include "attention16_parts.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -25,7 +26,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention16g_kernel(
     const T *__restrict__ q, int64_t ldq, const T *__restrict__ k, int64_t ldk,
     const T *__restrict__ vt, int64_t ldvt, T *__restrict__ out, int64_t ldo, int64_t H,
     int64_t M, int64_t Mp, int64_t Mk, int64_t Mkp, float scale_log2e, int64_t src_batch, int64_t nqb, int64_t nwhole,
-    int nsplit_tail, float *__restrict__ partial_base, int xcd_groups, const int32_t *__restrict__ q_count) {
+    int nsplit_tail, float *__restrict__ partial_base, int xcd_groups, const int32_t *__restrict__ q_count,
+    const DevPlan *__restrict__ dev_plan) {
     using F = Frag<T>;
     using vec = typename F::vec;
     using elem = typename F::elem;
@@ -48,13 +50,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention16g_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int l15 = lane & 15, g16 = lane >> 4;
+    // query-bounded launch planned on the device (attention16_plan_kernel, see attention16s_kernel): the roles of the workgroups
+    // behind the whole items come from the plan's tiers (wave-uniform loads); inside a tier all first pieces, then all second ...
+    int64_t tier_item0 = nwhole, tier_wg0 = nwhole, tier_rec0 = 0, split_major_items = 0;
+    if (dev_plan != nullptr) {
+        nqb = dev_plan->nqb;
+        xcd_groups = nqb >= 32 ? xcd_groups : 0;
+        int ti = 0;
+        while (ti + 1 < dev_plan->ntiers && (int)blockIdx.x >= dev_plan->tier[ti + 1].wg0) ++ti;
+        const DevTier tr = dev_plan->tier[ti];
+        if ((int64_t)blockIdx.x >= (int64_t)tr.wg0 + (int64_t)tr.items * tr.nsplit) return;   // behind the last tier
+        nwhole = dev_plan->tier[0].items;
+        nsplit_tail = tr.nsplit;
+        split_major_items = tr.items;
+        tier_item0 = tr.item0;
+        tier_wg0 = tr.wg0;
+        tier_rec0 = tr.rec0;
+    }
     const bool tail_wg = (int64_t)blockIdx.x >= nwhole;
-    const int64_t tail_id = (int64_t)blockIdx.x - nwhole;
+    const int64_t tail_id = (int64_t)blockIdx.x - tier_wg0;      // (host plan: one tier behind the whole items)
     const int nsplit = tail_wg ? nsplit_tail : 1;
-    const int64_t tail_item = tail_id / nsplit;
-    const int split = tail_wg ? (int)(tail_id % nsplit) : 0;
-    const int64_t lin = item_of(tail_wg ? nwhole + tail_item : (int64_t)blockIdx.x, nqb, xcd_groups);
-    float *partial = tail_wg ? partial_base + (tail_item * nsplit + split) * NV * REC * NT : nullptr;
+    const int64_t tail_item = split_major_items ? tail_id % split_major_items : tail_id / nsplit;
+    const int split = !tail_wg ? 0 : split_major_items ? (int)(tail_id / split_major_items) : (int)(tail_id % nsplit);
+    const int64_t lin = item_of(tail_wg ? tier_item0 + tail_item : (int64_t)blockIdx.x, nqb, xcd_groups);
+    float *partial = tail_wg ? partial_base + (tier_rec0 + tail_item * nsplit + split) * NV * REC * NT : nullptr;
     const int64_t b = lin / (nqb * H), h = (lin / nqb) % H;   // b: a SOURCE sample; the groups are the samples b + g * src_batch
     const int64_t q0 = (lin % nqb) * QB + wave * QW;
     const int64_t C = H * D;
@@ -422,6 +441,31 @@ int launch16g(const Args16 &a) {
     }
     const int64_t src_batch = a.B / a.share_groups;
     const size_t rec_bytes = (size_t)NV * rec16<D>() * NT * sizeof(float);
+    {
+        // query-bounded (vtm_attention_kv_shared_bounded): planned on the device like attention16s_kernel's bounded launches --
+        // the count is a device value, a host plan for Mq rows leaves the last round of the LIVE items mostly idle
+        // (34 816 rows, 0.78 live: 849 items on 256 slots took 4 rounds for 3.3 rounds of work)
+        const int slots = vtm::device_cus();       // one workgroup per CU
+        const int64_t nqb_max = vtm::cdiv(a.M, QB);
+        const size_t need = devplan_ws_bytes(slots, rec_bytes);
+        if (a.q_count != nullptr && a.ws != nullptr && a.ws_bytes >= need && devplan_enabled() && nqb_max * a.h * src_batch >= 2 * slots) {
+            DevPlan *plan = reinterpret_cast<DevPlan *>(a.ws);
+            float *records = reinterpret_cast<float *>(static_cast<char *>(a.ws) + DEVPLAN_HEADER);
+            const int xcd_pairs = (src_batch * a.h) % 8 == 0 ? (int)(src_batch * a.h / 8) : 0;
+            const float sl2e = a.scale * 1.4426950408889634f;
+            hipLaunchKernelGGL(attention16_plan_kernel, dim3(1), dim3(64), 0, a.s, a.q_count, (int)src_batch, (int)a.h, QB, slots,
+                               (int)vtm::cdiv(a.Mk, KV), plan);
+            const int64_t total = nqb_max * a.h * src_batch, tail_max = plan_tail_wgs(slots);
+            VTM_REQUIRE(total + tail_max < (1ll << 31) / 16, "vtm_attention: grid too large");
+            hipLaunchKernelGGL((attention16g_kernel<T, D, NG, WAVES>), dim3((unsigned)(total + tail_max)), dim3(NT), lds, a.s,
+                               (const T *)a.q, a.ldq, (const T *)a.k, a.ldk, (const T *)a.vt, a.ldvt, (T *)a.out, a.ldo, a.h, a.M, a.Mp,
+                               a.Mk, a.Mkp, sl2e, src_batch, nqb_max, total, 1, records, xcd_pairs, a.q_count, (const DevPlan *)plan);
+            hipLaunchKernelGGL((attention16_combine_kernel<T, D, 1, NG, WAVES>), dim3((unsigned)plan_split_items(slots), (unsigned)NV),
+                               dim3(NT), 0, a.s, (const float *)records, (T *)a.out, a.ldo, a.h, a.M, a.Mp, nqb_max, total, 1, xcd_pairs,
+                               a.q_count, src_batch, (const DevPlan *)plan);
+            return vtm::launch_status("vtm_attention");
+        }
+    }
     TailPlan p = plan_tail16(src_batch, a.h, a.M, a.Mk, QB, 1, rec_bytes, false);
     if (p.nsplit > 1 && (!a.ws || a.ws_bytes < p.ws_bytes)) {
         p.nsplit = 1;
@@ -433,7 +477,8 @@ int launch16g(const Args16 &a) {
     const int xcd_groups = ((src_batch * a.h) % 8 == 0 && p.nqb >= 32) ? (int)(src_batch * a.h / 8) : 0;
     hipLaunchKernelGGL((attention16g_kernel<T, D, NG, WAVES>), dim3((unsigned)(p.full + rem * p.nsplit)), dim3(NT), lds, a.s,
                        (const T *)a.q, a.ldq, (const T *)a.k, a.ldk, (const T *)a.vt, a.ldvt, (T *)a.out, a.ldo, a.h, a.M, a.Mp,
-                       a.Mk, a.Mkp, scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)a.ws, xcd_groups, a.q_count);
+                       a.Mk, a.Mkp, scale_log2e, src_batch, p.nqb, p.full, p.nsplit, (float *)a.ws, xcd_groups, a.q_count,
+                       (const DevPlan *)nullptr);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((attention16_combine_kernel<T, D, 1, NG, WAVES>), dim3((unsigned)rem, (unsigned)NV), dim3(NT), 0, a.s,
                            (const float *)a.ws, (T *)a.out, a.ldo, a.h, a.M, a.Mp, p.nqb, p.full, p.nsplit, xcd_groups,
@@ -445,10 +490,12 @@ int launch16g(const Args16 &a) {
 
 namespace vtm_att {
 
-size_t ws_bytes16g(int ng, int64_t src_batch, int64_t h, int64_t Mq, int64_t Mk) {
+size_t ws_bytes16g(int ng, int64_t src_batch, int64_t h, int64_t Mq, int64_t Mk, bool bounded) {
     constexpr int WAVES = 8, NT = WAVES * 64;
     const size_t rec = (size_t)ng * rec16<40>() * NT * sizeof(float);
-    return plan_tail16(src_batch, h, Mq, Mk, (int64_t)WAVES * QW, 1, rec, false).ws_bytes;
+    size_t n = plan_tail16(src_batch, h, Mq, Mk, (int64_t)WAVES * QW, 1, rec, false).ws_bytes;
+    if (bounded && devplan_enabled()) n = std::max(n, devplan_ws_bytes(vtm::device_cus(), rec));
+    return n;
 }
 
 int attention16g(const Args16 &a, int ng) {

@@ -190,7 +190,7 @@ TailPlan plan_tail16(int64_t B_items, int64_t h, int64_t Mq, int64_t Mk, int64_t
 size_t ws_bytes16(const Shape16 &sh, int64_t B_items, int64_t h, int64_t Mq, int64_t Mk, bool bounded);
 int attention16(const Args16 &a, const Shape16 &sh);
 // attention16g.hip: shared probabilities (ng = 2, 3 value groups), one-tile skew
-size_t ws_bytes16g(int ng, int64_t src_batch, int64_t h, int64_t Mq, int64_t Mk);
+size_t ws_bytes16g(int ng, int64_t src_batch, int64_t h, int64_t Mq, int64_t Mk, bool bounded);
 int attention16g(const Args16 &a, int ng);
 
 
